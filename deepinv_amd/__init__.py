@@ -1,0 +1,11 @@
+"""deepinv_amd — MI355X (gfx950) native forward/adjoint physics operators and the
+PnP / unfolded iteration loop that calls them, behind deepinv's own Python API.
+
+``import deepinv_amd as dinv`` then use ``dinv.physics.MRI``, ``dinv.optim.PGD`` … exactly as
+with the reference.  All arithmetic of the operators runs in hand-written HIP kernels reached
+through the C-ABI of ``libdeepinv_amd.so`` (``include/deepinv_amd.h``); there is no CPU path.
+"""
+__version__ = "0.1.0"
+
+from . import hip  # noqa: F401
+from . import physics  # noqa: F401

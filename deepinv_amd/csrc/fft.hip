@@ -1,0 +1,88 @@
+// FFT plan construction (host, fp64) and the generic one-axis complex FFT entry point.
+// Replaces torch.fft.fftn/ifftn (+fftshift/ifftshift) call sites of the reference:
+// deepinv/utils/mixins.py:159-180.
+#include <cmath>
+#include <vector>
+
+#include "fft_core.hpp"
+#include "fft_launch.hpp"
+
+using namespace dinv;
+
+extern "C" const char* dinv_last_error(void) { return err_buf(); }
+extern "C" int dinv_version(void) { return 1; }
+extern "C" int dinv_device_count(int* count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (count) *count = (e == hipSuccess) ? c : 0;
+    if (e != hipSuccess) return fail(100 + (int)e, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" size_t dinv_fft_table_bytes(int32_t n) { return n > 0 ? fft_table_bytes(n) : 0; }
+
+extern "C" int dinv_fft_plan_init(int32_t n, dinv_fft_plan* plan, void* host_table) {
+    DINV_REQUIRE(n >= 1, "fft length must be >= 1, got %d", n);
+    DINV_REQUIRE(plan != nullptr && host_table != nullptr, "null plan/table");
+    std::memset(plan, 0, sizeof(*plan));
+    plan->n = n;
+    // factorise: generic primes outermost, then 5, 3, then powers of two innermost so that the
+    // power-of-two stages see power-of-two sub-block lengths (shift/mask indexing).
+    std::vector<int> pow2, odd_small, primes;
+    int m = n, e = 0;
+    while (m % 2 == 0) { m /= 2; ++e; }
+    while (e >= 3) { pow2.push_back(8); e -= 3; }
+    if (e == 2) pow2.push_back(4);
+    if (e == 1) pow2.push_back(2);
+    while (m % 5 == 0) { odd_small.push_back(5); m /= 5; }
+    while (m % 3 == 0) { odd_small.push_back(3); m /= 3; }
+    for (int p = 7; (int64_t)p * p <= m; p += 2)
+        while (m % p == 0) { primes.push_back(p); m /= p; }
+    if (m > 1) primes.push_back(m);
+    std::vector<int> radix;
+    for (int p : primes) radix.push_back(p);
+    for (int p : odd_small) radix.push_back(p);
+    for (int p : pow2) radix.push_back(p);
+    if (radix.empty()) radix.push_back(1);  // n == 1: single trivial stage
+    DINV_REQUIRE((int)radix.size() <= DINV_MAX_STAGES, "fft length %d needs too many stages", n);
+    plan->nstages = (int)radix.size();
+    plan->generic = primes.empty() ? 0 : 1;
+    if (n == 1) plan->generic = 1;  // radix 1 goes through the generic stage (a copy)
+    for (size_t i = 0; i < radix.size(); ++i) plan->radix[i] = radix[i];
+
+    float* tw = reinterpret_cast<float*>(host_table);
+    int* perm = reinterpret_cast<int*>(tw + 2 * (size_t)n);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int t = 0; t < n; ++t) {
+        // exact octant reduction is unnecessary in fp64: |error| << fp32 ulp
+        double a = -two_pi * (double)t / (double)n;
+        tw[2 * t] = (float)std::cos(a);
+        tw[2 * t + 1] = (float)std::sin(a);
+    }
+    for (int idx = 0; idx < n; ++idx) {
+        int rem = idx, pos = 0, mcur = n;
+        for (size_t i = 0; i < radix.size(); ++i) {
+            int j = rem % radix[i];
+            rem /= radix[i];
+            mcur /= radix[i];
+            pos += j * mcur;
+        }
+        perm[idx] = pos;
+    }
+    return 0;
+}
+
+extern "C" int dinv_fft_c2c_axis(const float* in, float* out, int64_t outer, int64_t inner,
+                                 const dinv_fft_plan* plan, const void* table_dev, int32_t inverse,
+                                 int32_t centered, float scale, dinv_stream_t stream) {
+    DINV_REQUIRE(in && out && plan && table_dev, "null pointer argument");
+    DINV_REQUIRE(outer >= 0 && inner >= 1, "bad geometry outer=%lld inner=%lld", (long long)outer,
+                 (long long)inner);
+    if (outer == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    C2CIo io;
+    io.in = reinterpret_cast<const float2*>(in);
+    io.out = reinterpret_cast<float2*>(out);
+    if (inner == 1) return launch_rows<C2CIo>(io, outer, *plan, table_dev, inverse, centered, scale, s);
+    return launch_cols<C2CIo>(io, outer, inner, *plan, table_dev, inverse, centered, scale, s);
+}

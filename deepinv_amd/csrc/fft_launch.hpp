@@ -1,0 +1,182 @@
+// Kernel templates + launch helpers for one-axis FFT passes over HBM-resident tensors.
+//
+//   rows pass : tensor viewed [nlines, N], N contiguous.  A 256-thread workgroup owns `lpb`
+//               consecutive lines; 64 lanes run along N so every global access is a
+//               contiguous 256/512-byte wave transaction.
+//   cols pass : tensor viewed [P, N, Q], Q contiguous.  A workgroup owns an N x tq strip of
+//               one p; tq lanes run along Q (tq*8 B = 128 B segments for tq = 16).
+//
+// The `Io` functor (passed by value) fuses the pointwise work of the calling operator into
+// the load/store phase (coil-map multiply, mask multiply, planar<->interleaved layout
+// change), so each pass is exactly one read and one write of the tensor.
+#pragma once
+#include "fft_core.hpp"
+
+namespace dinv {
+
+// ------------------------------------------------------------------ plain complex IO
+struct C2CIo {
+    const float2* in;
+    float2* out;
+    struct RowCtx { int64_t base; };
+    struct ColCtx { int64_t base; int64_t q; };
+    int64_t n_, q_;  // filled by the launcher
+    __device__ __forceinline__ RowCtx row_ctx(int64_t line) const { return RowCtx{line * n_}; }
+    __device__ __forceinline__ float2 load(const RowCtx& c, int n) const { return in[c.base + n]; }
+    __device__ __forceinline__ void store(const RowCtx& c, int k, float2 v) const { out[c.base + k] = v; }
+    __device__ __forceinline__ ColCtx col_ctx(int64_t p, int64_t q) const { return ColCtx{p * n_ * q_ + q, q_}; }
+    __device__ __forceinline__ float2 load(const ColCtx& c, int k) const { return in[c.base + (int64_t)k * c.q]; }
+    __device__ __forceinline__ void store(const ColCtx& c, int k, float2 v) const { out[c.base + (int64_t)k * c.q] = v; }
+    __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
+};
+
+// ------------------------------------------------------------------ kernels
+template <class Io, bool INV>
+__global__ __launch_bounds__(256) void fft_rows_kernel(Io io, int64_t nlines, int lpb, dinv_fft_plan plan,
+                                                       const void* table, int centered, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = plan.n;
+    const int LS = (N % 2 == 0) ? N + 1 : N;
+    const int tid = threadIdx.x;
+    LdsCarve L = carve_lds(smem, N, lpb, LS, plan.generic != 0);
+    load_tables(L.tw, L.perm, table, N, tid, 256);
+    __syncthreads();
+    const int64_t line0 = (int64_t)blockIdx.x * lpb;
+    const int lines = (int)min((int64_t)lpb, nlines - line0);
+    const int c = centered ? N / 2 : 0;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int l = wv; l < lines; l += 4) {
+        const typename Io::RowCtx ctx = io.row_ctx(line0 + l);
+        float2* dst = L.buf + l * LS;
+        for (int n = lane; n < N; n += 64) {
+            int np = n - c;
+            if (np < 0) np += N;
+            dst[L.perm[np]] = io.load(ctx, n);
+        }
+    }
+    const float2* res = tile_fft<INV>(plan, L.buf, L.alt, L.tw, lines, LS, tid, 256);
+    for (int l = wv; l < lines; l += 4) {
+        const typename Io::RowCtx ctx = io.row_ctx(line0 + l);
+        const float2* src = res + l * LS;
+        for (int k = lane; k < N; k += 64) {
+            int kp = k - c;
+            if (kp < 0) kp += N;
+            io.store(ctx, k, cscale(src[kp], scale));
+        }
+    }
+}
+
+template <class Io, bool INV>
+__global__ __launch_bounds__(256) void fft_cols_kernel(Io io, int64_t Q, int tq, int64_t qtiles,
+                                                       dinv_fft_plan plan, const void* table, int centered,
+                                                       float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = plan.n;
+    const int LS = (N % 2 == 0) ? N + 1 : N;
+    const int tid = threadIdx.x;
+    LdsCarve L = carve_lds(smem, N, tq, LS, plan.generic != 0);
+    load_tables(L.tw, L.perm, table, N, tid, 256);
+    __syncthreads();
+    const int64_t p = blockIdx.x / qtiles;
+    const int64_t q0 = (blockIdx.x - p * qtiles) * tq;
+    const int cols = (int)min((int64_t)tq, Q - q0);
+    const int c = centered ? N / 2 : 0;
+    const int tx = tid % tq, ty = tid / tq, rpp = 256 / tq;
+    typename Io::ColCtx ctx = io.col_ctx(p, q0 + (tx < cols ? tx : 0));
+    if (tx < cols) {
+        float2* dst = L.buf + tx * LS;
+        for (int k = ty; k < N; k += rpp) {
+            int kp = k - c;
+            if (kp < 0) kp += N;
+            dst[L.perm[kp]] = io.load(ctx, k);
+        }
+    }
+    const float2* res = tile_fft<INV>(plan, L.buf, L.alt, L.tw, cols, LS, tid, 256);
+    if (tx < cols) {
+        const float2* src = res + tx * LS;
+        for (int k = ty; k < N; k += rpp) {
+            int kp = k - c;
+            if (kp < 0) kp += N;
+            io.store(ctx, k, cscale(src[kp], scale));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ tile sizing
+inline int rows_lines_per_block(const dinv_fft_plan& p) {
+    const int LS = fft_line_stride(p.n);
+    const size_t per_line = (size_t)LS * 8 * (p.generic ? 2 : 1);
+    int lpb = (int)(24576 / per_line);
+    if (lpb < 1) lpb = 1;
+    if (lpb > 64) lpb = 64;
+    return lpb;
+}
+
+inline int cols_tile_width(const dinv_fft_plan& p, int64_t Q) {
+    const int LS = fft_line_stride(p.n);
+    const size_t per_line = (size_t)LS * 8 * (p.generic ? 2 : 1);
+    int tq = 64;
+    while (tq > 1 && (size_t)tq * per_line > 49152) tq >>= 1;
+    if (tq > 16 && (size_t)tq * per_line > 40960) tq = 16;
+    while (tq > 1 && tq / 2 >= Q) tq >>= 1;
+    return tq;
+}
+
+template <class K>
+inline int set_lds_limit(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(100 + (int)e, "hipFuncSetAttribute(lds=%zu): %s", bytes, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+template <class Io>
+inline int launch_rows(Io io, int64_t nlines, const dinv_fft_plan& plan, const void* table, int inverse,
+                       int centered, float scale, hipStream_t s) {
+    if (nlines == 0) return 0;
+    io.set_geometry(plan.n, 1);
+    const int lpb = rows_lines_per_block(plan);
+    const size_t lds = fft_lds_bytes(plan, lpb);
+    DINV_REQUIRE(lds <= kMaxLdsBytes, "fft length %d does not fit the 160 KiB LDS tile (%zu B)", plan.n, lds);
+    const int64_t blocks = ceil_div(nlines, lpb);
+    DINV_REQUIRE(blocks < (1ll << 31), "too many fft lines (%lld)", (long long)nlines);
+    if (inverse) {
+        if (int e = set_lds_limit(fft_rows_kernel<Io, true>, lds)) return e;
+        hipLaunchKernelGGL((fft_rows_kernel<Io, true>), dim3((unsigned)blocks), dim3(256), lds, s, io, nlines, lpb,
+                           plan, table, centered, scale);
+    } else {
+        if (int e = set_lds_limit(fft_rows_kernel<Io, false>, lds)) return e;
+        hipLaunchKernelGGL((fft_rows_kernel<Io, false>), dim3((unsigned)blocks), dim3(256), lds, s, io, nlines,
+                           lpb, plan, table, centered, scale);
+    }
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+template <class Io>
+inline int launch_cols(Io io, int64_t P, int64_t Q, const dinv_fft_plan& plan, const void* table, int inverse,
+                       int centered, float scale, hipStream_t s) {
+    if (P == 0 || Q == 0) return 0;
+    io.set_geometry(plan.n, Q);
+    const int tq = cols_tile_width(plan, Q);
+    const size_t lds = fft_lds_bytes(plan, tq);
+    DINV_REQUIRE(lds <= kMaxLdsBytes, "fft length %d does not fit the 160 KiB LDS tile (%zu B)", plan.n, lds);
+    const int64_t qtiles = ceil_div(Q, tq);
+    const int64_t blocks = P * qtiles;
+    DINV_REQUIRE(blocks < (1ll << 31), "too many fft tiles (%lld)", (long long)blocks);
+    if (inverse) {
+        if (int e = set_lds_limit(fft_cols_kernel<Io, true>, lds)) return e;
+        hipLaunchKernelGGL((fft_cols_kernel<Io, true>), dim3((unsigned)blocks), dim3(256), lds, s, io, Q, tq,
+                           qtiles, plan, table, centered, scale);
+    } else {
+        if (int e = set_lds_limit(fft_cols_kernel<Io, false>, lds)) return e;
+        hipLaunchKernelGGL((fft_cols_kernel<Io, false>), dim3((unsigned)blocks), dim3(256), lds, s, io, Q, tq,
+                           qtiles, plan, table, centered, scale);
+    }
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace dinv

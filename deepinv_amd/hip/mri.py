@@ -1,0 +1,125 @@
+"""Fused MRI forward / adjoint (``dinv_mri_forward`` / ``dinv_mri_adjoint``).
+
+Replaces the ATen sequences of ``MultiCoilMRI.A`` (mri.py:254-272), ``MultiCoilMRI.A_adjoint``
+(mri.py:284-324), ``MRI`` via ``DecomposablePhysics`` (forward.py:1080-1117) and
+``MRIMixin.im_to_kspace / kspace_to_im`` (mixins.py:182-206).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import MriDesc, check, f32c, fft_plan, lib, ptr, require_hip, stream_ptr
+
+
+def _desc(batch, coils, vol, mask, maps, coil_dim, device):
+    d = MriDesc()
+    d.batch, d.coils, d.ndim = int(batch), int(coils), len(vol)
+    keep = []
+    for i, n in enumerate(vol):
+        d.dims[i] = int(n)
+        plan, table = fft_plan(int(n), device)
+        d.plan[i] = plan
+        d.table[i] = table.data_ptr()
+        keep.append(table)
+    d.mask_batch = 0 if mask is None else int(mask.shape[0])
+    d.maps_batch = 0 if maps is None else int(maps.shape[0])
+    d.coil_dim = int(coil_dim)
+    return d, keep
+
+
+def _prep_mask(mask, vol, batch):
+    if mask is None:
+        return None
+    mask = f32c(mask)
+    if tuple(mask.shape[2:]) != tuple(vol) or mask.shape[1] != 2 or mask.shape[0] not in (1, batch):
+        raise ValueError(f"mask of shape {tuple(mask.shape)} incompatible with data volume {tuple(vol)} / batch {batch}")
+    return mask
+
+
+def _prep_maps(maps, vol, batch):
+    if maps is None:
+        return None
+    if not maps.is_complex():
+        raise ValueError("coil_maps should be of torch complex dtype.")
+    maps = maps.to(torch.complex64).contiguous()
+    if tuple(maps.shape[2:]) != tuple(vol) or maps.shape[0] not in (1, batch):
+        raise ValueError(f"coil_maps of shape {tuple(maps.shape)} incompatible with volume {tuple(vol)} / batch {batch}")
+    return maps
+
+
+def _forward_raw(x, maps, mask, coil_dim):
+    dev = require_hip(x, maps, mask)
+    x = f32c(x)
+    if x.shape[1] != 2:
+        raise ValueError("x must be of shape (B,2,...,H,W)")
+    B, vol = x.shape[0], tuple(x.shape[2:])
+    maps = _prep_maps(maps, vol, B)
+    mask = _prep_mask(mask, vol, B)
+    N = 1 if maps is None else maps.shape[1]
+    d, keep = _desc(B, N, vol, mask, maps, coil_dim, dev)
+    yshape = (B, 2, N, *vol) if coil_dim else (B, 2, *vol)
+    y = torch.empty(yshape, device=dev, dtype=torch.float32)
+    ws = torch.empty(lib().dinv_mri_workspace_bytes(ctypes.byref(d)), device=dev, dtype=torch.uint8)
+    check(lib().dinv_mri_forward(ctypes.byref(d), ptr(x), ptr(None if maps is None else torch.view_as_real(maps)),
+                                 ptr(mask), ptr(y), ptr(ws), ws.numel(), stream_ptr(dev)))
+    return y
+
+
+def _adjoint_raw(y, maps, mask, coil_dim):
+    dev = require_hip(y, maps, mask)
+    y = f32c(y)
+    if y.shape[1] != 2:
+        raise ValueError("y must be of shape (B,2,N,...,H,W)")
+    B = y.shape[0]
+    vol = tuple(y.shape[3:]) if coil_dim else tuple(y.shape[2:])
+    maps = _prep_maps(maps, vol, B)
+    mask = _prep_mask(mask, vol, B)
+    N = y.shape[2] if coil_dim else 1
+    if maps is not None and maps.shape[1] != N:
+        raise ValueError(f"y has {N} coils but coil_maps has {maps.shape[1]}")
+    d, keep = _desc(B, N, vol, mask, maps, coil_dim, dev)
+    x = torch.empty((B, 2, *vol), device=dev, dtype=torch.float32)
+    ws = torch.empty(lib().dinv_mri_workspace_bytes(ctypes.byref(d)), device=dev, dtype=torch.uint8)
+    check(lib().dinv_mri_adjoint(ctypes.byref(d), ptr(y), ptr(None if maps is None else torch.view_as_real(maps)),
+                                 ptr(mask), ptr(x), ptr(ws), ws.numel(), stream_ptr(dev)))
+    return x
+
+
+class _MriForward(torch.autograd.Function):
+    """y = M F S x ; backward is the adjoint kernel (same trick as ApplyRadon, radon.py:493-531)."""
+
+    @staticmethod
+    def forward(ctx, x, maps, mask, coil_dim):
+        ctx.save_for_backward(maps, mask)
+        ctx.coil_dim = coil_dim
+        return _forward_raw(x, maps, mask, coil_dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        maps, mask = ctx.saved_tensors
+        return _MriAdjoint.apply(g, maps, mask, ctx.coil_dim), None, None, None
+
+
+class _MriAdjoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, maps, mask, coil_dim):
+        ctx.save_for_backward(maps, mask)
+        ctx.coil_dim = coil_dim
+        return _adjoint_raw(y, maps, mask, coil_dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        maps, mask = ctx.saved_tensors
+        return _MriForward.apply(g, maps, mask, ctx.coil_dim), None, None, None
+
+
+def mri_forward(x, coil_maps=None, mask=None, coil_dim=True):
+    """``mask * F(coil_maps * x)``; x ``[B,2,vol]`` -> ``[B,2,N,vol]`` (or ``[B,2,vol]`` if not coil_dim)."""
+    return _MriForward.apply(x, coil_maps, mask, bool(coil_dim))
+
+
+def mri_adjoint(y, coil_maps=None, mask=None, coil_dim=True):
+    """``sum_n conj(coil_maps_n) * F^H(mask * y_n)``."""
+    return _MriAdjoint.apply(y, coil_maps, mask, bool(coil_dim))

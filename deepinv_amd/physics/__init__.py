@@ -1,0 +1,4 @@
+"""Operator API mirror of ``deepinv.physics`` for the accelerated hot path."""
+from .forward import (Physics, LinearPhysics, DecomposablePhysics, Denoising, adjoint_function, power_method)
+from .noise import NoiseModel, ZeroNoise, GaussianNoise
+from .mri import MRI, MultiCoilMRI, MRIMixin

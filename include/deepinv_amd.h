@@ -1,0 +1,106 @@
+/*
+ * deepinv_amd — C-ABI of the MI355X (gfx950) hot-path library  (libdeepinv_amd.so)
+ *
+ * Drop-in boundary: every entry point below replaces the ATen call
+ * sequence behind one method of the reference's Python operator API.  The reference
+ * (deepinv v0.4.1) is 100 % Python/PyTorch, so "the FFI the reference would bind" is a
+ * ctypes binding from its operator classes; INTEGRATION.md shows that stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch types.  All tensor pointers are DEVICE
+ *     pointers to contiguous fp32 buffers owned by the caller (PyTorch's caching
+ *     allocator).  The library never allocates or frees device memory and never
+ *     synchronises: every kernel is enqueued on the caller's `stream`.
+ *   - complex tensors are interleaved (re,im) fp32 pairs (torch.complex64 layout);
+ *     deepinv's "[B,2,...]" real-pair tensors are called *planar*.
+ *   - return value 0 = success; non-zero = error, message via dinv_last_error()
+ *     (thread-local).  The Python host raises RuntimeError on non-zero.
+ *   - entry points are re-entrant per (device, stream).
+ */
+#ifndef DEEPINV_AMD_H
+#define DEEPINV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dinv_stream_t; /* hipStream_t */
+
+#define DINV_MAX_STAGES 16
+
+/* ------------------------------------------------------------------------- */
+/* library / error                                                            */
+/* ------------------------------------------------------------------------- */
+const char* dinv_last_error(void);
+int dinv_version(void);
+/* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
+int dinv_device_count(int* count);
+
+/* ------------------------------------------------------------------------- */
+/* FFT plans (in-LDS mixed-radix engine, csrc/fft_core.hpp)                    */
+/* replaces torch.fft.{fftn,ifftn,rfft2,irfft2,fftshift,ifftshift} call sites  */
+/* deepinv/utils/mixins.py:159-180, deepinv/physics/blur.py:639-657            */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n;        /* transform length */
+    int32_t nstages;  /* number of radix stages */
+    int32_t generic;  /* 1 when a stage uses the generic (prime) radix path */
+    int32_t reserved;
+    int32_t radix[DINV_MAX_STAGES]; /* outermost first */
+} dinv_fft_plan;
+
+/* bytes of the per-length table (n twiddles float2 + n int32 permutation) */
+size_t dinv_fft_table_bytes(int32_t n);
+/* fill `plan` and the HOST table buffer; caller uploads the table to the device */
+int dinv_fft_plan_init(int32_t n, dinv_fft_plan* plan, void* host_table);
+
+/* Generic centred/plain complex FFT along one axis of an interleaved complex tensor
+ * viewed as [outer, n, inner] (inner == 1 -> contiguous axis).  `inverse`: 0 forward
+ * (exp(-i..)), 1 inverse.  `centered`: ifftshift -> fft -> fftshift semantics of
+ * MRIMixin.fft (deepinv/utils/mixins.py:171-180).  `scale` multiplies the output
+ * (1/sqrt(n) for norm="ortho").  In-place (in == out) is allowed. */
+int dinv_fft_c2c_axis(const float* in, float* out, int64_t outer, int64_t inner,
+                      const dinv_fft_plan* plan, const void* table_dev, int32_t inverse,
+                      int32_t centered, float scale, dinv_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* MRI / MultiCoilMRI  (deepinv/physics/mri.py:80-163, 254-324;                */
+/*                      deepinv/utils/mixins.py:149-206)                       */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch;       /* B */
+    int32_t coils;       /* N (1 for single-coil MRI) */
+    int32_t ndim;        /* 2 or 3 transformed dims */
+    int32_t dims[3];     /* ndim==2: {H,W,0}; ndim==3: {D,H,W} */
+    int32_t mask_batch;  /* 0 = no mask, 1 = shared, B = per-sample; mask is [mb,2,vol] fp32 */
+    int32_t maps_batch;  /* 0 = no coil maps, 1 = shared, B = per-sample; maps are [mb,N,vol] c64 */
+    int32_t coil_dim;    /* 1: k-space has a coil dim  [B,2,N,vol] (MultiCoilMRI);
+                            0: k-space is [B,2,vol] (single-coil MRI, coils must be 1) */
+    int32_t reserved;
+    dinv_fft_plan plan[3];     /* one per transformed dim, same order as dims */
+    const void*   table[3];    /* device tables matching plan[] */
+} dinv_mri_desc;
+
+/* bytes of scratch the two calls below need (complex [B,N,vol] intermediate) */
+size_t dinv_mri_workspace_bytes(const dinv_mri_desc* d);
+
+/* y = M .* F(S_n .* x)      x:[B,2,vol] planar  ->  y:[B,2,(N,)vol] planar
+ * replaces MultiCoilMRI.A (mri.py:254-272) and MRI.A = U(mask*V_adjoint(x))
+ * (forward.py:1080-1096 with mri.py:99-104) */
+int dinv_mri_forward(const dinv_mri_desc* d, const float* x, const float* maps,
+                     const float* mask, float* y, void* workspace, size_t ws_bytes,
+                     dinv_stream_t stream);
+
+/* x = sum_n conj(S_n) .* F^H(M .* y_n)    y:[B,2,(N,)vol] -> x:[B,2,vol]
+ * replaces MultiCoilMRI.A_adjoint (mri.py:284-324, rss=False) and MRI.A_adjoint */
+int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const float* maps,
+                     const float* mask, float* x, void* workspace, size_t ws_bytes,
+                     dinv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPINV_AMD_H */

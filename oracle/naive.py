@@ -1,0 +1,49 @@
+"""fp64 numpy restatements straight from the defining sums.
+
+TEST INFRASTRUCTURE.  O(N^2): use only at the small sizes of the reference's own unit tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def centered_dft_matrix(n: int, inverse: bool = False) -> np.ndarray:
+    """A.1: X[k] = n^-1/2 sum_m x[m] exp(-+2 pi i (m-c)(k-c)/n), c = n//2 (odd and even n);
+    equals ifftshift -> (i)fft(norm='ortho') -> fftshift (deepinv/utils/mixins.py:159-180)."""
+    c = n // 2
+    idx = np.arange(n) - c
+    sign = 1.0 if inverse else -1.0
+    return np.exp(sign * 2j * np.pi * np.outer(idx, idx) / n) / np.sqrt(n)
+
+
+def centered_dftn(x: np.ndarray, ndim: int, inverse: bool = False) -> np.ndarray:
+    """Separable centred DFT over the last `ndim` axes of a complex array."""
+    x = x.astype(np.complex128)
+    for ax in range(-ndim, 0):
+        F = centered_dft_matrix(x.shape[ax], inverse)
+        x = np.moveaxis(np.tensordot(F, np.moveaxis(x, ax, 0), axes=(1, 0)), 0, ax)
+    return x
+
+
+def _cplx(x):  # [B,2,...] -> complex
+    return x[:, 0].astype(np.float64) + 1j * x[:, 1].astype(np.float64)
+
+
+def _planar(z):  # complex [B,...] -> [B,2,...]
+    return np.stack([z.real, z.imag], axis=1)
+
+
+def multicoil_A(x, maps, mask, ndim=2):
+    """A.2: y[b,:,n] = M . F_c(S[n] . x_c[b]) ; x [B,2,vol], maps [1|B,N,vol] c, mask [1|B,2,vol]"""
+    xc = _cplx(x)[:, None] * maps.astype(np.complex128)
+    k = centered_dftn(xc, ndim)
+    y = np.stack([k.real, k.imag], axis=1)  # [B,2,N,vol]
+    return mask[:, :, None].astype(np.float64) * y
+
+
+def multicoil_AT(y, maps, mask, ndim=2):
+    """A.2: x[b] = sum_n conj(S[n]) . F_c^-1(M . y_c[b,n])"""
+    my = mask[:, :, None].astype(np.float64) * y.astype(np.float64)
+    kc = my[:, 0] + 1j * my[:, 1]
+    im = centered_dftn(kc, ndim, inverse=True)
+    return _planar(np.sum(np.conj(maps.astype(np.complex128)) * im, axis=1))

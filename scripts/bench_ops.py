@@ -1,0 +1,52 @@
+"""Operator micro-benchmarks on one MI355X: A / A_adjoint time, algorithmic GB/s vs HBM peak.
+Usage: python scripts/bench_ops.py [mri2d|mri3d|...]"""
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import deepinv_amd as dinv  # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def bench_mri(B, coils, img, three_d):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, 2, *img, generator=g).to(dev)
+    maps = (torch.randn(1, coils, *img, dtype=torch.complex64, generator=g) / coils ** 0.5).to(dev)
+    mask = (torch.rand(*img, generator=g) > 0.75).float().to(dev)
+    phys = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, *img), three_d=three_d, device=dev)
+    y = phys.A(x)
+    vol = 1
+    for n in img:
+        vol *= n
+    alg = B * 2 * vol * 4 + B * 2 * coils * vol * 4 + coils * vol * 8 + 2 * vol * 4
+    tA = timeit(lambda: phys.A(x))
+    tT = timeit(lambda: phys.A_adjoint(y))
+    for name, t in (("A", tA), ("A_adjoint", tT)):
+        print(json.dumps({"op": f"MultiCoilMRI.{name}", "B": B, "coils": coils, "img": img, "ms": t * 1e3,
+                          "alg_MB": alg / 1e6, "GBps": alg / t / 1e9, "frac_hbm_peak": alg / t / HBM_PEAK}))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["mri2d", "mri3d"]
+    if "mri2d" in which:
+        bench_mri(32, 8, (320, 320), False)
+    if "mri3d" in which:
+        bench_mri(2, 12, (16, 256, 256), True)

@@ -1,0 +1,102 @@
+"""GPU parity of the HIP MRI path against the CPU oracle (tolerance 1e-4 relative fp32, the
+north_star bound; measured errors are ~1e-6), exact zero pattern, dot test <= 1e-5."""
+import pytest
+import torch
+
+from conftest import dot_test, rel_err
+from oracle import physics_cpu as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("shape,dims", [((3, 17, 11), (-2, -1)), ((2, 16, 8), (-2, -1)), ((2, 5, 17, 11), (-3, -2, -1)),
+                                        ((1, 320, 320), (-2, -1)), ((2, 7, 19), (-1,)), ((2, 29, 6), (-2,))])
+def test_centered_fft_matches_oracle(dev, shape, dims):
+    import deepinv_amd as dinv
+
+    x = torch.randn(*shape, dtype=torch.complex64, generator=_g())
+    for fn_o, fn in ((O.cfft, dinv.physics.MRIMixin.fft), (O.cifft, dinv.physics.MRIMixin.ifft)):
+        ref = fn_o(x, dims)
+        out = fn(x.to(dev), dim=dims).cpu()
+        assert rel_err(torch.view_as_real(out), torch.view_as_real(ref)) < TOL
+
+
+@pytest.mark.parametrize("img,three_d", [((17, 11), False), ((16, 8), False), ((5, 17, 11), True), ((320, 320), False),
+                                         ((4, 32, 20), True)])
+@pytest.mark.parametrize("batched_mask", [False, True])
+def test_single_coil_mri(dev, img, three_d, batched_mask):
+    import deepinv_amd as dinv
+
+    B = 3
+    g = _g(1)
+    x = torch.randn(B, 2, *img, generator=g)
+    mshape = (B, 1, *img) if batched_mask else img
+    mask = (torch.rand(*mshape, generator=g) > 0.6).float()
+    phys = dinv.physics.MRI(mask=mask, img_size=(2, *img), three_d=three_d, device=dev)
+    y = phys.A(x.to(dev))
+    y_ref = O.mri_A(x, mask, three_d)
+    assert y.shape == y_ref.shape
+    assert rel_err(y, y_ref) < TOL
+    # bit-exact zero pattern (reference test_physics.py:1052-1077)
+    full_mask = O.check_mask(mask, three_d).expand_as(y_ref)
+    assert torch.equal(y.cpu() == 0, full_mask == 0)
+    xa = phys.A_adjoint(y)
+    assert rel_err(xa, O.mri_AT(y_ref, mask, three_d)) < TOL
+    assert dot_test(phys, x.to(dev), y) < 1e-5
+    # closed forms of DecomposablePhysics
+    z = torch.randn(B, 2, *img, generator=g)
+    p = phys.prox_l2(z.to(dev), y, 0.7)
+    assert rel_err(p, O.mri_prox_l2(z, y_ref, 0.7, mask, three_d)) < TOL
+    assert rel_err(phys.A_dagger(y), O.mri_dagger(y_ref, mask, three_d)) < TOL
+
+
+@pytest.mark.parametrize("img,three_d,coils", [((17, 11), False, 7), ((5, 17, 11), True, 15), ((320, 320), False, 8),
+                                               ((16, 64, 48), True, 12), ((64, 64), False, 1)])
+@pytest.mark.parametrize("batched", [False, True])
+def test_multicoil_mri(dev, img, three_d, coils, batched):
+    import deepinv_amd as dinv
+
+    B = 2
+    g = _g(2)
+    x = torch.randn(B, 2, *img, generator=g)
+    mb = B if batched else 1
+    maps = torch.randn(mb, coils, *img, dtype=torch.complex64, generator=g) / coils ** 0.5
+    mask = (torch.rand(mb, 1, *img, generator=g) > 0.5).float()
+    phys = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, *img), three_d=three_d, device=dev)
+    y = phys.A(x.to(dev))
+    y_ref = O.multicoil_A(x, maps, mask, three_d)
+    assert y.shape == y_ref.shape == (B, 2, coils, *img)
+    assert rel_err(y, y_ref) < TOL
+    assert torch.all(y.cpu()[O.check_mask(mask, three_d)[:, :, None].expand_as(y_ref) == 0] == 0)
+    xa = phys.A_adjoint(y)
+    assert rel_err(xa, O.multicoil_AT(y_ref, maps, mask, three_d)) < TOL
+    assert dot_test(phys, x.to(dev), y) < 1e-5
+    xr = phys.A_adjoint(y, rss=True)
+    assert rel_err(xr, O.multicoil_AT_rss(y_ref, mask, three_d)) < TOL
+
+
+def test_mask_update_persists_and_autograd(dev):
+    import deepinv_amd as dinv
+
+    g = _g(3)
+    x = torch.randn(2, 2, 16, 12, generator=g).to(dev).requires_grad_(True)
+    phys = dinv.physics.MRI(img_size=(2, 16, 12), device=dev)
+    m2 = (torch.rand(16, 12, generator=g) > 0.5).float()
+    y = phys.A(x, mask=m2.to(dev))
+    assert torch.equal(phys.mask.cpu(), O.check_mask(m2))  # "the new mask is stored" (mri.py:28)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    assert rel_err(x.grad, O.mri_AT(w.cpu(), m2)) < TOL  # backward(A) = A_adjoint
+
+
+def test_cpu_tensor_fails_loudly():
+    import deepinv_amd as dinv
+
+    phys = dinv.physics.MRI(img_size=(2, 8, 8))
+    with pytest.raises(RuntimeError):
+        phys.A(torch.randn(1, 2, 8, 8))
