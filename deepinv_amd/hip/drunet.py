@@ -1,0 +1,105 @@
+"""ctypes wrappers for the DRUNet MFMA convolution kernels (csrc/drunet.hip)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import check, lib, ptr, stream_ptr
+
+
+class ActGeom(ctypes.Structure):
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+        ("hp", ctypes.c_int32), ("wp", ctypes.c_int32),
+        ("plane", ctypes.c_int64), ("np", ctypes.c_int64), ("sl", ctypes.c_int64), ("cs", ctypes.c_int64),
+    ]
+
+
+_declared = False
+
+
+def _l():
+    global _declared
+    l = lib()
+    if not _declared:
+        vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+        G = ctypes.POINTER(ActGeom)
+        l.dinv_act_geom_init.argtypes = [i32, i32, i32, G]
+        l.dinv_act_pack.argtypes = [G, vp, i32, vp, i32, f32, vp, vp]
+        l.dinv_act_unpack.argtypes = [G, vp, i32, vp, vp]
+        l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
+        l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
+        l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
+        _declared = True
+    return l
+
+
+def geom(batch: int, h: int, w: int) -> ActGeom:
+    g = ActGeom()
+    check(_l().dinv_act_geom_init(batch, h, w, ctypes.byref(g)))
+    return g
+
+
+def alloc(g: ActGeom, channels: int, device) -> torch.Tensor:
+    """zero-initialised padded-plane buffer [channels, cs]"""
+    return torch.zeros((channels, g.cs), device=device, dtype=torch.float32)
+
+
+def pack_conv3x3_weight(w: torch.Tensor) -> tuple[torch.Tensor, int, int]:
+    """OIHW [Cout,Cin,3,3] -> [Cout/MT][Cin/8][9][8][MT] (zero padded). Returns (packed, cin_p, cout_p)."""
+    cout, cin = w.shape[:2]
+    cin_p = (cin + 7) // 8 * 8
+    cout_p = (cout + 31) // 32 * 32
+    mt = 64 if cout_p % 64 == 0 else 32
+    wp = torch.zeros((cout_p, cin_p, 3, 3), device=w.device, dtype=torch.float32)
+    wp[:cout, :cin] = w.detach().float()
+    wp = wp.reshape(cout_p // mt, mt, cin_p // 8, 8, 9).permute(0, 2, 4, 3, 1).contiguous()
+    return wp, cin_p, cout_p
+
+
+def pack_down_weight(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d k2 s2 weight [Cout,Cin,2,2] -> [tap=dy*2+dx][Cin][Cout]"""
+    cout, cin = w.shape[:2]
+    return w.detach().float().permute(2, 3, 1, 0).reshape(4, cin, cout).contiguous()
+
+
+def pack_up_weight(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d k2 s2 weight [Cin,Cout,2,2] -> [tap=dy*2+dx][Cin][Cout]"""
+    cin, cout = w.shape[:2]
+    return w.detach().float().permute(2, 3, 0, 1).reshape(4, cin, cout).contiguous()
+
+
+def pack_input(g, x, sigma, act):
+    dev = x.device
+    if isinstance(sigma, torch.Tensor):
+        if sigma.numel() == 1:
+            mode, sp, sv = 0, None, float(sigma.item()) if not sigma.is_cuda else None
+            if sv is None:  # device scalar: avoid a host sync, expand on device
+                sigma = sigma.reshape(1).expand(g.batch).contiguous().float()
+                mode, sp, sv = 1, sigma, 0.0
+        elif sigma.numel() == g.batch:
+            mode, sp, sv = 1, sigma.reshape(-1).contiguous().float().to(dev), 0.0
+        else:
+            mode, sp, sv = 2, sigma.contiguous().float().to(dev), 0.0
+    else:
+        mode, sp, sv = 0, None, float(sigma)
+    check(_l().dinv_act_pack(ctypes.byref(g), ptr(x), x.shape[1], ptr(sp), mode, sv, ptr(act), stream_ptr(dev)))
+
+
+def unpack_output(g, act, cout, y):
+    check(_l().dinv_act_unpack(ctypes.byref(g), ptr(act), cout, ptr(y), stream_ptr(y.device)))
+
+
+def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False):
+    check(_l().dinv_conv3x3(ctypes.byref(g), ptr(x), ptr(x2), ptr(wpk), cin, cout, cout if cout_valid is None else cout_valid,
+                            ptr(y), ptr(res1), ptr(res2), int(relu), stream_ptr(y.device)))
+
+
+def down2x2(gi, go, x, w, cin, cout, y):
+    check(_l().dinv_conv_down2x2(ctypes.byref(gi), ctypes.byref(go), ptr(x), ptr(w), cin, cout, ptr(y), stream_ptr(y.device)))
+
+
+def up2x2(gi, go, x, x2, w, cin, cout, y):
+    check(_l().dinv_conv_up2x2(ctypes.byref(gi), ctypes.byref(go), ptr(x), ptr(x2), ptr(w), cin, cout, ptr(y),
+                               stream_ptr(y.device)))

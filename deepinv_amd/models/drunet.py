@@ -1,0 +1,254 @@
+"""DRUNet denoiser with an MFMA (fp32 matrix-core) inference path.
+
+Module tree and parameter names are identical to the reference (deepinv/models/drunet.py:39-101:
+``m_head``, ``m_down{1,2,3}``, ``m_body``, ``m_up{3,2,1}``, ``m_tail``; ResBlock ``res.0``/``res.2``)
+so reference ``state_dict``s / ``.pth`` checkpoints load unchanged.
+
+* inference (``torch.no_grad`` / eval, 2-D, default architecture) -> 64 hand-written HIP launches
+  (csrc/drunet.hip): 3x3 convs as implicit GEMM on ``v_mfma_f32_32x32x2_f32`` with ReLU, residual
+  and U-Net skip adds fused into load/epilogue; activations stay in padded channel planes.
+* training (autograd needed: ``deepinv.unfolded``) or ``dim=3`` -> the same modules run through
+  PyTorch-ROCm autograd (plumbing; hand-written conv backward is listed under "next").
+"""
+from __future__ import annotations
+
+from itertools import chain
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..hip import HipExtensionError
+from ..hip import drunet as K
+from .base import Denoiser
+
+
+def _conv_nd(dim):
+    return {2: nn.Conv2d, 3: nn.Conv3d}[dim]
+
+
+def _convT_nd(dim):
+    return {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}[dim]
+
+
+class ResBlock(nn.Module):
+    """x + conv(relu(conv(x)))  (drunet.py:403-434, mode 'CRC')"""
+
+    def __init__(self, channels, dim=2):
+        super().__init__()
+        C = _conv_nd(dim)
+        self.res = nn.Sequential(C(channels, channels, 3, 1, 1, bias=False), nn.ReLU(inplace=True),
+                                 C(channels, channels, 3, 1, 1, bias=False))
+
+    def forward(self, x):
+        return x + self.res(x)
+
+
+def weights_init_drunet(m):
+    """orthogonal init, gain 0.2 (drunet.py:689-692)"""
+    if m.__class__.__name__.find("Conv") != -1:
+        nn.init.orthogonal_(m.weight.data, gain=0.2)
+
+
+def test_pad(model, L, modulo=16):
+    """replicate-pad bottom/right to a multiple of `modulo`, run, crop (models/utils.py:49-61)"""
+    spatials = L.size()[2:]
+    padding = tuple(int(np.ceil(s / modulo) * modulo - s) for s in spatials)
+    padding = tuple(chain.from_iterable((0, v) for v in reversed(padding)))
+    L = {2: nn.ReplicationPad2d, 3: nn.ReplicationPad3d}[len(spatials)](padding)(L)
+    E = model(L)
+    return E[(...,) + tuple(slice(0, s) for s in spatials)]
+
+
+def test_onesplit(model, L, refield=32, sf=1):
+    """four overlapping quadrants (models/utils.py:64-98)"""
+    h, w = L.size()[-2:]
+    hh, ww = (h // 2 // refield + 1) * refield, (w // 2 // refield + 1) * refield
+    top, bottom, left, right = slice(0, hh), slice(h - hh, h), slice(0, ww), slice(w - ww, w)
+    Es = [model(L[..., a, b]) for a in (top, bottom) for b in (left, right)]
+    b, c = Es[0].size()[:2]
+    E = torch.zeros(b, c, sf * h, sf * w).type_as(L)
+    E[..., : h // 2 * sf, : w // 2 * sf] = Es[0][..., : h // 2 * sf, : w // 2 * sf]
+    E[..., : h // 2 * sf, w // 2 * sf: w * sf] = Es[1][..., : h // 2 * sf, (-w + w // 2) * sf:]
+    E[..., h // 2 * sf: h * sf, : w // 2 * sf] = Es[2][..., (-h + h // 2) * sf:, : w // 2 * sf]
+    E[..., h // 2 * sf: h * sf, w // 2 * sf: w * sf] = Es[3][..., (-h + h // 2) * sf:, (-w + w // 2) * sf:]
+    return E
+
+
+class DRUNet(Denoiser):
+    def __init__(self, in_channels=3, out_channels=3, nc=(64, 128, 256, 512), nb=4, act_mode="R",
+                 downsample_mode="strideconv", upsample_mode="convtranspose", pretrained=None,
+                 pretrained_2d_isotropic=False, device=None, dim=2):
+        super().__init__()
+        if act_mode != "R" or downsample_mode != "strideconv" or upsample_mode != "convtranspose":
+            raise NotImplementedError("only the default DRUNet architecture (ReLU / strideconv / convtranspose) is "
+                                      "on the accelerated path")
+        dim = int(str(dim).lower().replace("d", "")) if not isinstance(dim, int) else dim
+        if dim not in (2, 3):
+            raise ValueError("dim must be 2 or 3")
+        C, T = _conv_nd(dim), _convT_nd(dim)
+        self.in_channels, self.out_channels, self.nc, self.nb = in_channels, out_channels, tuple(nc), nb
+        cin = in_channels + 1  # + noise level map
+        self.m_head = C(cin, nc[0], 3, 1, 1, bias=False)
+        self.m_down1 = nn.Sequential(*[ResBlock(nc[0], dim) for _ in range(nb)], C(nc[0], nc[1], 2, 2, 0, bias=False))
+        self.m_down2 = nn.Sequential(*[ResBlock(nc[1], dim) for _ in range(nb)], C(nc[1], nc[2], 2, 2, 0, bias=False))
+        self.m_down3 = nn.Sequential(*[ResBlock(nc[2], dim) for _ in range(nb)], C(nc[2], nc[3], 2, 2, 0, bias=False))
+        self.m_body = nn.Sequential(*[ResBlock(nc[3], dim) for _ in range(nb)])
+        self.m_up3 = nn.Sequential(T(nc[3], nc[2], 2, 2, 0, bias=False), *[ResBlock(nc[2], dim) for _ in range(nb)])
+        self.m_up2 = nn.Sequential(T(nc[2], nc[1], 2, 2, 0, bias=False), *[ResBlock(nc[1], dim) for _ in range(nb)])
+        self.m_up1 = nn.Sequential(T(nc[1], nc[0], 2, 2, 0, bias=False), *[ResBlock(nc[0], dim) for _ in range(nb)])
+        self.m_tail = C(nc[0], out_channels, 3, 1, 1, bias=False)
+        self.dim = dim
+        if pretrained is not None:
+            if pretrained in ("download", "download_2d"):
+                raise RuntimeError("no network access: pass pretrained=<path to .pth> or None")
+            self.load_state_dict(torch.load(pretrained, map_location="cpu"), strict=True)
+            self.eval()
+        else:
+            self.apply(weights_init_drunet)
+        self._engine = None
+        if device is not None:
+            self.to(device)
+
+    # ------------------------------------------------------------------ reference-shaped torch graph
+    def forward_unet_torch(self, x0):
+        """drunet.py:200-210 through PyTorch-ROCm autograd (training / 3-D)."""
+        x1 = self.m_head(x0)
+        x2 = self.m_down1(x1)
+        x3 = self.m_down2(x2)
+        x4 = self.m_down3(x3)
+        x = self.m_body(x4)
+        x = self.m_up3(x + x4)
+        x = self.m_up2(x + x3)
+        x = self.m_up1(x + x2)
+        return self.m_tail(x + x1)
+
+    def _noise_map(self, x, sigma):
+        """drunet.py:226-249"""
+        if isinstance(sigma, torch.Tensor):
+            if sigma.ndim > 0:
+                if sigma.shape == (x.size(0), 1, *x.shape[2:]):
+                    return sigma
+                if sigma.shape in [(x.size(0),), (x.size(0), 1, *[1] * self.dim)] or sigma.numel() == 1:
+                    m = sigma.reshape(-1, 1, *[1] * self.dim).to(x)
+                    return m.expand(x.size(0), 1, *x.shape[2:])
+                raise ValueError("Incorrect shape, sigma should be of shape (1,), (batch_size,) or "
+                                 f"(batch_size, 1, height, width, (depth)), got {tuple(sigma.shape)}")
+            return torch.ones((x.size(0), 1, *x.shape[2:]), device=x.device) * sigma.to(x.device)
+        return torch.full((x.size(0), 1, *x.shape[2:]), float(sigma), device=x.device, dtype=x.dtype)
+
+    def _use_hip(self, x):
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        return self.dim == 2 and not needs_grad
+
+    def forward(self, x, sigma):
+        if not x.is_cuda:
+            raise HipExtensionError("deepinv_amd.models.DRUNet runs only on a HIP device; there is no CPU fallback")
+        if self._use_hip(x):
+            run = lambda inp: self._hip_forward(inp[:, :-1], inp[:, -1:])
+        else:
+            run = self.forward_unet_torch
+        xin = torch.cat((x, self._noise_map(x, sigma)), 1)
+        safe = all(s % 8 == 0 and s > 31 for s in xin.shape[2:])
+        if safe:
+            return run(xin)
+        if self.training or any(xin.size(2 + i) < 64 for i in range(self.dim)):
+            return test_pad(run, xin, modulo=16)
+        if self.dim == 3:
+            raise NotImplementedError("test_onesplit is not implemented yet for 3D.")
+        return test_onesplit(run, xin, refield=64)
+
+    # ------------------------------------------------------------------ MFMA inference engine
+    def _weights_version(self):
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def _prepare(self, device):
+        ver = self._weights_version()
+        if self._engine is not None and self._engine["ver"] == ver and self._engine["device"] == device:
+            return self._engine
+        e = {"ver": ver, "device": device, "ws": {}}
+
+        def c3(m):
+            return K.pack_conv3x3_weight(m.weight.to(device))
+
+        e["head"] = c3(self.m_head)
+        e["tail"] = c3(self.m_tail)
+        for name in ("m_down1", "m_down2", "m_down3"):
+            seq = getattr(self, name)
+            e[name] = [(c3(b.res[0]), c3(b.res[2])) for b in list(seq)[:-1]]
+            e[name + "_s"] = K.pack_down_weight(seq[-1].weight.to(device))
+        e["m_body"] = [(c3(b.res[0]), c3(b.res[2])) for b in self.m_body]
+        for name in ("m_up3", "m_up2", "m_up1"):
+            seq = getattr(self, name)
+            e[name + "_s"] = K.pack_up_weight(seq[0].weight.to(device))
+            e[name] = [(c3(b.res[0]), c3(b.res[2])) for b in list(seq)[1:]]
+        self._engine = e
+        return e
+
+    def _workspace(self, e, B, H, W, device):
+        key = (B, H, W)
+        ws = e["ws"].get(key)
+        if ws is None:
+            e["ws"].clear()  # one geometry at a time keeps the footprint bounded
+            nc = self.nc
+            g = [K.geom(B, H >> i, W >> i) for i in range(4)]
+            cin_p = e["head"][1]
+            ws = {"g": g, "in": K.alloc(g[0], cin_p, device), "out": K.alloc(g[0], self.out_channels, device)}
+            for i in range(4):
+                # skip tensor x_{i+1}, two ping-pong buffers and the ResBlock temporary
+                for nm in ("skip", "a", "b", "t"):
+                    ws[f"{nm}{i}"] = K.alloc(g[i], nc[i], device)
+            e["ws"][key] = ws
+        return ws
+
+    def _res_chain(self, g, blocks, c, x, a, b, t, last_extra=None):
+        """run ResBlocks: returns the buffer holding the result (never `x` itself is overwritten)"""
+        cur = x
+        bufs = [a, b]
+        for i, ((w1, ci, co), (w2, _, _)) in enumerate(blocks):
+            K.conv3x3(g, cur, w1, ci, co, t, relu=True)
+            dst = bufs[i % 2]
+            extra = last_extra if i == len(blocks) - 1 else None
+            K.conv3x3(g, t, w2, ci, co, dst, res1=cur, res2=extra)
+            cur = dst
+        return cur
+
+    def _hip_forward(self, x, sigma_map):
+        """forward_unet (drunet.py:200-210) as 64 conv launches + pack/unpack."""
+        dev = x.device
+        e = self._prepare(dev)
+        B, _, H, W = x.shape
+        ws = self._workspace(e, B, H, W, dev)
+        g = ws["g"]
+        nc = self.nc
+        x = x.contiguous().float()
+        K.pack_input(g[0], x, sigma_map, ws["in"])
+        (wh, cih, coh) = e["head"]
+        K.conv3x3(g[0], ws["in"], wh, cih, coh, ws["skip0"])                      # x1
+        cur = ws["skip0"]
+        downs = ("m_down1", "m_down2", "m_down3")
+        for i, name in enumerate(downs):
+            r = self._res_chain(g[i], e[name], nc[i], cur, ws[f"a{i}"], ws[f"b{i}"], ws[f"t{i}"])
+            K.down2x2(g[i], g[i + 1], r, e[name + "_s"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])   # x2, x3, x4
+            cur = ws[f"skip{i + 1}"]
+        r = self._res_chain(g[3], e["m_body"], nc[3], cur, ws["a3"], ws["b3"], ws["t3"])
+        skip_add = ws["skip3"]  # x + x4 is fused into the up-conv's operand load
+        for i, name in zip((2, 1, 0), ("m_up3", "m_up2", "m_up1")):
+            K.up2x2(g[i + 1], g[i], r, skip_add, e[name + "_s"], nc[i + 1], nc[i], ws[f"t{i}"])
+            # t{i} holds the up-conv output; run the ResBlocks with a/b ping-pong and a fresh temporary
+            r = self._res_chain_from_t(g[i], e[name], ws[f"t{i}"], ws[f"a{i}"], ws[f"b{i}"])
+            skip_add = ws[f"skip{i}"]
+        (wt, cit, cot) = e["tail"]
+        K.conv3x3(g[0], r, wt, cit, cot, ws["out"], cout_valid=self.out_channels, x2=ws["skip0"])  # m_tail(x + x1)
+        y = torch.empty((B, self.out_channels, H, W), device=dev, dtype=torch.float32)
+        K.unpack_output(g[0], ws["out"], self.out_channels, y)
+        return y
+
+    def _res_chain_from_t(self, g, blocks, t_in, a, b):
+        """ResBlocks whose input lives in the `t` buffer: rotate roles so nothing is clobbered."""
+        cur, tmp, other = t_in, a, b
+        for ((w1, ci, co), (w2, _, _)) in blocks:
+            K.conv3x3(g, cur, w1, ci, co, tmp, relu=True)
+            K.conv3x3(g, tmp, w2, ci, co, other, res1=cur)
+            cur, other = other, cur
+        return cur

@@ -44,9 +44,24 @@ def bench_mri(B, coils, img, three_d):
                           "alg_MB": alg / 1e6, "GBps": alg / t / 1e9, "frac_hbm_peak": alg / t / HBM_PEAK}))
 
 
+def bench_drunet(B, cin, H, W, gflop_per_img):
+    dev = torch.device("cuda:0")
+    model = dinv.models.DRUNet(cin, cin, pretrained=None).to(dev).eval()
+    x = torch.rand(B, cin, H, W, device=dev)
+    with torch.no_grad():
+        t = timeit(lambda: model(x, 0.05), iters=5, warmup=2)
+    tf = gflop_per_img * B / t / 1e3
+    print(json.dumps({"op": "DRUNet.forward", "B": B, "cin": cin, "img": [H, W], "ms": t * 1e3, "TFLOPs": tf,
+                      "frac_fp32_mfma_peak": tf / 157.3}))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["mri2d", "mri3d"]
     if "mri2d" in which:
         bench_mri(32, 8, (320, 320), False)
     if "mri3d" in which:
         bench_mri(2, 12, (16, 256, 256), True)
+    if "drunet" in which:
+        bench_drunet(32, 2, 320, 320, 433.4)
+    if "drunet4" in which:
+        bench_drunet(4, 2, 320, 320, 433.4)
