@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): PnP-PGD slices/sec (50 iterations) on 2-D 8-coil
+320x320 MRI with a 4x radial mask and the DRUNet(2->2) denoiser, global batch 32, plus
+A / A_adjoint GB/s against the HBM roofline.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one full 50-iteration PnP-PGD reconstruction of the global batch (inputs already
+resident in HBM).  Multi-GPU: the batch is sharded in contiguous slabs, one process per GPU,
+reconstructions combined by one RCCL all-gather per step (inside the timed region);
+total work is fixed as N grows ("scaling": "strong", the north_star's >=6x@8 target).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
+MFMA_F32_PEAK = 157.3e12   # FLOP/s dense fp32 matrix (v_mfma_f32_32x32x2_f32)
+
+
+def make_problem(dinv, B_local, offset, H, W, coils, device):
+    """Synthetic cfg-2 inputs, seeded per global slice index so that the global
+    batch is identical for every N."""
+    g = torch.Generator().manual_seed(0)
+    maps = torch.randn(1, coils, H, W, dtype=torch.complex64, generator=g)
+    maps = maps / maps.abs().pow(2).sum(dim=1, keepdim=True).sqrt()
+    mask = dinv.utils.radial_mask(H, W, 80)
+    xs, ns = [], []
+    for i in range(offset, offset + B_local):
+        gi = torch.Generator().manual_seed(1000 + i)
+        xs.append(torch.rand(1, 2, H, W, generator=gi))
+        ns.append(torch.randn(1, 2, coils, H, W, generator=gi))
+    x = torch.cat(xs).to(device)
+    noise = torch.cat(ns).to(device)
+    physics = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, H, W), device=device)
+    y = physics.A(x) + 0.01 * noise * physics.mask[:, :, None]
+    return physics, x, y, maps, mask
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="global batch (slices)")
+    ap.add_argument("--iters", type=int, default=50, help="PGD iterations per reconstruction")
+    ap.add_argument("--size", type=int, default=320)
+    ap.add_argument("--coils", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    import deepinv_amd as dinv
+    from deepinv_amd.hip import drunet as K
+
+    H = W = args.size
+    if args.batch % world:
+        raise SystemExit("global batch must be divisible by the number of GPUs")
+    B_local = args.batch // world
+    physics, x_true, y, maps, mask = make_problem(dinv, B_local, rank * B_local, H, W, args.coils, device)
+
+    torch.manual_seed(0)
+    denoiser = dinv.models.DRUNet(2, 2, pretrained=None).to(device).eval()
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(denoiser), stepsize=1.0, g_param=0.05,
+                           max_iter=args.iters, early_stop=False)
+    gathered = torch.empty((args.batch, 2, H, W), device=device)
+
+    def step():
+        xr = model(y, physics)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, xr.contiguous())
+            return gathered
+        return xr
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    K.profile_begin()          # HIP events around every conv3x3 launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    conv_ms, conv_flops, conv_n = K.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    # ---- operator GB/s (outside the timed region)
+    ops = []
+    def time_op(fn, n=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+    alg = (B_local * 2 * H * W + B_local * 2 * args.coils * H * W) * 4 + args.coils * H * W * 8 + 2 * H * W * 4
+    for name, fn in (("MultiCoilMRI.A", lambda: physics.A(x_true)), ("MultiCoilMRI.A_adjoint", lambda: physics.A_adjoint(y))):
+        t = time_op(fn)
+        ops.append({"op": name, "batch": B_local, "ms": round(t * 1e3, 4), "alg_MB": round(alg / 1e6, 2),
+                    "GBps": round(alg / t / 1e9, 1), "frac_hbm_peak": round(alg / t / HBM_PEAK, 4)})
+
+    if rank == 0:
+        slices_per_s = args.batch * args.steps / elapsed
+        achieved = conv_flops / (conv_ms * 1e-3) if conv_ms > 0 else 0.0
+        res = {
+            "metric": "PnP-PGD slices/sec (50 iters), 2D MRI 8-coil 320x320, 4x radial mask, DRUNet",
+            "value": round(slices_per_s, 4), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 2D MRI 8-coil 320x320, 4x radial mask (80 spokes), PnP-PGD 50 it + "
+                                   "DRUNet(2->2, random init), global batch %d" % args.batch,
+                       "global_batch": args.batch, "per_gpu_batch": B_local, "iters": args.iters,
+                       "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel (DRUNet 3x3 conv, v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(achieved / 1e12, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_F32_PEAK, 4), "traffic": None,
+                         "launches": conv_n, "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4)},
+            "operators": ops,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(denoiser, maps, mask, H, W, args.coils, args.iters)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(denoiser, maps, mask, H, W, coils, iters):
+    """The oracle ("port": same ATen CPU call sequence as the reference) timed on this box's host
+    cores on a bounded sample: 1 slice x `n_it` PGD iterations, scaled to `iters` iterations
+    (per-iteration cost is constant; per-slice CPU cost is batch independent)."""
+    from oracle import drunet_cpu as OD
+    from oracle import optim_cpu as OO
+    from oracle import physics_cpu as OP
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in denoiser.state_dict().items()}
+    g = torch.Generator().manual_seed(1000)
+    x = torch.rand(1, 2, H, W, generator=g)
+    A = lambda v: OP.multicoil_A(v, maps, mask)
+    AT = lambda v: OP.multicoil_AT(v, maps, mask)
+    y = A(x)
+    den = lambda u, s: OD.drunet(sd, u, s)
+    with torch.no_grad():
+        OO.pnp_pgd(y, A, AT, den, max_iter=1)  # warm-up
+        n_it = 0
+        t0 = time.perf_counter()
+        xk = AT(y)
+        while True:
+            xk = OO.pnp_pgd(y, A, AT, den, max_iter=1, x0=xk)
+            n_it += 1
+            if time.perf_counter() - t0 > 12.0 or n_it >= iters:
+                break
+        dt = time.perf_counter() - t0
+    per_slice = dt / n_it * iters
+    return {"value": round(1.0 / per_slice, 5), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"1 slice x {n_it} PGD iterations ({dt:.1f} s), scaled to {iters} iterations",
+            "threads": torch.get_num_threads()}
+
+
+if __name__ == "__main__":
+    main()

@@ -9,3 +9,7 @@ __version__ = "0.1.0"
 
 from . import hip  # noqa: F401
 from . import physics  # noqa: F401
+from . import models  # noqa: F401
+from . import optim  # noqa: F401
+from . import unfolded  # noqa: F401
+from . import utils  # noqa: F401

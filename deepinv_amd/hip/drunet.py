@@ -91,7 +91,39 @@ def unpack_output(g, act, cout, y):
     check(_l().dinv_act_unpack(ctypes.byref(g), ptr(act), cout, ptr(y), stream_ptr(y.device)))
 
 
-def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False):
+# ---- optional live profiling: HIP events around every conv3x3 launch on the launch stream
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """returns (total ms, total algorithmic FLOPs, launches) of the conv3x3 launches since profile_begin()"""
+    global _prof
+    rec, _prof = _prof, None
+    if not rec:
+        return 0.0, 0.0, 0
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b, _ in rec), float(sum(f for _, _, f in rec)), len(rec)
+
+
+def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False, cin_valid=None):
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _conv3x3(g, x, wpk, cin, cout, y, cout_valid, x2, res1, res2, relu)
+        e1.record()
+        co = cout if cout_valid is None else cout_valid
+        ci = cin if cin_valid is None else cin_valid
+        _prof.append((e0, e1, 2.0 * 9 * ci * co * g.batch * g.height * g.width))
+        return
+    _conv3x3(g, x, wpk, cin, cout, y, cout_valid, x2, res1, res2, relu)
+
+
+def _conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False):
     check(_l().dinv_conv3x3(ctypes.byref(g), ptr(x), ptr(x2), ptr(wpk), cin, cout, cout if cout_valid is None else cout_valid,
                             ptr(y), ptr(res1), ptr(res2), int(relu), stream_ptr(y.device)))
 

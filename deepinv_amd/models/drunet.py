@@ -224,7 +224,7 @@ class DRUNet(Denoiser):
         x = x.contiguous().float()
         K.pack_input(g[0], x, sigma_map, ws["in"])
         (wh, cih, coh) = e["head"]
-        K.conv3x3(g[0], ws["in"], wh, cih, coh, ws["skip0"])                      # x1
+        K.conv3x3(g[0], ws["in"], wh, cih, coh, ws["skip0"], cin_valid=self.in_channels + 1)  # x1
         cur = ws["skip0"]
         downs = ("m_down1", "m_down2", "m_down3")
         for i, name in enumerate(downs):

@@ -1,0 +1,61 @@
+"""The iteration loop (reference deepinv/optim/fixed_point.py:13-406; Anderson acceleration,
+off by default at optimizers.py:296, is not on the accelerated path)."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+
+class FixedPoint(nn.Module):
+    def __init__(self, iterator=None, update_params_fn=None, update_data_fidelity_fn=None, update_prior_fn=None,
+                 init_iterate_fn=None, init_metrics_fn=None, update_metrics_fn=None, check_conv_fn=None,
+                 backtracking_check_fn=None, max_iter=50, early_stop=True, anderson_acceleration_config=None,
+                 backtracking_config=None, verbose=False, show_progress_bar=False):
+        super().__init__()
+        if anderson_acceleration_config is not None:
+            raise NotImplementedError("Anderson acceleration is not implemented on the accelerated path")
+        self.iterator = iterator
+        self.max_iter = max_iter
+        self.early_stop = early_stop
+        self.update_params_fn = update_params_fn
+        self.update_data_fidelity_fn = update_data_fidelity_fn
+        self.update_prior_fn = update_prior_fn
+        self.init_iterate_fn = init_iterate_fn
+        self.init_metrics_fn = init_metrics_fn
+        self.update_metrics_fn = update_metrics_fn
+        self.check_conv_fn = check_conv_fn
+        self.backtracking_check_fn = backtracking_check_fn
+        self.backtracking_config = backtracking_config
+        self.verbose = verbose
+        self.show_progress_bar = show_progress_bar
+        self.backtracking_check = True
+
+    def single_iteration(self, X, it, *args, **kwargs):
+        """fixed_point.py:363-406"""
+        cur_params = self.update_params_fn(it) if self.update_params_fn else None
+        cur_df = self.update_data_fidelity_fn(it) if self.update_data_fidelity_fn else None
+        cur_prior = self.update_prior_fn(it) if self.update_prior_fn else None
+        X_prev = X
+        X = self.iterator(X_prev, cur_df, cur_prior, cur_params, *args, **kwargs)
+        self.backtracking_check = self.backtracking_check_fn(X_prev, X) if self.backtracking_check_fn else True
+        return X if self.backtracking_check else X_prev
+
+    def forward(self, *args, init=None, compute_metrics=False, x_gt=None, **kwargs):
+        """fixed_point.py:262-361"""
+        X = self.init_iterate_fn(*args, init, cost_fn=self.iterator.cost_fn) if self.init_iterate_fn else None
+        metrics = self.init_metrics_fn(X, x_gt=x_gt) if self.init_metrics_fn and compute_metrics else None
+        self.backtracking_check = True
+        failed = 0
+        for it in range(self.max_iter):
+            X_prev = X
+            X = self.single_iteration(X, it, *args, **kwargs)
+            if self.backtracking_check or self.backtracking_config is None:
+                failed = 0
+                metrics = (self.update_metrics_fn(metrics, X_prev, X, x_gt=x_gt)
+                           if self.update_metrics_fn and compute_metrics else None)
+                if self.early_stop and self.check_conv_fn is not None and it > 1 and self.check_conv_fn(it, X_prev, X):
+                    break
+            else:
+                failed += 1
+                if failed >= self.backtracking_config.max_iter:
+                    break
+        return X, metrics

@@ -1,0 +1,1 @@
+from .unfolded import BaseUnfold, unfolded_builder
