@@ -6,7 +6,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepinv_amd as dinv  # noqa: E402
 
 HBM_PEAK = 8.0e12
