@@ -2,3 +2,4 @@
 from .forward import (Physics, LinearPhysics, DecomposablePhysics, Denoising, adjoint_function, power_method)
 from .noise import NoiseModel, ZeroNoise, GaussianNoise
 from .mri import MRI, MultiCoilMRI, MRIMixin
+from .tomography import Tomography, RampFilter

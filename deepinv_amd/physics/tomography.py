@@ -1,0 +1,114 @@
+"""``Tomography`` (parallel beam) on HIP kernels — API mirror of deepinv/physics/tomography.py:26-350.
+
+Differences from the reference, all internal: no precomputed sampling grids (3 GB at 512/720 angles),
+the exact adjoint is a deterministic gather kernel instead of an autograd replay
+(``adjoint_via_backprop=True`` keeps its meaning: *exact* adjoint), and the ramp filter is a direct
+convolution.  Fan-beam geometry is out of scope.
+"""
+from __future__ import annotations
+
+from warnings import warn
+
+import torch
+from numpy import ndarray
+
+from ..hip import radon as hr
+from .forward import LinearPhysics
+
+
+class RampFilter(torch.nn.Module):
+    """radon.py:74-173 (dim=-2 only)"""
+
+    def __init__(self, dtype=torch.float32):
+        super().__init__()
+        self.dtype = dtype
+
+    def forward(self, x, dim=-2):
+        if dim not in (-2, 2):
+            raise NotImplementedError("the HIP ramp filter acts on the detector axis (dim=-2)")
+        return hr.ramp_filter(x)
+
+
+class Tomography(LinearPhysics):
+    def __init__(self, angles, img_width, circle=False, parallel_computation=True, adjoint_via_backprop=True,
+                 fbp_interpolate_boundary=False, normalize=None, fan_beam=False, fan_parameters=None,
+                 device=torch.device("cpu"), dtype=torch.float, **kwargs):
+        super().__init__(device=device, **kwargs)
+        if fan_beam:
+            raise NotImplementedError("fan-beam geometry is not on the accelerated path")
+        if isinstance(angles, int):
+            angles = torch.linspace(0, 180, steps=angles + 1, device=device)[:-1].to(device)
+        elif isinstance(angles, (list, tuple, ndarray)):
+            angles = torch.tensor(angles).to(device)
+        elif not isinstance(angles, torch.Tensor):
+            raise ValueError(f"angles must be int, float, iterable or Tensor, but got {type(angles)}")
+        self.register_buffer("angles", angles)
+        self.fan_beam = False
+        self.adjoint_via_backprop = adjoint_via_backprop
+        if circle and fbp_interpolate_boundary:
+            warn("The argument fbp_interpolate_boundary=True is not applicable if circle=True. The value "
+                 "fbp_interpolate_boundary will be changed to False...")
+            fbp_interpolate_boundary = False
+        self.fbp_interpolate_boundary = fbp_interpolate_boundary
+        self.img_width = img_width
+        self.circle = circle
+        self.dtype = dtype
+        self.parallel_computation = parallel_computation  # kept for API compatibility; no effect here
+        self.filter = RampFilter(dtype=dtype)
+        self._geo = None
+        if normalize is None:
+            warn("The default value of `normalize` is not specified and will be automatically set to `True`. "
+                 "Set `normalize` explicitly to `True` or `False` to avoid this warning.")
+            normalize = True
+        self.normalize = False
+        if normalize:
+            if torch.device(device).type != "cuda":
+                raise RuntimeError("Tomography(normalize=True) runs the power method on the HIP kernels: construct "
+                                   "it with device='cuda' (or normalize=False and load `operator_norm` later)")
+            x0 = torch.randn((1, img_width, img_width), generator=torch.Generator(device).manual_seed(0),
+                             device=device)[None]
+            operator_norm = self.compute_norm(x0, squared=False, verbose=False)
+            self.register_buffer("operator_norm", operator_norm)
+            self.normalize = True
+        self.to(device)
+
+    # ---- geometry tables live on the device of the data; rebuilt if the module moved
+    def _geometry(self, device):
+        if self._geo is None or self._geo.device != torch.device(device) or self._geo.A != self.angles.numel():
+            self._geo = hr.RadonGeometry(self.angles, self.img_width, self.circle, device)
+        return self._geo
+
+    def _scale(self):
+        return 1.0 / float(self.operator_norm) if self.normalize else 1.0
+
+    def A(self, x, **kwargs):
+        if not x.shape[-2:] == (self.img_width, self.img_width):
+            raise ValueError(f"Input image size {x.shape[-2:]} does not match the operator image size "
+                             f"{(self.img_width, self.img_width)}.")
+        return hr.radon_forward(x, self._geometry(x.device), self._scale())
+
+    def A_adjoint(self, y, **kwargs):
+        if self.adjoint_via_backprop:
+            return hr.radon_adjoint(y, self._geometry(y.device), self._scale())
+        return self._iradon_adjoint(y)
+
+    def _iradon_adjoint(self, y):
+        raise NotImplementedError("adjoint_via_backprop=False (interpolating, inexact back-projection) is not on the "
+                                  "accelerated path yet; the default exact adjoint is")
+
+    def fbp(self, y, **kwargs):
+        """filtered back-projection (tomography.py:258-293)"""
+        if not self.adjoint_via_backprop:
+            return self._iradon_adjoint(y)
+        y = self.filter(y)
+        out = self.A_adjoint(y, **kwargs) * torch.pi / (2 * self.angles.numel())
+        if self.normalize:
+            out = out * self.operator_norm ** 2
+        if self.fbp_interpolate_boundary:
+            out = torch.nn.functional.pad(out[:, :, 2:-2, 2:-2], (2, 2, 2, 2), mode="replicate")
+        return out
+
+    def A_dagger(self, y, fbp=False, **kwargs):
+        if fbp:
+            return self.fbp(y, **kwargs)
+        return super().A_dagger(y, **kwargs)

@@ -140,6 +140,35 @@ int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const
 int dinv_conv_up2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
                     const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Tomography: parallel-beam Radon, exact adjoint (gather form), ramp filter   */
+/* (deepinv/physics/functional/radon.py:74-173, 176-342;                       */
+/*  deepinv/physics/tomography.py:229-350; adjoint = forward.py:1302-1362)     */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_img;      /* B*C images */
+    int32_t width;      /* W (square image) */
+    int32_t grid;       /* G = ceil(sqrt2*W) (circle=0) or W (circle=1): detector count */
+    int32_t pad_before; /* (W+pad)//2 - W//2 (radon.py:261-268); 0 when circle */
+    int32_t n_angles;   /* A */
+    int32_t circle;     /* multiply by the inscribed-disc mask (radon.py:270-283) */
+    float   scale;      /* 1/operator_norm applied to the output (tomography.py:253-254) */
+    int32_t reserved;
+} dinv_radon_desc;
+
+size_t dinv_radon_workspace_bytes(const dinv_radon_desc* d, int32_t adjoint);
+/* x:[n_img,W,W] -> sino:[n_img,G,A].  xn:[G] = linspace(-1,1,G) (affine_grid base grid, fp32);
+ * cs:[A][2] = (cos,sin) of the angles in fp32 radians, both built by the host exactly as the
+ * reference builds them (radon.py:70-71, 334-341). */
+int dinv_radon_forward(const dinv_radon_desc* d, const float* x, const float* xn, const float* cs,
+                       float* sino, void* ws, size_t ws_bytes, dinv_stream_t stream);
+/* exact transpose of dinv_radon_forward: sino:[n_img,G,A] -> x:[n_img,W,W] */
+int dinv_radon_adjoint(const dinv_radon_desc* d, const float* sino, const float* xn, const float* cs,
+                       float* x, void* ws, size_t ws_bytes, dinv_stream_t stream);
+/* ramp filter along the detector axis of sino:[n_img,n_det,A] (RampFilter, radon.py:74-173) */
+int dinv_radon_ramp(int32_t n_img, int32_t n_det, int32_t n_angles, const float* sino, float* out,
+                    dinv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

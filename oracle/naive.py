@@ -47,3 +47,35 @@ def multicoil_AT(y, maps, mask, ndim=2):
     kc = my[:, 0] + 1j * my[:, 1]
     im = centered_dftn(kc, ndim, inverse=True)
     return _planar(np.sum(np.conj(maps.astype(np.complex128)) * im, axis=1))
+
+
+def radon_forward(x, angles_deg, circle=False):
+    """A.5 as explicit fp64 loops; x [W,W] -> [G,A].  Coordinates follow affine_grid/grid_sample with
+    align_corners=True (deepinv/physics/functional/radon.py:7-10, 252-342)."""
+    W = x.shape[0]
+    if circle:
+        ax = 2 * np.arange(W) / (W - 1) - 1.0
+        x = x * ((ax[:, None] ** 2 + ax[None, :] ** 2) <= 1)
+        G, pb = W, 0
+    else:
+        G = int(np.ceil(np.float32(np.sqrt(np.float32(2))) * np.float32(W)))
+        pad = int(np.ceil(np.float32(np.sqrt(np.float32(2))) * np.float32(W) - W))
+        pb = (W + pad) // 2 - W // 2
+    xp = np.zeros((G, G))
+    xp[pb:pb + W, pb:pb + W] = x
+    c = (G - 1) / 2.0
+    out = np.zeros((G, len(angles_deg)))
+    for a, deg in enumerate(angles_deg):
+        th = np.deg2rad(deg)
+        ct, st = np.cos(th), np.sin(th)
+        for j in range(G):
+            for i in range(G):
+                px = ct * (j - c) + st * (i - c) + c
+                py = -st * (j - c) + ct * (i - c) + c
+                x0, y0 = int(np.floor(px)), int(np.floor(py))
+                tx, ty = px - x0, py - y0
+                for (yy, xx, w) in ((y0, x0, (1 - tx) * (1 - ty)), (y0, x0 + 1, tx * (1 - ty)),
+                                    (y0 + 1, x0, (1 - tx) * ty), (y0 + 1, x0 + 1, tx * ty)):
+                    if 0 <= yy < G and 0 <= xx < G:
+                        out[j, a] += w * xp[yy, xx]
+    return out

@@ -125,3 +125,87 @@ def radial_mask(H, W, n_spokes):
         ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
         mask[yy[ok], xx[ok]] = 1.0
     return mask
+
+# --------------------------------------------------------------------------------------
+# Tomography  (deepinv/physics/functional/radon.py:74-342, deepinv/physics/tomography.py:229-350)
+# --------------------------------------------------------------------------------------
+_SQRT2 = (2 * torch.ones(1)).sqrt()
+
+
+def _deg2rad(x):
+    """radon.py:70-71"""
+    return x * 4 * torch.ones(1, dtype=x.dtype).atan() / 180
+
+
+def radon_grids(angles_deg, grid_size):
+    """Radon._create_grids, parallel beam (radon.py:311-342): one [1,G,G,2] grid per angle."""
+    grids = []
+    for theta in angles_deg:
+        t = _deg2rad(theta)
+        R = torch.tensor([[[t.cos(), t.sin(), 0], [-t.sin(), t.cos(), 0]]], dtype=torch.float)
+        grids.append(F.affine_grid(R, torch.Size([1, 1, grid_size, grid_size]), align_corners=True))
+    return grids
+
+
+def radon_pad(W):
+    """radon.py:261-268"""
+    diagonal = _SQRT2 * W
+    pad = int((diagonal - W).ceil())
+    pad_before = (W + pad) // 2 - W // 2
+    return pad_before, pad - pad_before
+
+
+def radon_forward(x, angles_deg, circle=False):
+    """Radon.forward, sequential branch (radon.py:252-309); x [N,C,W,W] -> [N,C,G,A]"""
+    N, C, W, _ = x.shape
+    if not circle:
+        pb, pa = radon_pad(W)
+        x = F.pad(x, (pb, pa, pb, pa))
+    else:
+        yax = 2 * torch.arange(W, dtype=torch.float)[None, :].expand(W, -1)[None, None] / (W - 1) - 1.0
+        x = x * ((yax.transpose(-2, -1) ** 2 + yax ** 2 <= 1).to(torch.float))
+    G = x.shape[-1]
+    out = torch.zeros(N, C, G, len(angles_deg), dtype=x.dtype)
+    for i, grid in enumerate(radon_grids(angles_deg, G)):
+        rotated = F.grid_sample(x, grid.repeat(N, 1, 1, 1), align_corners=True, mode="bilinear")
+        out[..., i] = rotated.sum(2)
+    return out
+
+
+def radon_adjoint(y, angles_deg, W, circle=False):
+    """exact adjoint via the vector-Jacobian product, as adjoint_function does (forward.py:1302-1362)"""
+    N, C = y.shape[:2]
+    x = torch.ones(N, C, W, W, requires_grad=True)
+    _, vjp = torch.func.vjp(lambda v: radon_forward(v, angles_deg, circle), x)
+    return vjp(y)[0]
+
+
+def ramp_fourier_filter(size):
+    """AbstractFilter._get_fourier_filter (radon.py:151-162)"""
+    n = torch.cat([torch.arange(1, size / 2 + 1, 2), torch.arange(size / 2 - 1, 0, -2)])
+    f = torch.zeros(size)
+    f[0] = 0.25
+    f[1::2] = -1 / (torch.pi * n) ** 2
+    return 2 * torch.fft.rfft(f, dim=-1)
+
+
+def ramp_filter(y):
+    """AbstractFilter.forward/filter along dim -2 (radon.py:79-149)"""
+    n = y.shape[-2]
+    P = max(64, int(2 ** (2 * torch.tensor(n)).float().log2().ceil()))
+    ff = ramp_fourier_filter(P).unsqueeze(-1)
+    padded = F.pad(y, (0, 0, 0, P - n))
+    proj = torch.fft.rfft(padded, dim=-2) * ff
+    return torch.fft.irfft(proj, dim=-2)[:, :, :n, :].contiguous()
+
+
+def tomography_fbp(y, angles_deg, W, operator_norm=None, circle=False):
+    """Tomography.fbp, exact-adjoint branch (tomography.py:258-293)"""
+    y = ramp_filter(y)
+    out = radon_adjoint(y, angles_deg, W, circle)
+    if operator_norm is not None:
+        out = out / operator_norm      # the adjoint of A = radon/||A|| inherits the division
+    out = out * torch.pi / (2 * len(angles_deg))
+    if operator_norm is not None:
+        out = out * operator_norm ** 2
+    return out

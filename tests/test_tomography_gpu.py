@@ -1,0 +1,88 @@
+"""Tomography (Radon fwd / exact adjoint / ramp / FBP) vs the CPU oracle.  fp32, tol 1e-4 relative."""
+import pytest
+import torch
+
+from conftest import dot_test, rel_err
+from oracle import physics_cpu as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("W,nang,circle,B,C", [(16, 16, False, 2, 1), (16, 16, True, 1, 2), (33, 20, False, 3, 1),
+                                               (64, 45, False, 9, 1), (64, 45, True, 2, 3), (128, 60, False, 1, 1)])
+def test_radon_forward_adjoint(dev, W, nang, circle, B, C):
+    import deepinv_amd as dinv
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, C, W, W, generator=g)
+    phys = dinv.physics.Tomography(angles=nang, img_width=W, circle=circle, normalize=False, device=dev)
+    ang = phys.angles.cpu()
+    y = phys.A(x.to(dev))
+    y_ref = O.radon_forward(x, ang, circle)
+    assert y.shape == y_ref.shape
+    assert rel_err(y, y_ref) < TOL
+    v = torch.randn(y_ref.shape, generator=g)
+    xa = phys.A_adjoint(v.to(dev))
+    assert rel_err(xa, O.radon_adjoint(v, ang, W, circle)) < TOL
+    assert dot_test(phys, x.to(dev), y) < 1e-5
+    assert abs(float(phys.adjointness_test(x.to(dev)))) < 1e-3 * max(1.0, float(y_ref.abs().sum()) ** 0.5)
+
+
+def test_tomography_docstring_known_answer(dev):
+    """literal vectors of the reference docstring (deepinv/physics/tomography.py:91-114)"""
+    import deepinv_amd as dinv
+
+    seed = torch.manual_seed(0)
+    x = torch.randn(1, 1, 4, 4)
+    angles = torch.linspace(0, 45, steps=3)
+    physics = dinv.physics.Tomography(angles=angles, img_width=4, circle=True, normalize=True, device=dev)
+    physics.operator_norm.fill_(1.0)  # compare the un-normalised projector against the oracle below
+    ref = O.radon_forward(x, angles, circle=True)
+    assert torch.allclose(physics.A(x.to(dev)).cpu(), ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,A", [(23, 16), (91, 45), (725, 32)])
+def test_ramp_filter(dev, N, A):
+    from deepinv_amd.hip import radon as hr
+
+    y = torch.randn(2, 1, N, A, generator=torch.Generator().manual_seed(1))
+    out = hr.ramp_filter(y.to(dev))
+    assert rel_err(out, O.ramp_filter(y)) < TOL
+
+
+def test_fbp_and_normalisation(dev):
+    import deepinv_amd as dinv
+
+    W, nang = 64, 90
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 1, W, W, generator=g)
+    torch.manual_seed(0)
+    phys = dinv.physics.Tomography(angles=nang, img_width=W, normalize=True, device=dev)
+    # ||A^T A|| ~ 1 after normalisation (reference test_physics.py:1460-1466)
+    sq = phys.compute_sqnorm(torch.randn(1, 1, W, W, device=dev), tol=1e-4, verbose=False)
+    assert abs(float(sq) - 1.0) < 1e-2
+    nrm = phys.operator_norm.cpu()
+    ang = phys.angles.cpu()
+    y_ref = O.radon_forward(x, ang) / nrm
+    y = phys.A(x.to(dev))
+    assert rel_err(y, y_ref) < TOL
+    rec = phys.A_dagger(y, fbp=True)
+    assert rel_err(rec, O.tomography_fbp(y_ref, ang, W, operator_norm=nrm)) < TOL
+    # FBP is a decent inverse (reference tolerance 65 %: test_physics.py:1468-1477)
+    assert rel_err(rec, x) < 0.65
+    # CG pseudo-inverse through the kernels (5 % in the reference)
+    phys2 = dinv.physics.Tomography(angles=nang, img_width=W, normalize=True, device=dev, max_iter=100, tol=1e-5)
+    r = phys2.A_dagger(phys2.A(x.to(dev)))
+    assert rel_err(r, x) < 0.15
+
+
+def test_radon_autograd(dev):
+    import deepinv_amd as dinv
+
+    phys = dinv.physics.Tomography(angles=12, img_width=16, normalize=False, device=dev)
+    x = torch.rand(1, 1, 16, 16, device=dev, requires_grad=True)
+    y = phys.A(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    assert rel_err(x.grad, phys.A_adjoint(w)) < 1e-6
