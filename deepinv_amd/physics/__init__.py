@@ -3,3 +3,5 @@ from .forward import (Physics, LinearPhysics, DecomposablePhysics, Denoising, ad
 from .noise import NoiseModel, ZeroNoise, GaussianNoise
 from .mri import MRI, MultiCoilMRI, MRIMixin
 from .tomography import Tomography, RampFilter
+from .blur import Blur, BlurFFT, Downsampling
+from . import functional

@@ -169,6 +169,35 @@ int dinv_radon_adjoint(const dinv_radon_desc* d, const float* sino, const float*
 int dinv_radon_ramp(int32_t n_img, int32_t n_det, int32_t n_angles, const float* sino, float* out,
                     dinv_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Blur / Downsampling: padded true convolution, its exact transpose, and the  */
+/* real<->half-complex 2-D FFT used by BlurFFT                                 */
+/* (deepinv/physics/functional/convolution.py:42-164, 689-758, 837-865;        */
+/*  deepinv/physics/blur.py:255-329, 639-657)                                  */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, channels, height, width;  /* full-resolution image x: [B,C,H,W] */
+    int32_t fbatch, fchannels, fh, fw;       /* filter [fb in {1,B}, fc in {1,C}, fh, fw] */
+    int32_t mode;    /* 0 valid, 1 circular, 2 reflect, 3 replicate, 4 constant(zeros) */
+    int32_t stride;  /* 1 for Blur; Downsampling factor otherwise (output = conv[::s, ::s]) */
+} dinv_conv_desc;
+
+int dinv_conv2d_out_size(const dinv_conv_desc* d, int32_t* ho, int32_t* wo);
+/* y = (k (*) pad(x))[::s, ::s]   (conv2d, convolution.py:42-107; Downsampling.A, blur.py:255-283) */
+int dinv_conv2d(const dinv_conv_desc* d, const float* x, const float* filter, float* y, dinv_stream_t stream);
+/* exact transpose of dinv_conv2d: y:[B,C,Ho,Wo] -> x:[B,C,H,W]
+ * (conv_transpose2d + _apply_transpose_padding, convolution.py:110-164, 689-758) */
+int dinv_conv2d_transpose(const dinv_conv_desc* d, const float* y, const float* filter, float* x,
+                          dinv_stream_t stream);
+
+/* rfft2 / irfft2 over the last two dims of a real [P,H,W] tensor (half spectrum [P,H,W/2+1] complex);
+ * unnormalised transforms times `scale`. */
+int dinv_rfft2(const float* x, float* out, int64_t P, const dinv_fft_plan* plan_h, const void* table_h,
+               const dinv_fft_plan* plan_w, const void* table_w, float scale, dinv_stream_t stream);
+int dinv_irfft2(const float* in, float* out, int64_t P, const dinv_fft_plan* plan_h, const void* table_h,
+                const dinv_fft_plan* plan_w, const void* table_w, float scale, void* ws, size_t ws_bytes,
+                dinv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

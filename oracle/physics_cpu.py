@@ -209,3 +209,101 @@ def tomography_fbp(y, angles_deg, W, operator_norm=None, circle=False):
     if operator_norm is not None:
         out = out * operator_norm ** 2
     return out
+
+# --------------------------------------------------------------------------------------
+# Blur / BlurFFT / Downsampling
+# (deepinv/physics/functional/convolution.py:42-164, 790-865; deepinv/physics/blur.py:255-363, 639-690)
+# --------------------------------------------------------------------------------------
+
+
+def conv2d(x, filter, padding="valid"):
+    """dF.conv2d (convolution.py:42-107): flipped filter, pad (pw-iw, pw, ph-ih, ph), grouped conv."""
+    if padding == "zeros":
+        padding = "constant"
+    B, C, H, W = x.shape
+    b, c, h, w = filter.shape
+    filter = filter.flip(dims=(-2, -1)).expand(B if b == 1 else b, C if c == 1 else c, h, w).contiguous()
+    if padding != "valid":
+        ph, ih, pw, iw = h // 2, (h - 1) % 2, w // 2, (w - 1) % 2
+        x = F.pad(x, (pw - iw, pw, ph - ih, ph), mode=padding, value=0)
+        H, W = x.shape[-2:]
+    out = F.conv2d(x.reshape(1, -1, H, W), filter.reshape(B * C, -1, h, w), padding="valid", groups=B * C)
+    return out.view(B, C, out.size(-2), -1).contiguous()
+
+
+def conv_transpose2d(y, filter, padding, H, W):
+    """exact transpose of conv2d: obtained by autograd, which is what the reference's own adjointness tests
+    (test_physics_functional.py:158-246) pin conv_transpose2d + _apply_transpose_padding against."""
+    B, C = y.shape[:2]
+    x = torch.zeros(B, C, H, W, requires_grad=True)
+    _, vjp = torch.func.vjp(lambda v: conv2d(v, filter, padding), x)
+    return vjp(y)[0]
+
+
+def filter_fft(filter, img_size, real_fft=True):
+    """convolution.py:790-812 over the last two dims"""
+    h, w = filter.shape[-2:]
+    f = F.pad(filter, (0, img_size[-1] - w, 0, img_size[-2] - h))
+    f = torch.roll(f, shifts=(-int(h / 2), -int(w / 2)), dims=(-2, -1))
+    return torch.fft.rfftn(f, dim=(-2, -1)) if real_fft else torch.fft.fftn(f, dim=(-2, -1))
+
+
+def blurfft_params(img_size, filter):
+    """BlurFFT.get_filter_parameters (blur.py:659-690)"""
+    if img_size[0] > filter.shape[1]:
+        filter = filter.repeat(1, img_size[0], 1, 1)
+    spec = filter_fft(filter, img_size)
+    mask = torch.abs(spec).unsqueeze(-1)
+    return torch.cat([mask, mask], dim=-1), torch.exp(1j * torch.angle(spec))
+
+
+def blurfft_A(x, mask, angle, img_size):
+    """U(mask * V_adjoint(x)) (forward.py:1080-1096, blur.py:639-657)"""
+    v = mask * torch.view_as_real(torch.fft.rfft2(x, norm="ortho"))
+    return torch.fft.irfft2(torch.view_as_complex(v) * angle, norm="ortho", s=img_size[-2:])
+
+
+def blurfft_AT(y, mask, angle, img_size):
+    """V(conj(mask) * U_adjoint(y)) (forward.py:1098-1117)"""
+    u = torch.view_as_real(torch.fft.rfft2(y, norm="ortho") * torch.conj(angle))
+    return torch.fft.irfft2(torch.view_as_complex((mask * u).contiguous()), norm="ortho", s=img_size[-2:])
+
+
+def blurfft_prox_l2(z, y, gamma, mask, angle, img_size):
+    """forward.py:1212-1234"""
+    b = blurfft_AT(y, mask, angle, img_size) + z / gamma
+    vb = torch.view_as_real(torch.fft.rfft2(b, norm="ortho")) / (mask * mask + 1 / gamma)
+    return torch.fft.irfft2(torch.view_as_complex(vb.contiguous()), norm="ortho", s=img_size[-2:])
+
+
+def downsampling_A(x, filter, factor, padding="circular"):
+    """blur.py:255-283"""
+    if filter is not None:
+        x = conv2d(x, filter, padding)
+    return x[:, :, ::factor, ::factor]
+
+
+def downsampling_AT(y, filter, factor, img_size, padding="circular"):
+    """blur.py:285-329"""
+    x = torch.zeros((y.shape[0],) + tuple(img_size), dtype=y.dtype)
+    x[:, :, ::factor, ::factor] = y
+    if filter is not None:
+        x = conv_transpose2d(x, filter, padding, img_size[-2], img_size[-1])
+    return x
+
+
+def downsampling_prox_l2(z, y, gamma, filter, factor, img_size):
+    """closed form for circular padding (blur.py:331-363)"""
+    Fh = filter_fft(filter, img_size, real_fft=False)
+    Fhc, Fh2 = torch.conj(Fh), torch.conj(Fh) * Fh
+    z_hat = downsampling_AT(y, filter, factor, img_size) + z / gamma
+    Fz = torch.fft.fft2(z_hat)
+
+    def splits(a, sf):
+        b = torch.stack(torch.chunk(a, sf, dim=2), dim=4)
+        return torch.cat(torch.chunk(b, sf, dim=3), dim=4)
+
+    top = torch.mean(splits(Fh * Fz, factor), dim=-1)
+    below = torch.mean(splits(Fh2, factor), dim=-1) + 1 / gamma
+    rc = Fhc * (top / below).repeat(1, 1, factor, factor)
+    return (z_hat - torch.real(torch.fft.ifft2(rc))) * gamma
