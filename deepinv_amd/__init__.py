@@ -13,3 +13,5 @@ from . import models  # noqa: F401
 from . import optim  # noqa: F401
 from . import unfolded  # noqa: F401
 from . import utils  # noqa: F401
+from . import sampling  # noqa: F401
+from . import distributed  # noqa: F401

@@ -1,0 +1,138 @@
+"""Iteration loops through the HIP operators: PnP-HQS + CG on Tomography, unfolded PGD autograd on 3-D
+multi-coil MRI, DiffPIR on x4 super-resolution — each against the CPU oracle."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import drunet_cpu as OD
+from oracle import optim_cpu as OO
+from oracle import physics_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pnp_hqs_tomography_with_cg(dev):
+    """config-3 shape in miniature: FBP init + PnP-HQS, prox by CG on the Radon kernels"""
+    import deepinv_amd as dinv
+
+    W, nang, B = 64, 60, 2
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, 1, W, W, generator=g)
+    phys = dinv.physics.Tomography(angles=nang, img_width=W, normalize=True, device=dev, max_iter=30, tol=1e-5)
+    nrm = phys.operator_norm.cpu()
+    ang = phys.angles.cpu()
+    sd = OD.init_state_dict(1, 1, seed=3)
+    den = dinv.models.DRUNet(1, 1, pretrained=None).to(dev).eval()
+    den.load_state_dict(sd)
+    A = lambda v: O.radon_forward(v, ang) / nrm
+    AT = lambda v: O.radon_adjoint(v, ang, W) / nrm
+    y_ref = A(x)
+    y = phys.A(x.to(dev))
+    assert rel_err(y, y_ref) < 1e-4
+    steps, sigs = [1.0, 0.5], [0.08, 0.04]
+    model = dinv.optim.HQS(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=steps, g_param=sigs,
+                           max_iter=2, custom_init=lambda yy, p: p.A_dagger(yy, fbp=True))
+    rec = model(y, phys)
+    with torch.no_grad():
+        x0 = O.tomography_fbp(y_ref, ang, W, operator_norm=nrm)
+        prox = lambda z, yy, gam: OO.prox_l2_cg(z, yy, gam, A, AT, max_iter=30, tol=1e-5)
+        ref = OO.pnp_hqs(y_ref, prox, lambda u, s: OD.drunet(sd, u, s), steps, sigs, max_iter=2, x0=x0)
+    assert rel_err(rec, ref) < 1e-3   # CG stops on a tolerance: iteration counts may differ by one
+
+
+def test_unfolded_pgd_3d_multicoil_autograd(dev):
+    """config-4 shape in miniature: gradients flow through the fused MRI kernels (backward(A) = A^T)"""
+    import deepinv_amd as dinv
+
+    g = torch.Generator().manual_seed(1)
+    vol, coils, B = (4, 16, 16), 3, 2
+    x = torch.rand(B, 2, *vol, generator=g).to(dev)
+    maps = (torch.randn(1, coils, *vol, dtype=torch.complex64, generator=g) / coils ** 0.5).to(dev)
+    mask = (torch.rand(*vol, generator=g) > 0.5).float().to(dev)
+    phys = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, *vol), three_d=True, device=dev)
+    y = phys.A(x)
+
+    class Den(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv3d(2, 2, 3, padding=1)
+
+        def forward(self, u, s):
+            return u - s * self.c(u)
+
+    model = dinv.unfolded.unfolded_builder("PGD", data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(Den().to(dev)),
+                                           params_algo={"stepsize": 0.8, "g_param": 0.05, "lambda": 1.0}, max_iter=3,
+                                           trainable_params=["stepsize", "g_param"], device=dev).to(dev)
+    loss = (model(y, phys) - x).pow(2).mean()
+    loss.backward()
+    gs = {n: p.grad for n, p in model.named_parameters()}
+    assert all(v is not None and torch.isfinite(v).all() for v in gs.values())
+    # same graph with the oracle operators on CPU (plain torch autograd through torch.fft)
+    import copy
+    mc = copy.deepcopy(model).cpu()
+
+    class PhysCPU(dinv.physics.LinearPhysics):
+        def A(self, v, **k):
+            return O.multicoil_A(v, maps.cpu(), mask.cpu(), True)
+
+        def A_adjoint(self, v, **k):
+            return O.multicoil_AT(v, maps.cpu(), mask.cpu(), True)
+
+    for p in mc.parameters():
+        p.grad = None
+    lc = (mc(y.cpu(), PhysCPU()) - x.cpu()).pow(2).mean()
+    lc.backward()
+    assert abs(loss.item() - lc.item()) / lc.item() < 1e-4
+    for (n, p) in mc.named_parameters():
+        assert rel_err(gs[n], p.grad) < 1e-3, n
+
+
+def test_diffpir_superresolution(dev, monkeypatch):
+    """config-5 shape in miniature.  The sampler draws torch.randn_like on the device; to compare sample paths
+    both sides draw from one seeded CPU stream."""
+    import deepinv_amd as dinv
+
+    streams = {}
+
+    def fake_randn_like(t, **kw):
+        gen = streams.setdefault("g", torch.Generator().manual_seed(7))
+        return torch.randn(t.shape, generator=gen).to(t.device)
+
+    B, img, f = 2, (3, 32, 32), 4
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(B, *img, generator=g)
+    phys = dinv.physics.Downsampling(img_size=img, filter="bicubic", factor=f, padding="circular", device=dev,
+                                     noise_model=dinv.physics.GaussianNoise(0.05))
+    k = phys.filter.cpu()
+    y_ref = O.downsampling_A(x, k, f)
+    sd = OD.init_state_dict(3, 3, seed=5)
+    den = dinv.models.DRUNet(3, 3, pretrained=None).to(dev).eval()
+    den.load_state_dict(sd)
+    n_it = 6
+    sampler = dinv.sampling.DiffPIR(den, dinv.optim.L2(), sigma=0.05, max_iter=n_it, zeta=0.1, lambda_=7.0, device=dev)
+    monkeypatch.setattr(torch, "randn_like", fake_randn_like)
+    out = sampler(y_ref.to(dev), phys)
+    # ---- oracle restatement of DiffPIR.forward (deepinv/sampling/diffusion.py:423-513)
+    streams.clear()
+    cpu = dinv.sampling.DiffPIR(lambda u, s: OD.drunet(sd, u, s), None, sigma=0.05, max_iter=n_it, zeta=0.1,
+                                lambda_=7.0, device="cpu")
+    prox = lambda z, yy, gam: O.downsampling_prox_l2(z, yy, float(gam), k, f, img)
+    with torch.no_grad():
+        xx = 2 * O.downsampling_AT(y_ref, k, f, img) - 1
+        sr, _ = cpu.get_alpha_prod()
+        seq = cpu.seq
+        for i in range(len(seq)):
+            cs = cpu.sigmas[seq[i]]
+            t_i = cpu.find_nearest(cpu.reduced_alpha_cumprod, cs)
+            at = 1 / sr[t_i] ** 2
+            if i == 0:
+                xx = (xx + (cs ** 2 - 4.0 * 0.05 ** 2).sqrt() * fake_randn_like(xx)) / sr[-1]
+            x0 = (2 * OD.drunet(sd, xx / (2 * at.sqrt()) + 0.5, float(cs / 2)) - 1).clamp(-1, 1)
+            if not seq[i] == seq[-1]:
+                x0 = prox(x0 / 2 + 0.5, y_ref, 1.0 / (2 * cpu.rhos[t_i])) * 2 - 1
+                t_im1 = cpu.find_nearest(cpu.reduced_alpha_cumprod, cpu.sigmas[seq[i + 1]])
+                eps = (xx - cpu.sqrt_alphas_cumprod[t_i] * x0) / cpu.sqrt_1m_alphas_cumprod[t_i]
+                xx = (cpu.sqrt_alphas_cumprod[t_im1] * x0 + cpu.sqrt_1m_alphas_cumprod[t_im1] * (1 - 0.1) ** 0.5 * eps
+                      + cpu.sqrt_1m_alphas_cumprod[t_im1] * 0.1 ** 0.5 * fake_randn_like(xx))
+        ref = xx / 2 + 0.5
+    assert rel_err(out, ref) < 1e-3

@@ -1,0 +1,140 @@
+"""Host logic of the iteration loop on CPU with a plain matrix LinearPhysics (no kernels involved):
+the loop, parameter schedules, CG / least squares, unfolded trainable parameters.
+Mirrors reference tests: optim/optimizers.py:179-218 doctest, test_optim.py:373-465 (optimality
+condition), :1131-1180 (least-squares solvers)."""
+import pytest
+import torch
+
+import deepinv_amd as dinv
+
+
+class MatPhysics(dinv.physics.LinearPhysics):
+    def __init__(self, M):
+        super().__init__()
+        self.M = M
+
+    def A(self, x, **kw):
+        return x @ self.M.T
+
+    def A_adjoint(self, y, **kw):
+        return y @ self.M
+
+
+def test_pgd_doctest_two_vector():
+    """optimizers.py:179-218: min 1/2||Ax-y||^2 with A=diag(2,3), y=(2,3) -> x=(1,1)"""
+    phys = MatPhysics(torch.tensor([[2.0, 0.0], [0.0, 3.0]]))
+    y = torch.tensor([[2.0, 3.0]])
+    for algo, kw in ((dinv.optim.PGD, dict(stepsize=0.1, max_iter=500)), (dinv.optim.HQS, dict(stepsize=10.0, max_iter=200)),
+                     (dinv.optim.GD, dict(stepsize=0.1, max_iter=500)), (dinv.optim.FISTA, dict(stepsize=0.1, max_iter=500))):
+        x = algo(data_fidelity=dinv.optim.L2(), **kw)(y, phys)
+        assert torch.allclose(x, torch.ones(1, 2), atol=1e-3), algo.__name__
+
+
+def test_pgd_l1_optimality_condition():
+    """first-order optimality of lasso solved by PGD with an explicit L1 prox (test_optim.py:373-465 spirit)"""
+    torch.manual_seed(0)
+    M = torch.randn(6, 4, dtype=torch.float64)
+    phys = MatPhysics(M)
+    y = torch.randn(1, 6, dtype=torch.float64)
+    lam = 0.3
+
+    class L1(dinv.optim.Prior):
+        def __init__(self):
+            super().__init__()
+            self.explicit_prior = True
+
+        def fn(self, x, *a, **k):
+            return x.abs().sum(dim=-1)
+
+        def prox(self, x, *a, gamma=1.0, **k):
+            return torch.sign(x) * torch.clamp(x.abs() - gamma, min=0)
+
+    step = 0.9 / float(torch.linalg.matrix_norm(M, 2) ** 2)
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=L1(), lambda_reg=lam, stepsize=step, max_iter=5000,
+                           early_stop=True, thres_conv=1e-13)
+    x = model(y, phys)
+    grad = phys.A_adjoint(phys.A(x) - y)
+    # -grad in lam * subdifferential of |.|_1
+    nz = x.abs() > 1e-9
+    assert torch.allclose(-grad[nz], lam * torch.sign(x[nz]), atol=1e-6)
+    assert torch.all(grad[~nz].abs() <= lam + 1e-6)
+
+
+def test_params_schedules_and_metrics():
+    phys = MatPhysics(torch.eye(3))
+    y = torch.ones(2, 3)
+    steps = [0.5, 0.25, 0.125]
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), stepsize=steps, max_iter=3)
+    x, metrics = model(y, phys, x_gt=torch.ones(2, 3), compute_metrics=True)
+    assert len(metrics["residual"]) == 2 and len(metrics["residual"][0]) == 3 and len(metrics["psnr"][0]) == 4
+    with pytest.raises(ValueError):
+        dinv.optim.PGD(data_fidelity=dinv.optim.L2(), stepsize=[0.1, 0.2], max_iter=5)
+    # custom init (tensor / tuple / callable)
+    x2 = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), stepsize=0.0, max_iter=1, custom_init=lambda y, p: 3 * y)(y, phys)
+    assert torch.allclose(x2, 3 * y)
+
+
+def test_cg_least_squares_matches_dense_solve():
+    torch.manual_seed(1)
+    M = torch.randn(8, 5, dtype=torch.float64)
+    phys = MatPhysics(M)
+    y = torch.randn(3, 8, dtype=torch.float64)
+    z = torch.randn(3, 5, dtype=torch.float64)
+    gamma = 0.7
+    x = dinv.optim.least_squares(phys.A, phys.A_adjoint, y, z=z, init=z, gamma=gamma, parallel_dim=[0], max_iter=200,
+                                 tol=1e-12)
+    H = M.T @ M + torch.eye(5, dtype=torch.float64) / gamma
+    ref = torch.linalg.solve(H, (y @ M + z / gamma).T).T
+    assert torch.allclose(x, ref, atol=1e-8)
+    # pseudo-inverse branch (gamma=None, overcomplete): A^+ y
+    xd = dinv.optim.least_squares(phys.A, phys.A_adjoint, y, parallel_dim=[0], max_iter=200, tol=1e-12)
+    assert torch.allclose(xd, (torch.linalg.pinv(M) @ y.T).T, atol=1e-7)
+    # prox_l2 / A_dagger of LinearPhysics route through it, with implicit backward
+    phys.max_iter, phys.tol = 200, 1e-12
+    zz = z.clone().requires_grad_(True)
+    p = phys.prox_l2(zz, y, gamma)
+    assert torch.allclose(p, ref, atol=1e-7)
+    p.sum().backward()
+    assert torch.allclose(zz.grad, torch.linalg.solve(H, torch.ones(5, 3, dtype=torch.float64)).T / gamma, atol=1e-6)
+
+
+def test_unfolded_builder_trains():
+    """deepinv/tests/test_unfolded.py:25-125: parameters are registered, receive gradients and change"""
+    torch.manual_seed(2)
+    M = torch.randn(6, 4) / 3
+    phys = MatPhysics(M)
+    x_true = torch.randn(5, 4)
+    y = phys.A(x_true)
+
+    class TinyDenoiser(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(4, 4)
+
+        def forward(self, x, sigma):
+            return x + 0.1 * sigma * self.lin(x)
+
+    model = dinv.unfolded.unfolded_builder("PGD", data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(TinyDenoiser()),
+                                           params_algo={"stepsize": 0.05, "g_param": 0.1, "lambda": 1.0}, max_iter=4,
+                                           trainable_params=["stepsize", "g_param"])
+    names = [n for n, _ in model.named_parameters()]
+    assert "init_params_algo.stepsize.0" in names and "init_params_algo.g_param.0" in names
+    assert any(n.startswith("prior.0.denoiser") for n in names)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in model.parameters()]
+    loss0 = None
+    for _ in range(5):
+        opt.zero_grad()
+        loss = (model(y, phys) - x_true).pow(2).mean()
+        loss0 = loss.item() if loss0 is None else loss0
+        loss.backward()
+        opt.step()
+    assert all(p.grad is not None for p in model.parameters())
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, model.parameters()))
+    assert loss.item() < loss0
+
+
+def test_dpir_schedule():
+    s, step, n = dinv.optim.get_DPIR_params(0.05)
+    assert n == 8 and abs(float(s[0]) - 49 / 255) < 1e-6 and abs(float(s[-1]) - 0.05) < 1e-6
+    assert torch.allclose(step, (1 / 0.23) * (s / 0.05) ** 2)
