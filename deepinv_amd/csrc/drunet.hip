@@ -63,7 +63,7 @@ struct Conv3Args {
     int32_t cin, cout_valid, relu;
 };
 
-template <int MREP>
+template <int MREP, bool RELU, int NRES>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     constexpr int MT = 32 * MREP;
     __shared__ __attribute__((aligned(16))) float xs[3][KC][SEG];
@@ -82,28 +82,61 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
 
     constexpr int XV = 3 * KC * (SEG / 4);  // float4 loads of activations per chunk (1584)
     constexpr int WV = 9 * KC * MT / 4;     // float4 loads of weights per chunk
+    constexpr int XI = (XV + 255) / 256, WI = (WV + 255) / 256;
     const float4* wblk = reinterpret_cast<const float4*>(a.w) + (int64_t)blockIdx.y * nchunks * WV;
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();  // previous chunk's MFMA phase has consumed LDS
-        for (int idx = tid; idx < XV; idx += 256) {
-            const int row = idx / (SEG / 4);
-            const int c4 = idx - row * (SEG / 4);
-            const int seg = row / KC, kc = row - seg * KC;
-            const int64_t off = (int64_t)(ch * KC + kc) * a.g.cs + a.g.sl + p0 + (int64_t)(seg - 1) * a.g.wp - HALO + c4 * 4;
-            float4 v = *reinterpret_cast<const float4*>(a.x + off);
+    // per-thread staging slots are fixed across chunks: precompute the (row, col) decomposition once
+    int xoff_lds[XI];
+    int64_t xoff_g[XI];
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+        const int idx = min(tid + it * 256, XV - 1);  // surplus slots re-load the last element (never stored)
+        const int row = idx / (SEG / 4);
+        const int c4 = idx - row * (SEG / 4);
+        const int seg = row / KC, kc = row - seg * KC;
+        xoff_lds[it] = (seg * KC + kc) * SEG + c4 * 4;
+        xoff_g[it] = (int64_t)kc * a.g.cs + a.g.sl + p0 + (int64_t)(seg - 1) * a.g.wp - HALO + c4 * 4;
+    }
+    float* xs_flat = &xs[0][0][0];
+    float4* ws_flat = reinterpret_cast<float4*>(&ws[0][0][0]);
+
+    // software pipeline: the global loads of chunk ch+1 are in flight while chunk ch is on the matrix cores;
+    // every load of a chunk is issued back to back (one exposed latency per chunk at most, not one per load).
+    // One code location for the loads (ch = -1 is the prologue trip) keeps xv/wv4 in registers.
+    float4 xv[XI];
+    float4 w0, w1, w2, w3, w4;  // weight prefetch slots as scalars (an array here is left in scratch by hipcc)
+    static_assert(WI <= 5, "weight prefetch slots");
+    for (int ch = -1; ch < nchunks; ++ch) {
+        if (ch >= 0) {
+            __syncthreads();  // previous chunk's MFMA phase has consumed LDS
+#pragma unroll
+            for (int it = 0; it < XI; ++it)
+                if (it < XI - 1 || tid + it * 256 < XV) *reinterpret_cast<float4*>(xs_flat + xoff_lds[it]) = xv[it];
+#define DINV_WST(IT, REG) if (IT < WI && (IT < WI - 1 || tid + IT * 256 < WV)) ws_flat[tid + IT * 256] = REG;
+            DINV_WST(0, w0) DINV_WST(1, w1) DINV_WST(2, w2) DINV_WST(3, w3) DINV_WST(4, w4)
+#undef DINV_WST
+            __syncthreads();
+        }
+        if (ch + 1 < nchunks) {
+            // unpredicated loads (surplus slots re-load the last element and are never stored): a predicated
+            // load into a loop-carried register forces an early vmcnt wait
+            const float* xbase = a.x + (int64_t)(ch + 1) * KC * a.g.cs;
+#pragma unroll
+            for (int it = 0; it < XI; ++it) xv[it] = *reinterpret_cast<const float4*>(xbase + xoff_g[it]);
             if (a.x2) {
-                const float4 u = *reinterpret_cast<const float4*>(a.x2 + off);
-                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                const float* x2base = a.x2 + (int64_t)(ch + 1) * KC * a.g.cs;
+#pragma unroll
+                for (int it = 0; it < XI; ++it) {
+                    const float4 u = *reinterpret_cast<const float4*>(x2base + xoff_g[it]);
+                    xv[it].x += u.x; xv[it].y += u.y; xv[it].z += u.z; xv[it].w += u.w;
+                }
             }
-            *reinterpret_cast<float4*>(&xs[seg][kc][c4 * 4]) = v;
+            const float4* wsrc = wblk + (int64_t)(ch + 1) * WV;
+#define DINV_WLD(IT, REG) if (IT < WI) REG = wsrc[min(tid + IT * 256, WV - 1)];
+            DINV_WLD(0, w0) DINV_WLD(1, w1) DINV_WLD(2, w2) DINV_WLD(3, w3) DINV_WLD(4, w4)
+#undef DINV_WLD
         }
-        {
-            const float4* src = wblk + (int64_t)ch * WV;
-            float4* dst = reinterpret_cast<float4*>(&ws[0][0][0]);
-            for (int idx = tid; idx < WV; idx += 256) dst[idx] = src[idx];
-        }
-        __syncthreads();
+        if (ch < 0) continue;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3 - 1;
@@ -132,19 +165,28 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
         const bool in = interior(a.g, p);
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
+            const int cb = co0 + m * 32 + 4 * lhi;
+            if (cb >= a.cout_valid) continue;  // (tail conv: only the first cout_valid planes exist)
+            const int64_t ob = (int64_t)cb * a.g.cs + a.g.sl + p;
+            float r1[16], r2[16];
+            // residual planes have zero borders, so border lanes may load them too: 16 independent loads in flight
+            if (NRES >= 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) r1[r] = a.res1[ob + (int64_t)((r & 3) + 8 * (r >> 2)) * a.g.cs];
+            }
+            if (NRES >= 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) r2[r] = a.res2[ob + (int64_t)((r & 3) + 8 * (r >> 2)) * a.g.cs];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (co >= a.cout_valid) continue;
-                const int64_t o = (int64_t)co * a.g.cs + a.g.sl + p;
-                float v = 0.f;
-                if (in) {
-                    v = acc[m][n][r];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.res1) v += a.res1[o];
-                    if (a.res2) v += a.res2[o];
-                }
-                a.y[o] = v;
+                const int co = cb + (r & 3) + 8 * (r >> 2);
+                if (MREP == 1 && co >= a.cout_valid) continue;
+                float v = acc[m][n][r];
+                if (RELU) v = fmaxf(v, 0.f);
+                if (NRES >= 1) v += r1[r];
+                if (NRES >= 2) v += r2[r];
+                a.y[ob + (int64_t)((r & 3) + 8 * (r >> 2)) * a.g.cs] = in ? v : 0.f;
             }
         }
     }
@@ -351,10 +393,21 @@ extern "C" int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float*
     Conv3Args a{make_geom(*g), x, x2, w_packed, y, res1, res2, cin, cout_valid, relu};
     const unsigned gx = (unsigned)ceil_div(g->np, NT);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nres = (res1 ? 1 : 0) + (res2 ? 1 : 0);
+    DINV_REQUIRE(res1 || !res2, "res2 given without res1");
     if (cout % 64 == 0) {
-        hipLaunchKernelGGL(conv3x3_kernel<2>, dim3(gx, cout / 64), dim3(256), 0, s, a);
+        DINV_REQUIRE(cout_valid == cout, "partial output planes are only supported for 32-wide cout tiles");
+        const dim3 grid(gx, cout / 64);
+#define DINV_LAUNCH_C3(RELU, NRES) hipLaunchKernelGGL((conv3x3_kernel<2, RELU, NRES>), grid, dim3(256), 0, s, a)
+        if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }
+        else      { if (nres == 0) DINV_LAUNCH_C3(false, 0); else if (nres == 1) DINV_LAUNCH_C3(false, 1); else DINV_LAUNCH_C3(false, 2); }
+#undef DINV_LAUNCH_C3
     } else {
-        hipLaunchKernelGGL(conv3x3_kernel<1>, dim3(gx, cout / 32), dim3(256), 0, s, a);
+        const dim3 grid(gx, cout / 32);
+#define DINV_LAUNCH_C3(RELU, NRES) hipLaunchKernelGGL((conv3x3_kernel<1, RELU, NRES>), grid, dim3(256), 0, s, a)
+        if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }
+        else      { if (nres == 0) DINV_LAUNCH_C3(false, 0); else if (nres == 1) DINV_LAUNCH_C3(false, 1); else DINV_LAUNCH_C3(false, 2); }
+#undef DINV_LAUNCH_C3
     }
     DINV_CHECK_LAUNCH();
     return 0;
