@@ -229,22 +229,38 @@ __global__ __launch_bounds__(256) void down2x2_kernel(DownArgs a) {
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    for (int tap = 0; tap < 4; ++tap) {
+    // K loop = 4 taps x cin, walked in groups of 4 k-steps (8 channels); the 16 operand loads of group g+1
+    // are issued before the 16 MFMAs of group g (register double buffer)
+    const int ngroups = 4 * (a.cin / 8);
+    float av[2][4][2], bv[2][4][2];
+    auto load_group = [&](int gidx, float (&A)[4][2], float (&B)[4][2]) {
+        const int tap = gidx / (a.cin / 8), c0 = (gidx - tap * (a.cin / 8)) * 8;
         const int64_t toff = (int64_t)(tap >> 1) * a.gi.wp + (tap & 1);
         const float* wt = a.w + (int64_t)tap * a.cin * a.cout + co0 + l31;
-#pragma unroll 4
-        for (int ci = lhi; ci < a.cin; ci += 2) {
-            float av[2], bv[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) av[m] = wt[(int64_t)ci * a.cout + m * 32];
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int ci = c0 + 2 * sidx + lhi;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bv[n] = a.x[(int64_t)ci * a.gi.cs + ioff[n] + toff];
+            for (int m = 0; m < 2; ++m) A[sidx][m] = wt[(int64_t)ci * a.cout + m * 32];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) B[sidx][n] = a.x[(int64_t)ci * a.gi.cs + ioff[n] + toff];
+        }
+    };
+    auto mma_group = [&](float (&A)[4][2], float (&B)[4][2]) {
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-        }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sidx][m], B[sidx][n], acc[m][n], 0, 0, 0);
+    };
+    load_group(0, av[0], bv[0]);
+    for (int gidx = 0; gidx < ngroups; gidx += 2) {
+        if (gidx + 1 < ngroups) load_group(gidx + 1, av[1], bv[1]);
+        mma_group(av[0], bv[0]);
+        if (gidx + 2 < ngroups) load_group(gidx + 2, av[0], bv[0]);
+        if (gidx + 1 < ngroups) mma_group(av[1], bv[1]);
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -300,21 +316,36 @@ __global__ __launch_bounds__(256) void up2x2_kernel(UpArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     const float* wt = a.w + (int64_t)tap * a.cin * a.cout + co0 + l31;
-#pragma unroll 4
-    for (int ci = lhi; ci < a.cin; ci += 2) {
-        float av[2], bv[2];
+    const int ngroups = a.cin / 8;
+    float av[2][4][2], bv[2][4][2];
+    auto load_group = [&](int gidx, float (&A)[4][2], float (&B)[4][2]) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) av[m] = wt[(int64_t)ci * a.cout + m * 32];
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int ci = gidx * 8 + 2 * sidx + lhi;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            bv[n] = a.x[(int64_t)ci * a.gi.cs + ioff[n]];
-            if (a.x2) bv[n] += a.x2[(int64_t)ci * a.gi.cs + ioff[n]];
+            for (int m = 0; m < 2; ++m) A[sidx][m] = wt[(int64_t)ci * a.cout + m * 32];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                B[sidx][n] = a.x[(int64_t)ci * a.gi.cs + ioff[n]];
+                if (a.x2) B[sidx][n] += a.x2[(int64_t)ci * a.gi.cs + ioff[n]];
+            }
         }
+    };
+    auto mma_group = [&](float (&A)[4][2], float (&B)[4][2]) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int sidx = 0; sidx < 4; ++sidx)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sidx][m], B[sidx][n], acc[m][n], 0, 0, 0);
+    };
+    load_group(0, av[0], bv[0]);
+    for (int gidx = 0; gidx < ngroups; gidx += 2) {
+        if (gidx + 1 < ngroups) load_group(gidx + 1, av[1], bv[1]);
+        mma_group(av[0], bv[0]);
+        if (gidx + 2 < ngroups) load_group(gidx + 2, av[0], bv[0]);
+        if (gidx + 1 < ngroups) mma_group(av[1], bv[1]);
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -420,7 +451,7 @@ extern "C" int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* 
     DINV_REQUIRE(x && w && y, "null tensor pointer");
     DINV_REQUIRE(gin->height == 2 * gout->height && gin->width == 2 * gout->width && gin->batch == gout->batch,
                  "down2x2 geometry mismatch");
-    DINV_REQUIRE(cin % 2 == 0 && cout % 64 == 0, "down2x2 needs even cin and cout %% 64 == 0 (got %d,%d)", cin, cout);
+    DINV_REQUIRE(cin % 8 == 0 && cout % 64 == 0, "down2x2 needs cin %% 8 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
     DownArgs a{make_geom(*gin), make_geom(*gout), x, w, y, cin, cout};
     hipLaunchKernelGGL(down2x2_kernel, dim3((unsigned)ceil_div(gout->np, NT), cout / 64), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
@@ -435,7 +466,7 @@ extern "C" int dinv_conv_up2x2(const dinv_act_geom* gin, const dinv_act_geom* go
     DINV_REQUIRE(x && w && y, "null tensor pointer");
     DINV_REQUIRE(gout->height == 2 * gin->height && gout->width == 2 * gin->width && gin->batch == gout->batch,
                  "up2x2 geometry mismatch");
-    DINV_REQUIRE(cin % 2 == 0 && cout % 64 == 0, "up2x2 needs even cin and cout %% 64 == 0 (got %d,%d)", cin, cout);
+    DINV_REQUIRE(cin % 8 == 0 && cout % 64 == 0, "up2x2 needs cin %% 8 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
     UpArgs a{make_geom(*gin), make_geom(*gout), x, x2, w, y, cin, cout};
     hipLaunchKernelGGL(up2x2_kernel, dim3((unsigned)ceil_div(gin->np, NT), cout / 64, 4), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);

@@ -11,6 +11,7 @@
 // change), so each pass is exactly one read and one write of the tensor.
 #pragma once
 #include "fft_core.hpp"
+#include "fft_static.hpp"
 
 namespace dinv {
 
@@ -132,11 +133,60 @@ inline int set_lds_limit(K kernel, size_t bytes) {
     return 0;
 }
 
+// ------------------------------------------------------------------ static-plan dispatch
+constexpr int kMaxGrid = 256 * 8;  // grid-stride over tiles: enough workgroups to fill 256 CUs several times
+
+template <int N> struct RowsL { static constexpr int value = N >= 512 ? 8 : (N >= 128 ? 16 : 32); };
+template <int N> struct ColsL { static constexpr int value = N == 16 ? 256 : 16; };
+
+template <int N, class Io>
+inline int launch_rows_static(Io io, int64_t nlines, const void* table, int inverse, int centered, float scale,
+                              hipStream_t s) {
+    using P = typename PlanFor<N>::P;
+    constexpr int L = RowsL<N>::value;
+    const int64_t ntiles = ceil_div(nlines, L);
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
+    if (inverse)
+        hipLaunchKernelGGL((fft_rows_static_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, nlines, ntiles,
+                           table, centered, scale);
+    else
+        hipLaunchKernelGGL((fft_rows_static_kernel<P, Io, false, L>), dim3(grid), dim3(256), 0, s, io, nlines, ntiles,
+                           table, centered, scale);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int N, class Io>
+inline int launch_cols_static(Io io, int64_t P_, int64_t Q, const void* table, int inverse, int centered, float scale,
+                              hipStream_t s) {
+    using P = typename PlanFor<N>::P;
+    constexpr int L = ColsL<N>::value;
+    const int64_t qtiles = ceil_div(Q, L);
+    const int64_t ntiles = P_ * qtiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
+    if (inverse)
+        hipLaunchKernelGGL((fft_cols_static_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, Q, qtiles, ntiles,
+                           table, centered, scale);
+    else
+        hipLaunchKernelGGL((fft_cols_static_kernel<P, Io, false, L>), dim3(grid), dim3(256), 0, s, io, Q, qtiles, ntiles,
+                           table, centered, scale);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+#define DINV_STATIC_SIZES(X) X(64) X(128) X(256) X(320) X(512)
+
 template <class Io>
 inline int launch_rows(Io io, int64_t nlines, const dinv_fft_plan& plan, const void* table, int inverse,
                        int centered, float scale, hipStream_t s) {
     if (nlines == 0) return 0;
     io.set_geometry(plan.n, 1);
+    switch (plan.n) {
+#define DINV_CASE(NN) case NN: return launch_rows_static<NN, Io>(io, nlines, table, inverse, centered, scale, s);
+        DINV_STATIC_SIZES(DINV_CASE)
+#undef DINV_CASE
+        default: break;
+    }
     const int lpb = rows_lines_per_block(plan);
     const size_t lds = fft_lds_bytes(plan, lpb);
     DINV_REQUIRE(lds <= kMaxLdsBytes, "fft length %d does not fit the 160 KiB LDS tile (%zu B)", plan.n, lds);
@@ -160,6 +210,12 @@ inline int launch_cols(Io io, int64_t P, int64_t Q, const dinv_fft_plan& plan, c
                        int centered, float scale, hipStream_t s) {
     if (P == 0 || Q == 0) return 0;
     io.set_geometry(plan.n, Q);
+    switch (plan.n) {
+#define DINV_CASE(NN) case NN: return launch_cols_static<NN, Io>(io, P, Q, table, inverse, centered, scale, s);
+        DINV_CASE(16) DINV_CASE(32) DINV_STATIC_SIZES(DINV_CASE)
+#undef DINV_CASE
+        default: break;
+    }
     const int tq = cols_tile_width(plan, Q);
     const size_t lds = fft_lds_bytes(plan, tq);
     DINV_REQUIRE(lds <= kMaxLdsBytes, "fft length %d does not fit the 160 KiB LDS tile (%zu B)", plan.n, lds);

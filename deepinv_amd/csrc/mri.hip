@@ -183,6 +183,87 @@ __global__ __launch_bounds__(256) void mri_rows_combine_kernel(const float2* __r
     }
 }
 
+// static-plan variant of the coil-combine pass: the coil sum is accumulated in registers by the threads that
+// own the last-stage outputs (fixed (line,k) per thread across coils -> deterministic order n = 0..N-1)
+struct CombineLine { int64_t t0, s0, x0; };  // offsets of coil 0 in t / maps, and of the output row
+
+template <class P, int L>
+__global__ __launch_bounds__(256) void mri_rows_combine_static_kernel(const float2* __restrict__ t,
+                                                                      const float2* __restrict__ maps,
+                                                                      float* __restrict__ x, int64_t nlines, int64_t R,
+                                                                      int ncoil, int maps_batch, int64_t ntiles,
+                                                                      const void* table, int centered, float scale) {
+    using TF = TileFft<P, true, true, L>;
+    constexpr int N = P::N;
+    __shared__ __attribute__((aligned(16))) float2 buf[TF::lds_floats2];
+    __shared__ CombineLine cl[L];
+    const float2* tw = reinterpret_cast<const float2*>(table);
+    const int tid = threadIdx.x;
+    const int c = centered ? N / 2 : 0;
+    const int64_t coil_stride = R * (int64_t)N;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t line0 = tile * L;
+        const int lines = (int)min((int64_t)L, nlines - line0);
+        __syncthreads();
+        if (tid < lines) {
+            const int64_t line = line0 + tid;
+            const int64_t b = line / R, r = line - b * R;
+            CombineLine v;
+            v.t0 = ((b * ncoil) * R + r) * (int64_t)N;
+            v.s0 = (((maps_batch > 1 ? b : 0) * ncoil) * R + r) * (int64_t)N;
+            v.x0 = ((b * 2) * R + r) * (int64_t)N;
+            cl[tid] = v;
+        }
+        __syncthreads();
+        float2 acc[TF::NSL][TF::RL];
+#pragma unroll
+        for (int a = 0; a < TF::NSL; ++a)
+#pragma unroll
+            for (int q = 0; q < TF::RL; ++q) acc[a][q] = make_float2(0.f, 0.f);
+        for (int coil = 0; coil < ncoil; ++coil) {
+            const int64_t co = coil * coil_stride;
+            TF::run(buf, tw, lines, c, scale, tid,
+                    [&](int line, int n) { return t[cl[line].t0 + co + n]; },
+                    [&](int slot, int line, int k, int q, float2 v) {
+                        if (maps) v = cmulc(v, maps[cl[line].s0 + co + k]);  // conj(S) * v
+                        acc[slot][q] = cadd(acc[slot][q], v);
+                    });
+            __syncthreads();  // buf is rewritten by the next coil's stage 1
+        }
+        // store: same item decomposition as the last stage of TileFft::run
+        constexpr int Q2N = (P::STAGES == 3) ? P::R2 : 1;
+#pragma unroll
+        for (int slot = 0; slot < TF::NSL; ++slot) {
+            const int w = tid + 256 * slot;
+            const int line = w / TF::KL, i = w - line * TF::KL;
+            if (w >= L * TF::KL || line >= lines) continue;
+            const int q1 = i % P::R1, q2 = i / P::R1;
+            float* xre = x + cl[line].x0;
+            float* xim = xre + coil_stride;
+#pragma unroll
+            for (int q = 0; q < TF::RL; ++q) {
+                int k = q1 + P::R1 * q2 + P::R1 * Q2N * q + c;
+                if (k >= N) k -= N;
+                xre[k] = acc[slot][q].x;
+                xim[k] = acc[slot][q].y;
+            }
+        }
+    }
+}
+
+template <int N>
+int launch_combine_static(const float2* t, const float2* maps, float* x, int64_t nlines, int64_t R, int ncoil,
+                          int maps_batch, const void* table, float scale, hipStream_t s) {
+    using P = typename PlanFor<N>::P;
+    constexpr int L = RowsL<N>::value;
+    const int64_t ntiles = ceil_div(nlines, L);
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
+    hipLaunchKernelGGL((mri_rows_combine_static_kernel<P, L>), dim3(grid), dim3(256), 0, s, t, maps, x, nlines, R, ncoil,
+                       maps_batch, ntiles, table, 1, scale);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
 int validate(const dinv_mri_desc* d) {
     DINV_REQUIRE(d != nullptr, "null descriptor");
     DINV_REQUIRE(d->ndim == 2 || d->ndim == 3, "ndim must be 2 or 3, got %d", d->ndim);
@@ -269,6 +350,17 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
     }
     // rows pass + coil combine
     const dinv_fft_plan& pw = d->plan[nd - 1];
+    {
+        const float2* mp = reinterpret_cast<const float2*>(maps);
+        const int64_t nl = (int64_t)d->batch * R;
+        const float sc = 1.0f / sqrtf((float)W);
+        switch (pw.n) {
+#define DINV_CASE(NN) case NN: return launch_combine_static<NN>(t, mp, x, nl, R, d->coils, d->maps_batch, d->table[nd - 1], sc, s);
+            DINV_STATIC_SIZES(DINV_CASE)
+#undef DINV_CASE
+            default: break;
+        }
+    }
     int lpb = rows_lines_per_block(pw);
     if (lpb > 16) lpb = 16;
     const int LS = fft_line_stride(pw.n);
