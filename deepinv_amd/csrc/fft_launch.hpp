@@ -11,6 +11,9 @@
 // change), so each pass is exactly one read and one write of the tensor.
 #pragma once
 #include "fft_core.hpp"
+#include <cstdlib>
+#include <type_traits>
+
 #include "fft_static.hpp"
 
 namespace dinv {
@@ -139,11 +142,19 @@ constexpr int kMaxGrid = 256 * 8;  // grid-stride over tiles: enough workgroups 
 template <int N> struct RowsL { static constexpr int value = N >= 512 ? 8 : (N >= 128 ? 16 : 32); };
 template <int N> struct ColsL { static constexpr int value = N == 16 ? 256 : 16; };
 
-template <int N, class Io>
-inline int launch_rows_static(Io io, int64_t nlines, const void* table, int inverse, int centered, float scale,
-                              hipStream_t s) {
-    using P = typename PlanFor<N>::P;
-    constexpr int L = RowsL<N>::value;
+// tunable: lines per workgroup of the rows passes (smaller tiles -> more workgroups per CU in flight)
+inline int rows_L_override() {
+    static int v = [] { const char* e = getenv("DINV_ROWS_L"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+template <class T, class = void> struct io_planar_store : std::false_type {};
+template <class T> struct io_planar_store<T, std::void_t<decltype(T::planar_store)>> : std::bool_constant<T::planar_store> {};
+
+template <int N, class Io, int L>
+inline int launch_rows_static_L(Io io, int64_t nlines, const void* table, int inverse, int centered, float scale,
+                                hipStream_t s) {
+    using P = std::conditional_t<io_planar_store<Io>::value, typename PlanForS<N>::P, typename PlanFor<N>::P>;
     const int64_t ntiles = ceil_div(nlines, L);
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
     if (inverse)
@@ -154,6 +165,22 @@ inline int launch_rows_static(Io io, int64_t nlines, const void* table, int inve
                            table, centered, scale);
     DINV_CHECK_LAUNCH();
     return 0;
+}
+
+template <int N, class Io>
+inline int launch_rows_static(Io io, int64_t nlines, const void* table, int inverse, int centered, float scale,
+                              hipStream_t s) {
+    int L = rows_L_override();
+    if (L == 0) L = RowsL<N>::value;
+    if (N >= 512 && L > 8) L = 8;
+    if (L <= 4) return launch_rows_static_L<N, Io, 4>(io, nlines, table, inverse, centered, scale, s);
+    if (L <= 8) return launch_rows_static_L<N, Io, 8>(io, nlines, table, inverse, centered, scale, s);
+    if constexpr (N < 512) {
+        if (L <= 16) return launch_rows_static_L<N, Io, 16>(io, nlines, table, inverse, centered, scale, s);
+        if constexpr (N < 128) return launch_rows_static_L<N, Io, 32>(io, nlines, table, inverse, centered, scale, s);
+        return launch_rows_static_L<N, Io, 16>(io, nlines, table, inverse, centered, scale, s);
+    }
+    return launch_rows_static_L<N, Io, 8>(io, nlines, table, inverse, centered, scale, s);
 }
 
 template <int N, class Io>

@@ -90,6 +90,13 @@ template <> struct PlanFor<256> { static constexpr bool ok = true; using P = Sta
 template <> struct PlanFor<320> { static constexpr bool ok = true; using P = StaticPlan<320, 5, 8, 8>; };
 template <> struct PlanFor<512> { static constexpr bool ok = true; using P = StaticPlan<512, 8, 8, 8>; };
 
+// store-friendly plans (R1 = 8): the last stage then emits k = i + 64*q3 with i = lane, i.e. 64 consecutive
+// outputs per register -> full 256-byte wave stores even for planar (4-byte) outputs
+template <int N> struct PlanForS { using P = typename PlanFor<N>::P; };
+template <> struct PlanForS<128> { using P = StaticPlan<128, 8, 8, 2>; };
+template <> struct PlanForS<256> { using P = StaticPlan<256, 8, 8, 4>; };
+template <> struct PlanForS<320> { using P = StaticPlan<320, 8, 8, 5>; };
+
 inline bool has_static_plan(int n) { return n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 320 || n == 512; }
 
 // ------------------------------------------------------------------ tile transform
@@ -132,7 +139,7 @@ struct TileFft {
             for (int j = 0; j < R1; ++j) {
                 int n = u + M1 * j + c;
                 if (n >= N) n -= N;
-                v[j] = load(line, n);
+                v[j] = load(slot, j, line, n);
             }
             Bfly<R1, INV>::run(v);
             if constexpr (P::STAGES == 1) {
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void fft_rows_static_kernel(Io io, int64_t nli
         if (tid < lines) ctxs[tid] = io.row_ctx(line0 + tid);
         __syncthreads();
         TF::run(buf, tw, lines, c, scale, tid,
-                [&](int line, int n) { return io.load(ctxs[line], n); },
+                [&](int, int, int line, int n) { return io.load(ctxs[line], n); },
                 [&](int, int line, int k, int, float2 v) { io.store(ctxs[line], k, v); });
     }
 }
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256) void fft_cols_static_kernel(Io io, int64_t Q, 
         const typename Io::ColCtx ctx = io.col_ctx(p, q0 + (line < cols ? line : 0));
         if (P::STAGES > 1) __syncthreads();
         TF::run(buf, tw, cols, c, scale, tid,
-                [&](int, int n) { return io.load(ctx, n); },
+                [&](int, int, int, int n) { return io.load(ctx, n); },
                 [&](int, int, int k, int, float2 v) { io.store(ctx, k, v); });
     }
 }

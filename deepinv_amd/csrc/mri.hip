@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void mri_rows_combine_static_kernel(const floa
         for (int coil = 0; coil < ncoil; ++coil) {
             const int64_t co = coil * coil_stride;
             TF::run(buf, tw, lines, c, scale, tid,
-                    [&](int line, int n) { return t[cl[line].t0 + co + n]; },
+                    [&](int, int, int line, int n) { return t[cl[line].t0 + co + n]; },
                     [&](int slot, int line, int k, int q, float2 v) {
                         if (maps) v = cmulc(v, maps[cl[line].s0 + co + k]);  // conj(S) * v
                         acc[slot][q] = cadd(acc[slot][q], v);
@@ -262,6 +262,250 @@ int launch_combine_static(const float2* t, const float2* maps, float* x, int64_t
                        maps_batch, ntiles, table, 1, scale);
     DINV_CHECK_LAUNCH();
     return 0;
+}
+
+// =====================================================================================================
+// Static-plan pipeline (all transformed sizes in {16,32,64,128,256,320,512}): pass order chosen so that the big
+// planar k-space tensor y is only ever touched along its contiguous rows, and x / coil maps are read once per
+// workgroup instead of once per coil / batch element:
+//   forward : cols(first axis) with coil loop [x cached in registers, S -> t] ; (cols(H) in place) ; rows(W) [t -> y*mask]
+//   adjoint : rows(W) [y*mask -> t] ; (cols(H) in place) ; cols(first axis) + coil combine [t,S -> x]
+// =====================================================================================================
+
+// rows pass, forward: interleaved t -> planar y * mask   (lines = (b, n, r) rows of length W)
+struct RowsPlanarMaskStoreIo {
+    static constexpr bool planar_store = true;  // -> store-friendly plan (64-wide output runs)
+    const float2* t;
+    float* y;
+    const float* mask;
+    int32_t ncoil, mask_batch;
+    int64_t R, W;  // rows per volume, row length
+    int64_t n_, q_;
+    struct RowCtx { int64_t tin, yre, yim, mre, mim; };
+    struct ColCtx {};
+    __device__ __forceinline__ RowCtx row_ctx(int64_t line) const {
+        const int64_t r = line % R, bn = line / R;
+        const int64_t n = bn % ncoil, b = bn / ncoil;
+        const int64_t vol = R * W;
+        RowCtx c;
+        c.tin = line * W;
+        c.yre = ((b * 2) * ncoil + n) * vol + r * W;
+        c.yim = c.yre + (int64_t)ncoil * vol;
+        c.mre = ((mask_batch > 1 ? b : 0) * 2) * vol + r * W;
+        c.mim = c.mre + vol;
+        return c;
+    }
+    __device__ __forceinline__ float2 load(const RowCtx& c, int n) const { return t[c.tin + n]; }
+    __device__ __forceinline__ void store(const RowCtx& c, int k, float2 v) const {
+        if (mask) {  // float multiply exactly as mri.py:271; masked-out samples are written as exact zeros
+            v.x = mask[c.mre + k] * v.x;
+            v.y = mask[c.mim + k] * v.y;
+        }
+        y[c.yre + k] = v.x;
+        y[c.yim + k] = v.y;
+    }
+    __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
+};
+
+// rows pass, adjoint: planar y * mask -> interleaved t
+struct RowsPlanarMaskLoadIo {
+    const float* y;
+    const float* mask;
+    float2* t;
+    int32_t ncoil, mask_batch;
+    int64_t R, W;
+    int64_t n_, q_;
+    struct RowCtx { int64_t tout, yre, yim, mre, mim; };
+    struct ColCtx {};
+    __device__ __forceinline__ RowCtx row_ctx(int64_t line) const {
+        const int64_t r = line % R, bn = line / R;
+        const int64_t n = bn % ncoil, b = bn / ncoil;
+        const int64_t vol = R * W;
+        RowCtx c;
+        c.tout = line * W;
+        c.yre = ((b * 2) * ncoil + n) * vol + r * W;
+        c.yim = c.yre + (int64_t)ncoil * vol;
+        c.mre = ((mask_batch > 1 ? b : 0) * 2) * vol + r * W;
+        c.mim = c.mre + vol;
+        return c;
+    }
+    __device__ __forceinline__ float2 load(const RowCtx& c, int n) const {
+        float2 v = make_float2(y[c.yre + n], y[c.yim + n]);
+        if (mask) {
+            v.x = mask[c.mre + n] * v.x;
+            v.y = mask[c.mim + n] * v.y;
+        }
+        return v;
+    }
+    __device__ __forceinline__ void store(const RowCtx& c, int k, float2 v) const { t[c.tout + k] = v; }
+    __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
+};
+
+// cols pass along the first volume axis, forward: planar x times coil map -> interleaved t (p = b*ncoil + n)
+struct ColsCoilLoadIo {
+    const float* x;
+    const float2* maps;
+    float2* t;
+    int32_t ncoil, maps_batch;
+    int64_t n_, q_;
+    struct RowCtx {};
+    struct ColCtx { int64_t xre, xim, s, o; };
+    __device__ __forceinline__ ColCtx col_ctx(int64_t p, int64_t q) const {
+        const int64_t vol = n_ * q_;
+        const int64_t b = p / ncoil, n = p % ncoil;
+        ColCtx c;
+        c.xre = (b * 2) * vol + q;
+        c.xim = c.xre + vol;
+        c.s = ((maps_batch > 1 ? b : 0) * ncoil + n) * vol + q;
+        c.o = p * vol + q;
+        return c;
+    }
+    __device__ __forceinline__ float2 load(const ColCtx& c, int k) const {
+        const int64_t o = (int64_t)k * q_;
+        float2 v = make_float2(x[c.xre + o], x[c.xim + o]);
+        if (maps) v = cmul(maps[c.s + o], v);
+        return v;
+    }
+    __device__ __forceinline__ void store(const ColCtx& c, int k, float2 v) const { t[c.o + (int64_t)k * q_] = v; }
+    __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
+};
+
+// cols pass along the first volume axis with a coil loop: t[b,n] = F_axis(S[n] * x[b]); x stays in registers
+template <class P, int L>
+__global__ __launch_bounds__(256) void mri_cols_coil_fwd_kernel(const float* __restrict__ x,
+                                                                const float2* __restrict__ maps,
+                                                                float2* __restrict__ t, int ncoil, int maps_batch,
+                                                                int64_t Q, int64_t qtiles, int64_t ntiles,
+                                                                const void* table, float scale) {
+    using TF = TileFft<P, false, false, L>;
+    constexpr int N = P::N;
+    __shared__ __attribute__((aligned(16))) float2 buf[P::STAGES > 1 ? TF::lds_floats2 : 1];
+    const float2* tw = reinterpret_cast<const float2*>(table);
+    const int tid = threadIdx.x, line = tid % L;
+    const int c = N / 2;
+    const int64_t vol = (int64_t)N * Q;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t b = tile / qtiles;
+        const int64_t q0 = (tile - b * qtiles) * L;
+        const int cols = (int)min((int64_t)L, Q - q0);
+        const int64_t q = q0 + (line < cols ? line : 0);
+        const float* xre = x + (b * 2) * vol + q;
+        const float* xim = xre + vol;
+        // cache this thread's stage-1 inputs of x (same item decomposition as TileFft::run stage 1)
+        float2 xc[TF::NS1][P::R1];
+#pragma unroll
+        for (int slot = 0; slot < TF::NS1; ++slot) {
+            const int w = tid + 256 * slot;
+            const int u = w / L;
+#pragma unroll
+            for (int j = 0; j < P::R1; ++j) {
+                int n = u + P::M1 * j + c;
+                if (n >= N) n -= N;
+                const bool ok = w < L * P::K1 && line < cols;
+                xc[slot][j] = ok ? make_float2(xre[(int64_t)n * Q], xim[(int64_t)n * Q]) : make_float2(0.f, 0.f);
+            }
+        }
+        for (int coil = 0; coil < ncoil; ++coil) {
+            const float2* s = maps ? maps + (((maps_batch > 1 ? b : 0) * ncoil + coil) * vol + q) : nullptr;
+            float2* o = t + ((b * ncoil + coil) * vol + q);
+            if (P::STAGES > 1) __syncthreads();
+            TF::run(buf, tw, cols, c, scale, tid,
+                    [&](int slot, int j, int, int n) {
+                        return s ? cmul(s[(int64_t)n * Q], xc[slot][j]) : xc[slot][j];
+                    },
+                    [&](int, int, int k, int, float2 v) { o[(int64_t)k * Q] = v; });
+        }
+    }
+}
+
+// cols pass along the first volume axis + coil combine: x[b] = sum_n conj(S[n]) * F^H_axis(t[b,n])
+template <class P, int L>
+__global__ __launch_bounds__(256) void mri_cols_combine_inv_kernel(const float2* __restrict__ t,
+                                                                   const float2* __restrict__ maps,
+                                                                   float* __restrict__ x, int ncoil, int maps_batch,
+                                                                   int64_t Q, int64_t qtiles, int64_t ntiles,
+                                                                   const void* table, float scale) {
+    using TF = TileFft<P, true, false, L>;
+    constexpr int N = P::N;
+    __shared__ __attribute__((aligned(16))) float2 buf[P::STAGES > 1 ? TF::lds_floats2 : 1];
+    const float2* tw = reinterpret_cast<const float2*>(table);
+    const int tid = threadIdx.x, line = tid % L;
+    const int c = N / 2;
+    const int64_t vol = (int64_t)N * Q;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t b = tile / qtiles;
+        const int64_t q0 = (tile - b * qtiles) * L;
+        const int cols = (int)min((int64_t)L, Q - q0);
+        const int64_t q = q0 + (line < cols ? line : 0);
+        float2 acc[TF::NSL][TF::RL];
+#pragma unroll
+        for (int a = 0; a < TF::NSL; ++a)
+#pragma unroll
+            for (int r = 0; r < TF::RL; ++r) acc[a][r] = make_float2(0.f, 0.f);
+        for (int coil = 0; coil < ncoil; ++coil) {
+            const float2* in = t + ((b * ncoil + coil) * vol + q);
+            const float2* s = maps ? maps + (((maps_batch > 1 ? b : 0) * ncoil + coil) * vol + q) : nullptr;
+            if (P::STAGES > 1) __syncthreads();
+            TF::run(buf, tw, cols, c, scale, tid,
+                    [&](int, int, int, int n) { return in[(int64_t)n * Q]; },
+                    [&](int slot, int, int k, int r, float2 v) {
+                        if (s) v = cmulc(v, s[(int64_t)k * Q]);  // conj(S) * v
+                        acc[slot][r] = cadd(acc[slot][r], v);
+                    });
+        }
+        // store with the last-stage item decomposition of TileFft::run
+        float* xre = x + (b * 2) * vol + q;
+        float* xim = xre + vol;
+        constexpr int Q2N = (P::STAGES == 3) ? P::R2 : 1;
+#pragma unroll
+        for (int slot = 0; slot < TF::NSL; ++slot) {
+            const int w = tid + 256 * slot;
+            const int i = w / L;
+            if (w >= L * TF::KL || line >= cols) continue;
+            const int q1 = P::STAGES == 1 ? 0 : i % P::R1, q2 = P::STAGES == 1 ? 0 : i / P::R1;
+#pragma unroll
+            for (int r = 0; r < TF::RL; ++r) {
+                int k = (P::STAGES == 1 ? r : q1 + P::R1 * q2 + P::R1 * Q2N * r) + c;
+                if (k >= N) k -= N;
+                xre[(int64_t)k * Q] = acc[slot][r].x;
+                xim[(int64_t)k * Q] = acc[slot][r].y;
+            }
+        }
+    }
+}
+
+template <int N>
+int launch_cols_coil_fwd(const float* x, const float2* maps, float2* t, int64_t B, int ncoil, int maps_batch, int64_t Q,
+                         const void* table, float scale, hipStream_t s) {
+    using P = typename PlanFor<N>::P;
+    constexpr int L = ColsL<N>::value;
+    const int64_t qtiles = ceil_div(Q, L), ntiles = B * qtiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
+    hipLaunchKernelGGL((mri_cols_coil_fwd_kernel<P, L>), dim3(grid), dim3(256), 0, s, x, maps, t, ncoil, maps_batch, Q,
+                       qtiles, ntiles, table, scale);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int N>
+int launch_cols_combine_inv(const float2* t, const float2* maps, float* x, int64_t B, int ncoil, int maps_batch,
+                            int64_t Q, const void* table, float scale, hipStream_t s) {
+    using P = typename PlanFor<N>::P;
+    constexpr int L = ColsL<N>::value;
+    const int64_t qtiles = ceil_div(Q, L), ntiles = B * qtiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
+    hipLaunchKernelGGL((mri_cols_combine_inv_kernel<P, L>), dim3(grid), dim3(256), 0, s, t, maps, x, ncoil, maps_batch, Q,
+                       qtiles, ntiles, table, scale);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+#define DINV_ALL_STATIC(X) X(16) X(32) X(64) X(128) X(256) X(320) X(512)
+
+bool all_static(const dinv_mri_desc* d) {
+    for (int i = 0; i < d->ndim; ++i)
+        if (!has_static_plan(d->dims[i])) return false;
+    return d->dims[d->ndim - 1] >= 64;  // the rows pass has static kernels from 64 up
 }
 
 int validate(const dinv_mri_desc* d) {
@@ -311,6 +555,30 @@ extern "C" int dinv_mri_forward(const dinv_mri_desc* d, const float* x, const fl
     float2* t = reinterpret_cast<float2*>(workspace);
     const int64_t P = (int64_t)d->batch * d->coils;
 
+    if (all_static(d)) {
+        const float2* mp = reinterpret_cast<const float2*>(maps);
+        const int64_t N0 = d->dims[0], Q0 = vol / N0;
+        const float sc0 = 1.0f / sqrtf((float)N0);
+        int e = 0;
+        static const bool coil_loop = getenv("DINV_MRI_COIL_LOOP") != nullptr;  // experiment knob
+        if (coil_loop) {
+            switch (d->dims[0]) {
+#define DINV_CASE(NN) case NN: e = launch_cols_coil_fwd<NN>(x, mp, t, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s); break;
+                DINV_ALL_STATIC(DINV_CASE)
+#undef DINV_CASE
+            }
+        } else {
+            ColsCoilLoadIo cio{x, mp, t, d->coils, d->maps_batch, 0, 0};
+            e = launch_cols(cio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s);
+        }
+        if (e) return e;
+        if (nd == 3) {
+            C2CIo mio{t, t, 0, 0};
+            if ((e = launch_cols(mio, P * d->dims[0], W, d->plan[1], d->table[1], 0, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
+        }
+        RowsPlanarMaskStoreIo sio{t, y, mask, d->coils, d->mask_batch, R, W, 0, 0};
+        return launch_rows(sio, P * R, d->plan[nd - 1], d->table[nd - 1], 0, 1, 1.0f / sqrtf((float)W), s);
+    }
     RowsCoilLoadIo rio{x, reinterpret_cast<const float2*>(maps), t, d->coils, d->maps_batch, R, W, 0, 0};
     if (int e = launch_rows(rio, P * R, d->plan[nd - 1], d->table[nd - 1], 0, 1, 1.0f / sqrtf((float)W), s)) return e;
     if (nd == 3) {
@@ -340,6 +608,22 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
     float2* t = reinterpret_cast<float2*>(workspace);
     const int64_t P = (int64_t)d->batch * d->coils;
 
+    if (all_static(d)) {
+        RowsPlanarMaskLoadIo lio{y, mask, t, d->coils, d->mask_batch, R, W, 0, 0};
+        if (int e = launch_rows(lio, P * R, d->plan[nd - 1], d->table[nd - 1], 1, 1, 1.0f / sqrtf((float)W), s)) return e;
+        if (nd == 3) {
+            C2CIo mio{t, t, 0, 0};
+            if (int e = launch_cols(mio, P * d->dims[0], W, d->plan[1], d->table[1], 1, 1, 1.0f / sqrtf((float)d->dims[1]), s)) return e;
+        }
+        const float2* mp = reinterpret_cast<const float2*>(maps);
+        const int64_t N0 = d->dims[0], Q0 = vol / N0;
+        const float sc0 = 1.0f / sqrtf((float)N0);
+        switch (d->dims[0]) {
+#define DINV_CASE(NN) case NN: return launch_cols_combine_inv<NN>(t, mp, x, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s);
+            DINV_ALL_STATIC(DINV_CASE)
+#undef DINV_CASE
+        }
+    }
     const int64_t Na = d->dims[0];
     ColsPlanarMaskLoadIo cio{y, mask, t, d->coils, d->mask_batch, 0, 0};
     if (int e = launch_cols(cio, P, vol / Na, d->plan[0], d->table[0], 1, 1, 1.0f / sqrtf((float)Na), s)) return e;

@@ -27,7 +27,7 @@ def test_centered_fft_matches_oracle(dev, shape, dims):
 
 
 @pytest.mark.parametrize("img,three_d", [((17, 11), False), ((16, 8), False), ((5, 17, 11), True), ((320, 320), False),
-                                         ((4, 32, 20), True)])
+                                         ((4, 32, 20), True), ((64, 256), False), ((16, 128, 64), True)])
 @pytest.mark.parametrize("batched_mask", [False, True])
 def test_single_coil_mri(dev, img, three_d, batched_mask):
     import deepinv_amd as dinv
@@ -56,7 +56,10 @@ def test_single_coil_mri(dev, img, three_d, batched_mask):
 
 
 @pytest.mark.parametrize("img,three_d,coils", [((17, 11), False, 7), ((5, 17, 11), True, 15), ((320, 320), False, 8),
-                                               ((16, 64, 48), True, 12), ((64, 64), False, 1)])
+                                               ((16, 64, 48), True, 12), ((64, 64), False, 1),
+                                               # static-plan pipeline (every dim in {16,32,64,128,256,320,512})
+                                               ((16, 64, 128), True, 3), ((32, 256), False, 2), ((128, 64), False, 5),
+                                               ((512, 320), False, 1), ((16, 32, 64), True, 2)])
 @pytest.mark.parametrize("batched", [False, True])
 def test_multicoil_mri(dev, img, three_d, coils, batched):
     import deepinv_amd as dinv
