@@ -18,6 +18,21 @@
 
 namespace dinv {
 
+// ------------------------------------------------------------------ 16-byte vector access helpers
+__device__ __forceinline__ void ld_c4(const float2* p, float2 (&v)[4]) {  // 4 interleaved complex = 2 x float4
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = make_float2(a.x, a.y); v[1] = make_float2(a.z, a.w); v[2] = make_float2(b.x, b.y); v[3] = make_float2(b.z, b.w);
+}
+__device__ __forceinline__ void st_c4(float2* p, const float2 (&v)[4]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+}
+__device__ __forceinline__ float4 ld_f4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st_f4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <class T, class = void> struct io_has_vec4 : std::false_type {};
+template <class T> struct io_has_vec4<T, std::void_t<decltype(T::has_vec4)>> : std::bool_constant<T::has_vec4> {};
+
 // ------------------------------------------------------------------ plain complex IO
 struct C2CIo {
     const float2* in;
@@ -28,6 +43,9 @@ struct C2CIo {
     __device__ __forceinline__ RowCtx row_ctx(int64_t line) const { return RowCtx{line * n_}; }
     __device__ __forceinline__ float2 load(const RowCtx& c, int n) const { return in[c.base + n]; }
     __device__ __forceinline__ void store(const RowCtx& c, int k, float2 v) const { out[c.base + k] = v; }
+    static constexpr bool has_vec4 = true;
+    __device__ __forceinline__ void load4(const RowCtx& c, int n0, float2 (&v)[4]) const { ld_c4(in + c.base + n0, v); }
+    __device__ __forceinline__ void store4(const RowCtx& c, int k0, const float2 (&v)[4]) const { st_c4(out + c.base + k0, v); }
     __device__ __forceinline__ ColCtx col_ctx(int64_t p, int64_t q) const { return ColCtx{p * n_ * q_ + q, q_}; }
     __device__ __forceinline__ float2 load(const ColCtx& c, int k) const { return in[c.base + (int64_t)k * c.q]; }
     __device__ __forceinline__ void store(const ColCtx& c, int k, float2 v) const { out[c.base + (int64_t)k * c.q] = v; }
@@ -157,6 +175,19 @@ inline int launch_rows_static_L(Io io, int64_t nlines, const void* table, int in
     using P = std::conditional_t<io_planar_store<Io>::value, typename PlanForS<N>::P, typename PlanFor<N>::P>;
     const int64_t ntiles = ceil_div(nlines, L);
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
+    static const bool no_vec = getenv("DINV_NO_VEC4") != nullptr;  // experiment knob
+    if constexpr (io_has_vec4<Io>::value && P::STAGES >= 2 && P::M1 % 4 == 0 && (P::N / (P::STAGES == 3 ? P::R3 : P::R2)) % 4 == 0) {
+        if (!no_vec && (centered == 0 || (P::N / 2) % 4 == 0)) {
+            if (inverse)
+                hipLaunchKernelGGL((fft_rows_static_v4_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, nlines,
+                                   ntiles, table, centered, scale);
+            else
+                hipLaunchKernelGGL((fft_rows_static_v4_kernel<P, Io, false, L>), dim3(grid), dim3(256), 0, s, io, nlines,
+                                   ntiles, table, centered, scale);
+            DINV_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (inverse)
         hipLaunchKernelGGL((fft_rows_static_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, nlines, ntiles,
                            table, centered, scale);
@@ -185,18 +216,20 @@ inline int launch_rows_static(Io io, int64_t nlines, const void* table, int inve
 
 template <int N, class Io>
 inline int launch_cols_static(Io io, int64_t P_, int64_t Q, const void* table, int inverse, int centered, float scale,
-                              hipStream_t s) {
+                              hipStream_t s, int group = 1) {
     using P = typename PlanFor<N>::P;
     constexpr int L = ColsL<N>::value;
     const int64_t qtiles = ceil_div(Q, L);
     const int64_t ntiles = P_ * qtiles;
-    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
+    if (group > 1 && (P_ % group != 0 || getenv("DINV_NO_XCD_MAP"))) group = 1;
+    const int64_t padded = group > 1 ? ceil_div(ntiles, (int64_t)8 * group) * 8 * group : ntiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(padded, kMaxGrid);
     if (inverse)
         hipLaunchKernelGGL((fft_cols_static_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, Q, qtiles, ntiles,
-                           table, centered, scale);
+                           table, centered, scale, group);
     else
         hipLaunchKernelGGL((fft_cols_static_kernel<P, Io, false, L>), dim3(grid), dim3(256), 0, s, io, Q, qtiles, ntiles,
-                           table, centered, scale);
+                           table, centered, scale, group);
     DINV_CHECK_LAUNCH();
     return 0;
 }
@@ -234,11 +267,11 @@ inline int launch_rows(Io io, int64_t nlines, const dinv_fft_plan& plan, const v
 
 template <class Io>
 inline int launch_cols(Io io, int64_t P, int64_t Q, const dinv_fft_plan& plan, const void* table, int inverse,
-                       int centered, float scale, hipStream_t s) {
+                       int centered, float scale, hipStream_t s, int group = 1) {
     if (P == 0 || Q == 0) return 0;
     io.set_geometry(plan.n, Q);
     switch (plan.n) {
-#define DINV_CASE(NN) case NN: return launch_cols_static<NN, Io>(io, P, Q, table, inverse, centered, scale, s);
+#define DINV_CASE(NN) case NN: return launch_cols_static<NN, Io>(io, P, Q, table, inverse, centered, scale, s, group);
         DINV_CASE(16) DINV_CASE(32) DINV_STATIC_SIZES(DINV_CASE)
 #undef DINV_CASE
         default: break;

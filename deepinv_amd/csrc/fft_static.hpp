@@ -14,6 +14,8 @@
 
 namespace dinv {
 
+__host__ __device__ inline int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 // ------------------------------------------------------------------ radix-16 butterfly (4x4 DIF, constants)
 template <bool INV>
 struct Bfly<16, INV> {
@@ -198,6 +200,89 @@ struct TileFft {
             }
         }
     }
+
+    // ---- ROW-mode variant with 4 adjacent elements per thread on the global side: every global access is a
+    // 16-byte-per-lane vector access (the guide's "vectorize ALWAYS" rule; 4-byte-per-lane streams top out near
+    // 2.7 TB/s on this chip, 16-byte ones reach >5 TB/s).  loadv(line, n0, out[4]) / emitv(line, k0, q, v[4]).
+    template <class LoadV, class EmitV>
+    static __device__ __forceinline__ void run_v4(float2* buf, const float2* __restrict__ tw, int lines, int c,
+                                                  float scale, int tid, LoadV loadv, EmitV emitv) {
+        static_assert(ROW, "run_v4 is a rows-pass variant");
+        constexpr int R1 = P::R1, R2 = P::R2, M1 = P::M1, M2 = P::M2;
+        static_assert(M1 % 4 == 0 && KL % 4 == 0 && N % 8 == 0 && P::STAGES >= 2, "vector width 4 needs 4 | M1, KL");
+        constexpr int T1 = M1 / 4;                       // threads per line, stage 1
+        constexpr int NSV1 = (L * T1 + 255) / 256;
+#pragma unroll
+        for (int slot = 0; slot < NSV1; ++slot) {
+            const int w = tid + 256 * slot;
+            const int line = w / T1, u0 = (w - line * T1) * 4;
+            if (w >= L * T1 || line >= lines) continue;
+            float2 x[R1][4];
+#pragma unroll
+            for (int j = 0; j < R1; ++j) {
+                int n0 = u0 + M1 * j + c;
+                if (n0 >= N) n0 -= N;
+                loadv(line, n0, x[j]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float2 v[R1];
+#pragma unroll
+                for (int j = 0; j < R1; ++j) v[j] = x[j][e];
+                Bfly<R1, INV>::run(v);
+                apply_twiddle_powers<R1, INV>(v, tw[u0 + e]);
+#pragma unroll
+                for (int q = 0; q < R1; ++q) buf[addr(line, q, u0 + e)] = v[q];
+            }
+        }
+        __syncthreads();
+        if constexpr (P::STAGES == 3) {
+            constexpr int NS2 = (L * P::K2 + 255) / 256;
+#pragma unroll
+            for (int slot = 0; slot < NS2; ++slot) {
+                const int w = tid + 256 * slot;
+                int line, i;
+                split(w, P::K2, line, i);
+                if (w >= L * P::K2 || line >= lines) continue;
+                const int q1 = i / M2, u = i % M2;
+                float2 v[R2];
+#pragma unroll
+                for (int j = 0; j < R2; ++j) v[j] = buf[addr(line, q1, u + M2 * j)];
+                Bfly<R2, INV>::run(v);
+                apply_twiddle_powers<R2, INV>(v, tw[R1 * u]);
+#pragma unroll
+                for (int q = 0; q < R2; ++q) buf[addr(line, q1, q * M2 + u)] = v[q];
+            }
+            __syncthreads();
+        }
+        constexpr int Q2N = (P::STAGES == 3) ? R2 : 1;
+        constexpr int TL = KL / 4;                       // threads per line, last stage
+        constexpr int NSVL = (L * TL + 255) / 256;
+#pragma unroll
+        for (int slot = 0; slot < NSVL; ++slot) {
+            const int w = tid + 256 * slot;
+            const int line = w / TL, i0 = (w - line * TL) * 4;
+            if (w >= L * TL || line >= lines) continue;
+            float2 o[RL][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e;
+                const int q1 = i % R1, q2 = i / R1;
+                float2 v[RL];
+#pragma unroll
+                for (int j = 0; j < RL; ++j) v[j] = buf[addr(line, q1, (Q2N > 1 ? q2 * RL : 0) + j)];
+                Bfly<RL, INV>::run(v);
+#pragma unroll
+                for (int q = 0; q < RL; ++q) o[q][e] = cscale(v[q], scale);
+            }
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                int k0 = i0 + R1 * Q2N * q + c;
+                if (k0 >= N) k0 -= N;
+                emitv(line, k0, q, o[q]);
+            }
+        }
+    }
 };
 
 // ------------------------------------------------------------------ kernels
@@ -223,15 +308,49 @@ __global__ __launch_bounds__(256) void fft_rows_static_kernel(Io io, int64_t nli
 }
 
 template <class P, class Io, bool INV, int L>
+__global__ __launch_bounds__(256) void fft_rows_static_v4_kernel(Io io, int64_t nlines, int64_t ntiles,
+                                                                 const void* table, int centered, float scale) {
+    using TF = TileFft<P, INV, true, L>;
+    __shared__ __attribute__((aligned(16))) float2 buf[TF::lds_floats2];
+    __shared__ typename Io::RowCtx ctxs[L];
+    const float2* tw = reinterpret_cast<const float2*>(table);
+    const int tid = threadIdx.x;
+    const int c = centered ? P::N / 2 : 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t line0 = tile * L;
+        const int lines = (int)min((int64_t)L, nlines - line0);
+        __syncthreads();
+        if (tid < lines) ctxs[tid] = io.row_ctx(line0 + tid);
+        __syncthreads();
+        TF::run_v4(buf, tw, lines, c, scale, tid,
+                   [&](int line, int n0, float2 (&out)[4]) { io.load4(ctxs[line], n0, out); },
+                   [&](int line, int k0, int, const float2 (&v)[4]) { io.store4(ctxs[line], k0, v); });
+    }
+}
+
+template <class P, class Io, bool INV, int L>
 __global__ __launch_bounds__(256) void fft_cols_static_kernel(Io io, int64_t Q, int64_t qtiles, int64_t ntiles,
-                                                              const void* table, int centered, float scale) {
+                                                              const void* table, int centered, float scale,
+                                                              int group) {
     using TF = TileFft<P, INV, false, L>;
     __shared__ __attribute__((aligned(16))) float2 buf[P::STAGES > 1 ? TF::lds_floats2 : 1];
     const float2* tw = reinterpret_cast<const float2*>(table);
     const int tid = threadIdx.x;
     const int c = centered ? P::N / 2 : 0;
     const int line = tid % L;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // `group` > 1: the `group` consecutive outer indices p = g*group + m share input data (the coils of one
+    // slice share x).  Blocks b and b+8 run on the same XCD (observed placement; speed only, never
+    // correctness), so the members of a sharing set are laid out 8 apart and hit that XCD's L2.
+    const int64_t padded = group > 1 ? ceil_div_dev(ntiles, (int64_t)8 * group) * 8 * group : ntiles;
+    for (int64_t T = blockIdx.x; T < padded; T += gridDim.x) {
+        int64_t tile = T;
+        if (group > 1) {
+            const int64_t chunk = T / (8 * group), within = T - chunk * (8 * group);
+            const int64_t set = chunk * 8 + within % 8, member = within / 8;
+            const int64_t g = set / qtiles, qt = set - g * qtiles;
+            tile = (g * group + member) * qtiles + qt;
+            if (tile >= ntiles) continue;
+        }
         const int64_t p = tile / qtiles;
         const int64_t q0 = (tile - p * qtiles) * L;
         const int cols = (int)min((int64_t)L, Q - q0);

@@ -304,6 +304,18 @@ struct RowsPlanarMaskStoreIo {
         y[c.yre + k] = v.x;
         y[c.yim + k] = v.y;
     }
+    static constexpr bool has_vec4 = true;
+    __device__ __forceinline__ void load4(const RowCtx& c, int n0, float2 (&v)[4]) const { ld_c4(t + c.tin + n0, v); }
+    __device__ __forceinline__ void store4(const RowCtx& c, int k0, const float2 (&v)[4]) const {
+        float4 re = make_float4(v[0].x, v[1].x, v[2].x, v[3].x), im = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+        if (mask) {
+            const float4 mr = ld_f4(mask + c.mre + k0), mi = ld_f4(mask + c.mim + k0);
+            re = make_float4(mr.x * re.x, mr.y * re.y, mr.z * re.z, mr.w * re.w);
+            im = make_float4(mi.x * im.x, mi.y * im.y, mi.z * im.z, mi.w * im.w);
+        }
+        st_f4(y + c.yre + k0, re);
+        st_f4(y + c.yim + k0, im);
+    }
     __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
 };
 
@@ -338,6 +350,18 @@ struct RowsPlanarMaskLoadIo {
         return v;
     }
     __device__ __forceinline__ void store(const RowCtx& c, int k, float2 v) const { t[c.tout + k] = v; }
+    static constexpr bool has_vec4 = true;
+    __device__ __forceinline__ void load4(const RowCtx& c, int n0, float2 (&v)[4]) const {
+        float4 re = ld_f4(y + c.yre + n0), im = ld_f4(y + c.yim + n0);
+        if (mask) {
+            const float4 mr = ld_f4(mask + c.mre + n0), mi = ld_f4(mask + c.mim + n0);
+            re = make_float4(mr.x * re.x, mr.y * re.y, mr.z * re.z, mr.w * re.w);
+            im = make_float4(mi.x * im.x, mi.y * im.y, mi.z * im.z, mi.w * im.w);
+        }
+        v[0] = make_float2(re.x, im.x); v[1] = make_float2(re.y, im.y);
+        v[2] = make_float2(re.z, im.z); v[3] = make_float2(re.w, im.w);
+    }
+    __device__ __forceinline__ void store4(const RowCtx& c, int k0, const float2 (&v)[4]) const { st_c4(t + c.tout + k0, v); }
     __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
 };
 
@@ -474,6 +498,95 @@ __global__ __launch_bounds__(256) void mri_cols_combine_inv_kernel(const float2*
     }
 }
 
+// coil combination as a streaming pass: x[b] = sum_n conj(S[n]) * t[b,n], 4 pixels (2 x 16 B of t) per thread,
+// the coil maps of a pixel quad stay in registers across a chunk of batch elements
+constexpr int CB = 4;  // batch elements per thread
+template <int NC>
+__global__ __launch_bounds__(256) void mri_coil_combine_kernel(const float2* __restrict__ t,
+                                                               const float2* __restrict__ maps,
+                                                               float* __restrict__ x, int64_t vol, int batch,
+                                                               int ncoil, int maps_batch) {
+    const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pix = quad * 4;
+    if (pix >= vol) return;
+    const int b0 = blockIdx.y * CB;
+    float2 sv[NC][4];
+    const bool shared_maps = maps_batch <= 1;
+    const bool cached = maps && shared_maps && ncoil <= NC;  // maps of this pixel quad live in registers
+    if (cached) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+            if (n < ncoil) ld_c4(maps + (int64_t)n * vol + pix, sv[n]);
+    }
+    for (int bb = 0; bb < CB; ++bb) {
+        const int b = b0 + bb;
+        if (b >= batch) break;
+        float2 acc[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+        for (int n0 = 0; n0 < ncoil; n0 += NC) {
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                if (n0 + n >= ncoil) break;
+                float2 tv[4];
+                ld_c4(t + ((int64_t)b * ncoil + n0 + n) * vol + pix, tv);
+                if (maps) {
+                    if (!cached) ld_c4(maps + ((int64_t)(shared_maps ? 0 : b) * ncoil + n0 + n) * vol + pix, sv[n]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = cadd(acc[e], cmulc(tv[e], sv[n][e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = cadd(acc[e], tv[e]);
+                }
+            }
+        }
+        float* xre = x + ((int64_t)b * 2) * vol + pix;
+        st_f4(xre, make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x));
+        st_f4(xre + vol, make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y));
+    }
+}
+
+// coil expansion as a streaming pass: t[b,n] = S[n] * x[b]; same blocking as the combine kernel
+template <int NC>
+__global__ __launch_bounds__(256) void mri_coil_expand_kernel(const float* __restrict__ x,
+                                                              const float2* __restrict__ maps,
+                                                              float2* __restrict__ t, int64_t vol, int batch, int ncoil,
+                                                              int maps_batch) {
+    const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pix = quad * 4;
+    if (pix >= vol) return;
+    const int b0 = blockIdx.y * CB;
+    float2 sv[NC][4];
+    const bool shared_maps = maps_batch <= 1;
+    const bool cached = maps && shared_maps && ncoil <= NC;
+    if (cached) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+            if (n < ncoil) ld_c4(maps + (int64_t)n * vol + pix, sv[n]);
+    }
+    for (int bb = 0; bb < CB; ++bb) {
+        const int b = b0 + bb;
+        if (b >= batch) break;
+        const float* xre = x + ((int64_t)b * 2) * vol + pix;
+        const float4 re = ld_f4(xre), im = ld_f4(xre + vol);
+        const float2 xv[4] = {make_float2(re.x, im.x), make_float2(re.y, im.y), make_float2(re.z, im.z), make_float2(re.w, im.w)};
+        for (int n0 = 0; n0 < ncoil; n0 += NC) {
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                if (n0 + n >= ncoil) break;
+                float2 o[4];
+                if (maps) {
+                    if (!cached) ld_c4(maps + ((int64_t)(shared_maps ? 0 : b) * ncoil + n0 + n) * vol + pix, sv[n]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = cmul(sv[n][e], xv[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = xv[e];
+                }
+                st_c4(t + ((int64_t)b * ncoil + n0 + n) * vol + pix, o);
+            }
+        }
+    }
+}
+
 template <int N>
 int launch_cols_coil_fwd(const float* x, const float2* maps, float2* t, int64_t B, int ncoil, int maps_batch, int64_t Q,
                          const void* table, float scale, hipStream_t s) {
@@ -567,9 +680,17 @@ extern "C" int dinv_mri_forward(const dinv_mri_desc* d, const float* x, const fl
                 DINV_ALL_STATIC(DINV_CASE)
 #undef DINV_CASE
             }
+        } else if (vol % 4 == 0 && N0 > 16 && !getenv("DINV_MRI_FUSED_EXPAND")) {
+            // wide streaming coil expansion, then a C2C pass along the first axis in place
+            const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
+            hipLaunchKernelGGL((mri_coil_expand_kernel<8>), grid, dim3(256), 0, s, x, mp, t, vol, d->batch, d->coils,
+                               d->maps_batch);
+            DINV_CHECK_LAUNCH();
+            C2CIo fio{t, t, 0, 0};
+            e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s);
         } else {
             ColsCoilLoadIo cio{x, mp, t, d->coils, d->maps_batch, 0, 0};
-            e = launch_cols(cio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s);
+            e = launch_cols(cio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s, d->coils);
         }
         if (e) return e;
         if (nd == 3) {
@@ -618,6 +739,17 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
         const float2* mp = reinterpret_cast<const float2*>(maps);
         const int64_t N0 = d->dims[0], Q0 = vol / N0;
         const float sc0 = 1.0f / sqrtf((float)N0);
+        static const bool fused_combine = getenv("DINV_MRI_FUSED_COMBINE") != nullptr;  // experiment knob
+        if (!fused_combine && vol % 4 == 0 && N0 > 16) {
+            // C2C pass along the first axis in place, then a wide streaming coil combination
+            C2CIo fio{t, t, 0, 0};
+            if (int e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 1, 1, sc0, s)) return e;
+            const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
+            hipLaunchKernelGGL((mri_coil_combine_kernel<8>), grid, dim3(256), 0, s, t, mp, x, vol, d->batch, d->coils,
+                               d->maps_batch);
+            DINV_CHECK_LAUNCH();
+            return 0;
+        }
         switch (d->dims[0]) {
 #define DINV_CASE(NN) case NN: return launch_cols_combine_inv<NN>(t, mp, x, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s);
             DINV_ALL_STATIC(DINV_CASE)
