@@ -196,6 +196,51 @@ __global__ __launch_bounds__(256) void radon_adj_kernel(RadonGeom g, const float
     }
 }
 
+// ---- interpolating back-projection (IRadon.forward, radon.py:396-444; used when adjoint_via_backprop=False):
+// reco[y][x] = sum_a bilinear(sino, col = ixtab[a] (~ a), row = ((x*cos - y*sin + 1)/2)(G-1)), zero padding,
+// on the G x G grid, cropped to W x W, optional disc mask.  One thread per output pixel of one image.
+__global__ __launch_bounds__(256) void iradon_kernel(RadonGeom g, const float* __restrict__ sino,
+                                                     const float* __restrict__ xn, const float2* __restrict__ cs,
+                                                     const float* __restrict__ ixtab, float* __restrict__ out) {
+    extern __shared__ float smem[];
+    float2* cs_s = reinterpret_cast<float2*>(smem);
+    float* ix_s = smem + 2 * g.A;
+    for (int i = threadIdx.x; i < g.A; i += 256) { cs_s[i] = cs[i]; ix_s[i] = ixtab[i]; }
+    __syncthreads();
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (col >= g.W || row >= g.W) return;
+    const float xg = xn[col + g.pad], yg = xn[row + g.pad];  // meshgrid(linspace(-1,1,G)), radon.py:446-456
+    const float gm1 = (float)(g.G - 1);
+    const float* sn = sino + (int64_t)n * g.G * g.A;
+    float acc = 0.f;
+    const bool live = !g.circle || (xg * xg + yg * yg <= 1.0f);
+    if (live) {
+        for (int a = 0; a < g.A; ++a) {
+            const float t = xg * cs_s[a].x - yg * cs_s[a].y;   // _XYtoT (radon.py:458-461)
+            const float iy = ((t + 1.0f) * 0.5f) * gm1;
+            const float ix = ix_s[a];
+            const float fy = floorf(iy), fx = floorf(ix);
+            const float ty = iy - fy, tx = ix - fx;
+            const int y0 = (int)fy, x0 = (int)fx;
+            float v = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int yy = y0 + dy, xx = x0 + dx;
+                    if (yy >= 0 && yy < g.G && xx >= 0 && xx < g.A) {
+                        const float w = (dy ? ty : 1.0f - ty) * (dx ? tx : 1.0f - tx);
+                        v = fmaf(w, sn[(int64_t)yy * g.A + xx], v);
+                    }
+                }
+            acc += v;
+        }
+    }
+    out[((int64_t)n * g.W + row) * g.W + col] = acc * g.scale;
+}
+
 // ---- ramp filter along the detector axis: out[n][j][a] = sum_m h[j-m] y[n][m][a]
 constexpr int RJ = 8;  // outputs per thread
 __global__ __launch_bounds__(256) void ramp_kernel(int n_img, int N, int A, const float* __restrict__ y,
@@ -301,6 +346,21 @@ extern "C" int dinv_radon_adjoint(const dinv_radon_desc* d, const float* sino, c
         hipLaunchKernelGGL(radon_pack_sino<NB>, dim3(pk_blocks), dim3(256), 0, s, g, sino, sp);
         hipLaunchKernelGGL(radon_adj_kernel<NB>, grid, dim3(256), lds, s, g, sp, xn, cs2, x);
     });
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_radon_backproject(const dinv_radon_desc* d, const float* sino, const float* xn, const float* cs,
+                                      const float* ixtab, float* out, dinv_stream_t stream) {
+    RadonGeom g;
+    if (int e = check_desc(d, &g)) return e;
+    if (g.n_img == 0) return 0;
+    DINV_REQUIRE(sino && xn && cs && ixtab && out, "null pointer");
+    DINV_REQUIRE(g.n_img <= 65535, "too many images per call");
+    const size_t lds = (size_t)g.A * 3 * sizeof(float);
+    DINV_REQUIRE(lds <= 64 * 1024, "too many angles for the LDS tables");
+    hipLaunchKernelGGL(iradon_kernel, dim3((g.W + 63) / 64, (g.W + 3) / 4, g.n_img), dim3(256), lds,
+                       reinterpret_cast<hipStream_t>(stream), g, sino, xn, reinterpret_cast<const float2*>(cs), ixtab, out);
     DINV_CHECK_LAUNCH();
     return 0;
 }

@@ -28,6 +28,7 @@ def _l():
         l.dinv_radon_forward.argtypes = [D, vp, vp, vp, vp, vp, sz, vp]
         l.dinv_radon_adjoint.argtypes = [D, vp, vp, vp, vp, vp, sz, vp]
         l.dinv_radon_ramp.argtypes = [i32, i32, i32, vp, vp, vp]
+        l.dinv_radon_backproject.argtypes = [D, vp, vp, vp, vp, vp, vp]
         _declared = True
     return l
 
@@ -50,6 +51,9 @@ class RadonGeometry:
         self.A = int(a.numel())
         self.cs = torch.stack([theta.cos(), theta.sin()], dim=1).contiguous().to(device)
         self.xn = torch.linspace(-1, 1, self.G).to(device)   # affine_grid base grid, align_corners=True
+        # IRadon grid x-coordinate of angle column a (radon.py:474-489) -> unnormalised like grid_sample does
+        X = torch.arange(self.A, dtype=torch.float32) * 2.0 / (self.A - 1) - 1.0 if self.A > 1 else torch.zeros(1)
+        self.ixtab = (((X + 1.0) / 2) * (self.A - 1)).contiguous().to(device)
         self.device = torch.device(device)
 
     def desc(self, n_img: int, scale: float) -> RadonDesc:
@@ -102,6 +106,41 @@ class _RadonAdj(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return _RadonFwd.apply(g, ctx.geo, ctx.scale), None, None
+
+
+def iradon_backproject(y, geo: RadonGeometry, scale=1.0):
+    """sum_a interp(sino[:, a], x cos - y sin) on the image grid (IRadon.forward without filter / pi/(2A) factor)"""
+    dev = require_hip(y, geo.xn)
+    y = f32c(y)
+    B, C, G, A = y.shape
+    if G != geo.G or A != geo.A:
+        raise ValueError(f"sinogram of shape {tuple(y.shape)} does not match the operator ({geo.G} detectors, {geo.A} angles)")
+    out = torch.empty((B, C, geo.W, geo.W), device=dev, dtype=torch.float32)
+    n = B * C
+    for s0 in range(0, n, 65535):
+        e = min(n, s0 + 65535)
+        d = geo.desc(e - s0, scale)
+        check(_l().dinv_radon_backproject(ctypes.byref(d), ptr(y.view(n, G, A)[s0:e]), ptr(geo.xn), ptr(geo.cs),
+                                          ptr(geo.ixtab), ptr(out.view(n, geo.W, geo.W)[s0:e]), stream_ptr(dev)))
+    return out
+
+
+class _ApplyRadon(torch.autograd.Function):
+    """Radon / interpolating back-projection pair of the reference's ``ApplyRadon`` (radon.py:493-531): each one's
+    autograd backward is the other (an *inexact* adjoint pair by design)."""
+
+    @staticmethod
+    def forward(ctx, x, geo, scale, adjoint):
+        ctx.geo, ctx.scale, ctx.adjoint = geo, scale, adjoint
+        return iradon_backproject(x, geo, scale) if adjoint else _fwd(x, geo, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ApplyRadon.apply(g, ctx.geo, ctx.scale, not ctx.adjoint), None, None, None
+
+
+def apply_radon(x, geo, scale, adjoint):
+    return _ApplyRadon.apply(x, geo, float(scale), bool(adjoint))
 
 
 def radon_forward(x, geo, scale=1.0):

@@ -85,21 +85,25 @@ class Tomography(LinearPhysics):
         if not x.shape[-2:] == (self.img_width, self.img_width):
             raise ValueError(f"Input image size {x.shape[-2:]} does not match the operator image size "
                              f"{(self.img_width, self.img_width)}.")
-        return hr.radon_forward(x, self._geometry(x.device), self._scale())
+        if self.adjoint_via_backprop:
+            return hr.radon_forward(x, self._geometry(x.device), self._scale())
+        return hr.apply_radon(x, self._geometry(x.device), self._scale(), False)   # ApplyRadon (radon.py:493-531)
 
     def A_adjoint(self, y, **kwargs):
         if self.adjoint_via_backprop:
             return hr.radon_adjoint(y, self._geometry(y.device), self._scale())
-        return self._iradon_adjoint(y)
-
-    def _iradon_adjoint(self, y):
-        raise NotImplementedError("adjoint_via_backprop=False (interpolating, inexact back-projection) is not on the "
-                                  "accelerated path yet; the default exact adjoint is")
+        # ApplyRadon(adjoint=True) = iradon(y, filtering=False) / pi * 2A = plain interpolated sum; / operator_norm
+        return hr.apply_radon(y, self._geometry(y.device), self._scale(), True)
 
     def fbp(self, y, **kwargs):
         """filtered back-projection (tomography.py:258-293)"""
         if not self.adjoint_via_backprop:
-            return self._iradon_adjoint(y)
+            out = hr.apply_radon(self.filter(y), self._geometry(y.device), 1.0, True) * torch.pi / (2 * self.angles.numel())
+            if self.normalize:
+                out = out * self.operator_norm
+            if self.fbp_interpolate_boundary:
+                out = torch.nn.functional.pad(out[:, :, 2:-2, 2:-2], (2, 2, 2, 2), mode="replicate")
+            return out
         y = self.filter(y)
         out = self.A_adjoint(y, **kwargs) * torch.pi / (2 * self.angles.numel())
         if self.normalize:

@@ -165,6 +165,11 @@ int dinv_radon_forward(const dinv_radon_desc* d, const float* x, const float* xn
 /* exact transpose of dinv_radon_forward: sino:[n_img,G,A] -> x:[n_img,W,W] */
 int dinv_radon_adjoint(const dinv_radon_desc* d, const float* sino, const float* xn, const float* cs,
                        float* x, void* ws, size_t ws_bytes, dinv_stream_t stream);
+/* interpolating back-projection of IRadon.forward (radon.py:396-444), the inexact adjoint used when
+ * adjoint_via_backprop=False: sino:[n_img,G,A] -> out:[n_img,W,W] * scale.  ixtab:[A] are the fp32 column
+ * coordinates ((X+1)/2)(A-1), X = a*2/(A-1)-1, exactly as the reference grid holds them (radon.py:474-489). */
+int dinv_radon_backproject(const dinv_radon_desc* d, const float* sino, const float* xn, const float* cs,
+                           const float* ixtab, float* out, dinv_stream_t stream);
 /* ramp filter along the detector axis of sino:[n_img,n_det,A] (RampFilter, radon.py:74-173) */
 int dinv_radon_ramp(int32_t n_img, int32_t n_det, int32_t n_angles, const float* sino, float* out,
                     dinv_stream_t stream);

@@ -307,3 +307,25 @@ def downsampling_prox_l2(z, y, gamma, filter, factor, img_size):
     below = torch.mean(splits(Fh2, factor), dim=-1) + 1 / gamma
     rc = Fhc * (top / below).repeat(1, 1, factor, factor)
     return (z_hat - torch.real(torch.fft.ifft2(rc))) * gamma
+
+
+def iradon_backproject(y, angles_deg, W, circle=False):
+    """IRadon.forward(filtering=False) / pi * (2A): the interpolating back-projection that ApplyRadon uses as
+    (inexact) adjoint when adjoint_via_backprop=False (radon.py:396-444, 458-489, 493-514), sequential branch."""
+    B, C, G, A = y.shape
+    unit = torch.linspace(-1, 1, G)
+    ygrid, xgrid = torch.meshgrid(unit, unit, indexing="ij")
+    reco = torch.zeros(B, C, G, G)
+    for i in range(A):
+        X = torch.ones(G).view(-1, 1).repeat(1, G) * i * 2.0 / (A - 1) - 1.0
+        t = _deg2rad(angles_deg[i])
+        Y = xgrid * t.cos() - ygrid * t.sin()
+        grid = torch.cat((X.unsqueeze(-1), Y.unsqueeze(-1)), dim=-1).unsqueeze(0)
+        reco += F.grid_sample(y, grid.repeat(B, 1, 1, 1), align_corners=True, mode="bilinear")
+    if not circle:
+        pad = int(torch.tensor(G - W, dtype=torch.float).ceil())
+        pb = (W + pad) // 2 - W // 2
+        reco = F.pad(reco, (-pb, -(pad - pb), -pb, -(pad - pb)))
+    else:
+        reco[(xgrid ** 2 + ygrid ** 2 > 1).repeat(B, C, 1, 1)] = 0.0
+    return reco

@@ -86,3 +86,25 @@ def test_radon_autograd(dev):
     w = torch.randn_like(y)
     (y * w).sum().backward()
     assert rel_err(x.grad, phys.A_adjoint(w)) < 1e-6
+
+
+@pytest.mark.parametrize("W,nang,circle", [(16, 12, False), (16, 12, True), (48, 30, False)])
+def test_iradon_branch_adjoint_via_backprop_false(dev, W, nang, circle):
+    """B3: interpolating (inexact) back-projection, ApplyRadon pair (radon.py:360-531, tomography.py:251,275-288,344-348)"""
+    import deepinv_amd as dinv
+
+    g = torch.Generator().manual_seed(5)
+    phys = dinv.physics.Tomography(angles=nang, img_width=W, circle=circle, normalize=False, adjoint_via_backprop=False,
+                                   device=dev)
+    ang = phys.angles.cpu()
+    x = torch.rand(2, 1, W, W, generator=g)
+    y_ref = O.radon_forward(x, ang, circle)
+    assert rel_err(phys.A(x.to(dev)), y_ref) < TOL
+    v = torch.randn(y_ref.shape, generator=g)
+    assert rel_err(phys.A_adjoint(v.to(dev)), O.iradon_backproject(v, ang, W, circle)) < TOL
+    fbp_ref = O.iradon_backproject(O.ramp_filter(y_ref), ang, W, circle) * torch.pi / (2 * nang)
+    assert rel_err(phys.A_dagger(y_ref.to(dev), fbp=True), fbp_ref) < TOL
+    # autograd of A uses the interpolating back-projection (ApplyRadon.backward)
+    xg = x.to(dev).requires_grad_(True)
+    (phys.A(xg) * v.to(dev)).sum().backward()
+    assert rel_err(xg.grad, O.iradon_backproject(v, ang, W, circle)) < TOL
