@@ -6,20 +6,23 @@
 // 323-434, 524-602.  fp32 in / fp32 accumulate: the f32 MFMA is bit-for-bit an fmaf chain, so
 // parity with the reference's fp32 CPU path is summation-order only.
 //
-// Activation layout ("padded channel planes", CNHW): act[c][SL + b*PLANE + r*WP + col] with
-// (r,col) in a zero-bordered (H+2) x WP frame, WP = roundup(W+2,4).  A 3x3 tap is then a
-// constant shift (dy*WP + dx) of the flattened pixel index, so the convolution is a GEMM
-//     Y[co][p] = sum_{tap,ci} Wt[tap][ci][co] * X[ci][p + shift(tap)]
-// with M = Cout (A operand = weights), N = flattened padded pixels (B operand = activations,
-// pixel-contiguous -> every global / LDS access is lane-linear), K = 9*Cin.  Border outputs are
-// computed and then overwritten with exact zeros (select, not multiply) to keep the invariant.
+// Activation layout ("padded pixel rows, channels blocked by 8"):
+//     act[c/8][SL + b*PLANE + r*WP + col][c%8]            (one block row = cs pixels x 8 floats)
+// with (r,col) in a zero-bordered (H+2) x WP frame, WP = roundup(W+2,4).  A 3x3 tap is a constant
+// shift (dy*WP + dx) of the flattened pixel index, so the convolution is a GEMM
+//     Y[co][p] = sum_{tap,ci} Wt[tap][co][ci] * X[ci][p + shift(tap)]
+// with M = Cout (A operand = weights), N = flattened padded pixels (B operand = activations), K = 9*Cin.
+// The 8-channel blocking is chosen for the 32x32x2 MFMA: lane half h = lane>>5 supplies k = h, so a lane
+// reads channels 4h..4h+3 of its pixel (B) / of its cout row (A) as ONE 16-byte LDS read that feeds four
+// k-steps, and the D fragment (4 consecutive couts per lane per register quad) is ONE 16-byte global store.
+// Border outputs are computed and then overwritten with exact zeros (select) to keep the zero-frame invariant.
 //
-// Workgroup tile: 256 pixels x 64 couts, 4 waves, each wave 64 px x 64 co = 2x2 MFMA tiles
-// (64 accumulator VGPRs).  Per 8-channel chunk the WG stages 3 row segments x 8 ch x 264 px
-// of activations (each loaded once, reused by the 3 dx taps straight from LDS) and the
-// 9x8x64 weight block: 43.8 KB LDS -> 3 workgroups / CU, whose MFMA phases cover each other's
-// staging.  144 MFMAs (9216 matrix-pipe cycles) per chunk per wave vs ~11 16-byte loads per
-// thread: the kernel is matrix-pipe bound (roofline: 157.3 TFLOP/s fp32 MFMA).
+// Workgroup tile: 256 pixels x 64 couts, 4 waves, each wave 64 px x 64 co = 2x2 MFMA tiles (64 accumulator
+// registers).  Per 8-channel block the WG stages 3 row segments x 258 px x 8 ch (each activation loaded once,
+// reused by the 3 dx taps out of LDS) and the 9x64x8 weight block into LDS rows padded to 12 floats
+// (conflict-free ds_read_b128): 64.8 KB -> 2 workgroups / CU.  The global loads of block k+1 are in flight
+// while block k is on the matrix cores (register software pipeline).  Per tap a wave issues 4 ds_read_b128
+// and 16 MFMAs (1024 matrix-pipe cycles).  Roofline: 157.3 TFLOP/s fp32 MFMA.
 #include "common.hpp"
 
 using namespace dinv;
@@ -28,10 +31,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NT = 256;       // pixels per workgroup
-constexpr int KC = 8;         // input channels per staged chunk
-constexpr int HALO = 4;       // staged halo (floats) on each side of a row segment, keeps 16 B alignment
+constexpr int NT = 256;          // pixels per workgroup
+constexpr int KC = 8;            // channels per block
+constexpr int HALO = 1;          // staged halo pixels on each side of a row segment
 constexpr int SEG = NT + 2 * HALO;
+constexpr int LP = 12;           // LDS row pitch in floats (8 used + 4 pad): conflict-free b128 reads
 
 struct Geom {
     int32_t batch, h, w, hp, wp;
@@ -52,22 +56,59 @@ __device__ __forceinline__ bool interior(const Geom& g, int64_t p) {
     return r >= 1 && r <= g.h && c >= 1 && c <= g.w;
 }
 
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float comp(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+
+// epilogue shared by the three conv kernels: D[i][j], j = lane&31 (pixel), i = (reg&3) + 8*(reg>>2) + 4*h (cout),
+// i.e. register quad g = reg>>2 holds couts 8g+4h .. 8g+4h+3 = one float4 of channel block g.
+template <int MREP, bool RELU, int NRES>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[MREP][2], int n, int64_t opix, bool in, int cb0,
+                                           int cblocks_valid, int64_t cs, int lhi, float* __restrict__ y,
+                                           const float* __restrict__ res1, const float* __restrict__ res2) {
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        float4 r1[4], r2[4];
+        if (NRES >= 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (cb0 + 4 * m + g < cblocks_valid) r1[g] = ld4(res1 + ((int64_t)(cb0 + 4 * m + g) * cs + opix) * 8 + 4 * lhi);
+        }
+        if (NRES >= 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (cb0 + 4 * m + g < cblocks_valid) r2[g] = ld4(res2 + ((int64_t)(cb0 + 4 * m + g) * cs + opix) * 8 + 4 * lhi);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (cb0 + 4 * m + g >= cblocks_valid) continue;
+            float4 v = make_float4(acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
+            if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (NRES >= 1) v = add4(v, r1[g]);
+            if (NRES >= 2) v = add4(v, r2[g]);
+            if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            st4(y + ((int64_t)(cb0 + 4 * m + g) * cs + opix) * 8 + 4 * lhi, v);
+        }
+    }
+}
+
 struct Conv3Args {
     Geom g;
-    const float* x;    // [cin][cs]
+    const float* x;    // [cin/8][cs][8]
     const float* x2;   // optional second input added on load (U-Net skip), or null
-    const float* w;    // packed [cout/MT][cin/KC][9][KC][MT]
-    float* y;          // [cout_valid][cs]
+    const float* w;    // packed [cout/MT][cin/8][9][MT][8]
+    float* y;          // [cblocks_valid][cs][8]
     const float* res1; // optional residuals added in the epilogue
     const float* res2;
-    int32_t cin, cout_valid, relu;
+    int32_t cin, cblocks_valid, relu;
 };
 
 template <int MREP, bool RELU, int NRES>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     constexpr int MT = 32 * MREP;
-    __shared__ __attribute__((aligned(16))) float xs[3][KC][SEG];
-    __shared__ __attribute__((aligned(16))) float ws[9][KC][MT];
+    __shared__ __attribute__((aligned(16))) float xs[3 * SEG * LP];
+    __shared__ __attribute__((aligned(16))) float ws[9 * MT * LP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * NT;
@@ -80,56 +121,50 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    constexpr int XV = 3 * KC * (SEG / 4);  // float4 loads of activations per chunk (1584)
-    constexpr int WV = 9 * KC * MT / 4;     // float4 loads of weights per chunk
+    constexpr int XSEG = SEG * 2;           // float4 per staged row segment (2 per pixel)
+    constexpr int XV = 3 * XSEG;            // 1548 float4 of activations per block
+    constexpr int WV = 9 * MT * 2;          // float4 of weights per block
     constexpr int XI = (XV + 255) / 256, WI = (WV + 255) / 256;
+    static_assert(XI == 7 && WI <= 5, "prefetch slots");
     const float4* wblk = reinterpret_cast<const float4*>(a.w) + (int64_t)blockIdx.y * nchunks * WV;
 
-    // per-thread staging slots are fixed across chunks: precompute the (row, col) decomposition once
-    int xoff_lds[XI];
-    int64_t xoff_g[XI];
+    // per-thread staging slots are fixed across blocks: (segment, float4-within-segment) decomposition once
+    int xoff_lds[XI], xoff_g[XI];
 #pragma unroll
     for (int it = 0; it < XI; ++it) {
         const int idx = min(tid + it * 256, XV - 1);  // surplus slots re-load the last element (never stored)
-        const int row = idx / (SEG / 4);
-        const int c4 = idx - row * (SEG / 4);
-        const int seg = row / KC, kc = row - seg * KC;
-        xoff_lds[it] = (seg * KC + kc) * SEG + c4 * 4;
-        xoff_g[it] = (int64_t)kc * a.g.cs + a.g.sl + p0 + (int64_t)(seg - 1) * a.g.wp - HALO + c4 * 4;
+        const int seg = idx / XSEG, r = idx - seg * XSEG;
+        xoff_lds[it] = (seg * SEG + (r >> 1)) * LP + (r & 1) * 4;
+        xoff_g[it] = ((seg - 1) * a.g.wp - HALO) * 8 + r * 4;  // floats, relative to pixel p0 of the block row
     }
-    float* xs_flat = &xs[0][0][0];
-    float4* ws_flat = reinterpret_cast<float4*>(&ws[0][0][0]);
+    const int64_t row0 = (a.g.sl + p0) * 8;  // float offset of pixel p0 inside a block row
 
-    // software pipeline: the global loads of chunk ch+1 are in flight while chunk ch is on the matrix cores;
-    // every load of a chunk is issued back to back (one exposed latency per chunk at most, not one per load).
-    // One code location for the loads (ch = -1 is the prologue trip) keeps xv/wv4 in registers.
-    float4 xv[XI];
-    float4 w0, w1, w2, w3, w4;  // weight prefetch slots as scalars (an array here is left in scratch by hipcc)
-    static_assert(WI <= 5, "weight prefetch slots");
+    // software pipeline: the global loads of block ch+1 are in flight while block ch is on the matrix cores;
+    // unpredicated loads + scalar prefetch slots keep everything in registers (hipcc leaves arrays of
+    // loop-carried prefetch data in scratch, and predicated loads force early vmcnt waits)
+    float4 xv0, xv1, xv2, xv3, xv4, xv5, xv6;
+    float4 w0, w1, w2, w3, w4;
     for (int ch = -1; ch < nchunks; ++ch) {
         if (ch >= 0) {
-            __syncthreads();  // previous chunk's MFMA phase has consumed LDS
-#pragma unroll
-            for (int it = 0; it < XI; ++it)
-                if (it < XI - 1 || tid + it * 256 < XV) *reinterpret_cast<float4*>(xs_flat + xoff_lds[it]) = xv[it];
-#define DINV_WST(IT, REG) if (IT < WI && (IT < WI - 1 || tid + IT * 256 < WV)) ws_flat[tid + IT * 256] = REG;
+            __syncthreads();  // previous block's MFMA phase has consumed LDS
+#define DINV_XST(IT, REG) if (IT < XI - 1 || tid + IT * 256 < XV) st4(xs + xoff_lds[IT], REG);
+            DINV_XST(0, xv0) DINV_XST(1, xv1) DINV_XST(2, xv2) DINV_XST(3, xv3) DINV_XST(4, xv4) DINV_XST(5, xv5) DINV_XST(6, xv6)
+#undef DINV_XST
+#define DINV_WST(IT, REG) if (IT < WI && (IT < WI - 1 || tid + IT * 256 < WV)) { const int i_ = tid + IT * 256; st4(ws + (i_ >> 1) * LP + (i_ & 1) * 4, REG); }
             DINV_WST(0, w0) DINV_WST(1, w1) DINV_WST(2, w2) DINV_WST(3, w3) DINV_WST(4, w4)
 #undef DINV_WST
             __syncthreads();
         }
         if (ch + 1 < nchunks) {
-            // unpredicated loads (surplus slots re-load the last element and are never stored): a predicated
-            // load into a loop-carried register forces an early vmcnt wait
-            const float* xbase = a.x + (int64_t)(ch + 1) * KC * a.g.cs;
-#pragma unroll
-            for (int it = 0; it < XI; ++it) xv[it] = *reinterpret_cast<const float4*>(xbase + xoff_g[it]);
+            const float* xb = a.x + (int64_t)(ch + 1) * a.g.cs * 8 + row0;
+#define DINV_XLD(IT, REG) REG = ld4(xb + xoff_g[IT]);
+            DINV_XLD(0, xv0) DINV_XLD(1, xv1) DINV_XLD(2, xv2) DINV_XLD(3, xv3) DINV_XLD(4, xv4) DINV_XLD(5, xv5) DINV_XLD(6, xv6)
+#undef DINV_XLD
             if (a.x2) {
-                const float* x2base = a.x2 + (int64_t)(ch + 1) * KC * a.g.cs;
-#pragma unroll
-                for (int it = 0; it < XI; ++it) {
-                    const float4 u = *reinterpret_cast<const float4*>(x2base + xoff_g[it]);
-                    xv[it].x += u.x; xv[it].y += u.y; xv[it].z += u.z; xv[it].w += u.w;
-                }
+                const float* xb2 = a.x2 + (int64_t)(ch + 1) * a.g.cs * 8 + row0;
+#define DINV_XLD2(IT, REG) REG = add4(REG, ld4(xb2 + xoff_g[IT]));
+                DINV_XLD2(0, xv0) DINV_XLD2(1, xv1) DINV_XLD2(2, xv2) DINV_XLD2(3, xv3) DINV_XLD2(4, xv4) DINV_XLD2(5, xv5) DINV_XLD2(6, xv6)
+#undef DINV_XLD2
             }
             const float4* wsrc = wblk + (int64_t)(ch + 1) * WV;
 #define DINV_WLD(IT, REG) if (IT < WI) REG = wsrc[min(tid + IT * 256, WV - 1)];
@@ -137,69 +172,44 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
 #undef DINV_WLD
         }
         if (ch < 0) continue;
+        // one tap = 4 ds_read_b128 (channels 4h..4h+3 of this lane's cout rows / pixels) + 16 MFMAs
+        const float* xrow = xs + (wv * 64 + l31 + HALO) * LP + 4 * lhi;
+        const float* wrow = ws + l31 * LP + 4 * lhi;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3 - 1;
+            float4 av[MREP], bv[2];
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                const int k = kk * 2 + lhi;
-                float av[MREP], bv[2];
+            for (int m = 0; m < MREP; ++m) av[m] = ld4(wrow + (tap * MT + m * 32) * LP);
 #pragma unroll
-                for (int m = 0; m < MREP; ++m) av[m] = ws[tap][k][m * 32 + l31];
+            for (int n = 0; n < 2; ++n) bv[n] = ld4(xrow + (dy * SEG + n * 32 + dx) * LP);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) bv[n] = xs[dy][k][wv * 64 + n * 32 + l31 + HALO + dx];
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int m = 0; m < MREP; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-            }
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(av[m], s), comp(bv[n], s), acc[m][n], 0, 0, 0);
         }
     }
-    // epilogue: D[i][j], j = lane&31 (pixel), i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
-    const int co0 = blockIdx.y * MT;
+    const int cb0 = blockIdx.y * (MT / 8);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int64_t p = p0 + wv * 64 + n * 32 + l31;
         if (p >= a.g.np) continue;
-        const bool in = interior(a.g, p);
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-            const int cb = co0 + m * 32 + 4 * lhi;
-            if (cb >= a.cout_valid) continue;  // (tail conv: only the first cout_valid planes exist)
-            const int64_t ob = (int64_t)cb * a.g.cs + a.g.sl + p;
-            float r1[16], r2[16];
-            // residual planes have zero borders, so border lanes may load them too: 16 independent loads in flight
-            if (NRES >= 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) r1[r] = a.res1[ob + (int64_t)((r & 3) + 8 * (r >> 2)) * a.g.cs];
-            }
-            if (NRES >= 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) r2[r] = a.res2[ob + (int64_t)((r & 3) + 8 * (r >> 2)) * a.g.cs];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cb + (r & 3) + 8 * (r >> 2);
-                if (MREP == 1 && co >= a.cout_valid) continue;
-                float v = acc[m][n][r];
-                if (RELU) v = fmaxf(v, 0.f);
-                if (NRES >= 1) v += r1[r];
-                if (NRES >= 2) v += r2[r];
-                a.y[ob + (int64_t)((r & 3) + 8 * (r >> 2)) * a.g.cs] = in ? v : 0.f;
-            }
-        }
+        store_tile<MREP, RELU, NRES>(acc, n, a.g.sl + p, interior(a.g, p), cb0, a.cblocks_valid, a.g.cs, lhi, a.y, a.res1,
+                                     a.res2);
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// 2x2 stride-2 convolution (downsample_strideconv, drunet.py:524-552): K = 4*Cin, B operand
-// gathered straight from global/L2 (stride-2 pixels); 2.3 % of DRUNet's FLOPs.
+// 2x2 stride-2 convolution (downsample_strideconv, drunet.py:524-552): K = 4 taps x Cin; B operand gathered
+// straight from global/L2 (one 16-byte load = 4 k-steps); 2.3 % of DRUNet's FLOPs together with the up-conv.
 struct DownArgs {
     Geom gi, go;
-    const float* x;  // [cin][gi.cs]
-    const float* w;  // [4][cin][cout]
-    float* y;        // [cout][go.cs]
+    const float* x;  // [cin/8][gi.cs][8]
+    const float* w;  // [4][cin/8][cout][8]
+    float* y;        // [cout/8][go.cs][8]
     int32_t cin, cout;
 };
 
@@ -229,61 +239,50 @@ __global__ __launch_bounds__(256) void down2x2_kernel(DownArgs a) {
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    // K loop = 4 taps x cin, walked in groups of 4 k-steps (8 channels); the 16 operand loads of group g+1
-    // are issued before the 16 MFMAs of group g (register double buffer)
-    const int ngroups = 4 * (a.cin / 8);
-    float av[2][4][2], bv[2][4][2];
-    auto load_group = [&](int gidx, float (&A)[4][2], float (&B)[4][2]) {
-        const int tap = gidx / (a.cin / 8), c0 = (gidx - tap * (a.cin / 8)) * 8;
-        const int64_t toff = (int64_t)(tap >> 1) * a.gi.wp + (tap & 1);
-        const float* wt = a.w + (int64_t)tap * a.cin * a.cout + co0 + l31;
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const int ci = c0 + 2 * sidx + lhi;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) A[sidx][m] = wt[(int64_t)ci * a.cout + m * 32];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) B[sidx][n] = a.x[(int64_t)ci * a.gi.cs + ioff[n] + toff];
-        }
-    };
-    auto mma_group = [&](float (&A)[4][2], float (&B)[4][2]) {
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sidx][m], B[sidx][n], acc[m][n], 0, 0, 0);
-    };
-    load_group(0, av[0], bv[0]);
-    for (int gidx = 0; gidx < ngroups; gidx += 2) {
-        if (gidx + 1 < ngroups) load_group(gidx + 1, av[1], bv[1]);
-        mma_group(av[0], bv[0]);
-        if (gidx + 2 < ngroups) load_group(gidx + 2, av[0], bv[0]);
-        if (gidx + 1 < ngroups) mma_group(av[1], bv[1]);
+    const int ncb = a.cin / 8, ngroups = 4 * ncb;
+    // group g = (tap, channel block): 4 operand loads feed 16 MFMAs; loads of group g+1 issued before the MFMAs of g
+    float4 a00, a01, b00, b01, a10, a11, b10, b11;
+#define DINV_LOAD_GROUP(GIDX, A0, A1, B0, B1)                                                                   \
+    {                                                                                                           \
+        const int tap_ = (GIDX) / ncb, cb_ = (GIDX) - tap_ * ncb;                                               \
+        const int64_t toff_ = (int64_t)(tap_ >> 1) * a.gi.wp + (tap_ & 1);                                      \
+        const float* wt_ = a.w + (((int64_t)tap_ * ncb + cb_) * a.cout + co0 + l31) * 8 + 4 * lhi;              \
+        A0 = ld4(wt_); A1 = ld4(wt_ + 32 * 8);                                                                  \
+        B0 = ld4(a.x + ((int64_t)cb_ * a.gi.cs + ioff[0] + toff_) * 8 + 4 * lhi);                               \
+        B1 = ld4(a.x + ((int64_t)cb_ * a.gi.cs + ioff[1] + toff_) * 8 + 4 * lhi);                               \
     }
+#define DINV_MMA_GROUP(A0, A1, B0, B1)                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                             \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(A0, s), comp(B0, s), acc[0][0], 0, 0, 0);         \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(A0, s), comp(B1, s), acc[0][1], 0, 0, 0);         \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(A1, s), comp(B0, s), acc[1][0], 0, 0, 0);         \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(A1, s), comp(B1, s), acc[1][1], 0, 0, 0);         \
+    }
+    DINV_LOAD_GROUP(0, a00, a01, b00, b01)
+    for (int gidx = 0; gidx < ngroups; gidx += 2) {
+        if (gidx + 1 < ngroups) DINV_LOAD_GROUP(gidx + 1, a10, a11, b10, b11)
+        DINV_MMA_GROUP(a00, a01, b00, b01)
+        if (gidx + 2 < ngroups) DINV_LOAD_GROUP(gidx + 2, a00, a01, b00, b01)
+        if (gidx + 1 < ngroups) DINV_MMA_GROUP(a10, a11, b10, b11)
+    }
+#undef DINV_LOAD_GROUP
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int64_t q = q0 + n * 32 + l31;
         if (q >= a.go.np) continue;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                a.y[(int64_t)co * a.go.cs + a.go.sl + q] = in[n] ? acc[m][n][r] : 0.f;
-            }
+        store_tile<2, false, 0>(acc, n, a.go.sl + q, in[n], co0 / 8, a.cout / 8, a.go.cs, lhi, a.y, nullptr, nullptr);
     }
 }
 
-// 2x2 stride-2 transposed convolution (upsample_convtranspose, drunet.py:493-521): four
-// parity-class GEMMs with K = Cin; input optionally the sum of two tensors (U-Net skip add).
+// 2x2 stride-2 transposed convolution (upsample_convtranspose, drunet.py:493-521): four parity-class GEMMs with
+// K = Cin; input optionally the sum of two tensors (U-Net skip add).  Only interior pixels are written; the zero
+// frame of the output buffer is never touched.
 struct UpArgs {
     Geom gi, go;
-    const float* x;   // [cin][gi.cs]
+    const float* x;   // [cin/8][gi.cs][8]
     const float* x2;  // optional, added to x
-    const float* w;   // [4][cin][cout]
-    float* y;         // [cout][go.cs]
+    const float* w;   // [4][cin/8][cout][8]
+    float* y;         // [cout/8][go.cs][8]
     int32_t cin, cout;
 };
 
@@ -315,86 +314,71 @@ __global__ __launch_bounds__(256) void up2x2_kernel(UpArgs a) {
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    const float* wt = a.w + (int64_t)tap * a.cin * a.cout + co0 + l31;
-    const int ngroups = a.cin / 8;
-    float av[2][4][2], bv[2][4][2];
-    auto load_group = [&](int gidx, float (&A)[4][2], float (&B)[4][2]) {
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const int ci = gidx * 8 + 2 * sidx + lhi;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) A[sidx][m] = wt[(int64_t)ci * a.cout + m * 32];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                B[sidx][n] = a.x[(int64_t)ci * a.gi.cs + ioff[n]];
-                if (a.x2) B[sidx][n] += a.x2[(int64_t)ci * a.gi.cs + ioff[n]];
-            }
-        }
-    };
-    auto mma_group = [&](float (&A)[4][2], float (&B)[4][2]) {
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sidx][m], B[sidx][n], acc[m][n], 0, 0, 0);
-    };
-    load_group(0, av[0], bv[0]);
-    for (int gidx = 0; gidx < ngroups; gidx += 2) {
-        if (gidx + 1 < ngroups) load_group(gidx + 1, av[1], bv[1]);
-        mma_group(av[0], bv[0]);
-        if (gidx + 2 < ngroups) load_group(gidx + 2, av[0], bv[0]);
-        if (gidx + 1 < ngroups) mma_group(av[1], bv[1]);
+    const int ncb = a.cin / 8;
+    float4 a00, a01, b00, b01, a10, a11, b10, b11;
+#define DINV_LOAD_GROUP(CB, A0, A1, B0, B1)                                                                      \
+    {                                                                                                           \
+        const float* wt_ = a.w + (((int64_t)tap * ncb + (CB)) * a.cout + co0 + l31) * 8 + 4 * lhi;              \
+        A0 = ld4(wt_); A1 = ld4(wt_ + 32 * 8);                                                                  \
+        const int64_t o0_ = ((int64_t)(CB) * a.gi.cs + ioff[0]) * 8 + 4 * lhi;                                  \
+        const int64_t o1_ = ((int64_t)(CB) * a.gi.cs + ioff[1]) * 8 + 4 * lhi;                                  \
+        B0 = ld4(a.x + o0_); B1 = ld4(a.x + o1_);                                                               \
+        if (a.x2) { B0 = add4(B0, ld4(a.x2 + o0_)); B1 = add4(B1, ld4(a.x2 + o1_)); }                           \
     }
+    DINV_LOAD_GROUP(0, a00, a01, b00, b01)
+    for (int cb = 0; cb < ncb; cb += 2) {
+        if (cb + 1 < ncb) DINV_LOAD_GROUP(cb + 1, a10, a11, b10, b11)
+        DINV_MMA_GROUP(a00, a01, b00, b01)
+        if (cb + 2 < ncb) DINV_LOAD_GROUP(cb + 2, a00, a01, b00, b01)
+        if (cb + 1 < ncb) DINV_MMA_GROUP(a10, a11, b10, b11)
+    }
+#undef DINV_LOAD_GROUP
+#undef DINV_MMA_GROUP
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         if (!in[n]) continue;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                a.y[(int64_t)co * a.go.cs + ooff[n]] = acc[m][n][r];
-            }
+        store_tile<2, false, 0>(acc, n, ooff[n], true, co0 / 8, a.cout / 8, a.go.cs, lhi, a.y, nullptr, nullptr);
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// NCHW <-> padded channel planes.  pack also writes the noise-level map channel
-// (drunet.py:238-251: x = cat(x, sigma map)).
+// NCHW <-> blocked padded rows.  pack also writes the noise-level map channel (drunet.py:238-251:
+// x = cat(x, sigma map)); one thread per pixel writes the whole first channel block (cin+1 <= 8).
 __global__ void pack_kernel(Geom g, const float* __restrict__ x, int cin, const float* __restrict__ sigma,
                             int sigma_mode, float sigma_scalar, float* __restrict__ act) {
-    // grid: (ceil(w/64), h, (cin+1)*batch)
+    // grid: (ceil(w/64), h, batch)
     const int col = blockIdx.x * 64 + threadIdx.x;
     const int row = blockIdx.y;
-    const int c = blockIdx.z / g.batch, b = blockIdx.z % g.batch;
+    const int b = blockIdx.z;
     if (col >= g.w) return;
-    float v;
-    if (c < cin) {
-        v = x[(((int64_t)b * cin + c) * g.h + row) * g.w + col];
-    } else {
-        // sigma_mode 0: scalar, 1: per-sample [B], 2: map [B,1,H,W]
-        v = sigma_mode == 0 ? sigma_scalar : sigma_mode == 1 ? sigma[b] : sigma[((int64_t)b * g.h + row) * g.w + col];
-    }
-    act[(int64_t)c * g.cs + g.sl + (int64_t)b * g.plane + (int64_t)(row + 1) * g.wp + col + 1] = v;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = c < cin ? x[(((int64_t)b * cin + c) * g.h + row) * g.w + col] : 0.f;
+    // sigma_mode 0: scalar, 1: per-sample [B], 2: map [B,1,H,W]
+    const float sg = sigma_mode == 0 ? sigma_scalar : sigma_mode == 1 ? sigma[b] : sigma[((int64_t)b * g.h + row) * g.w + col];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c == cin) v[c] = sg;
+    float* o = act + (g.sl + (int64_t)b * g.plane + (int64_t)(row + 1) * g.wp + col + 1) * 8;
+    st4(o, make_float4(v[0], v[1], v[2], v[3]));
+    st4(o + 4, make_float4(v[4], v[5], v[6], v[7]));
 }
 
 __global__ void unpack_kernel(Geom g, const float* __restrict__ act, int cout, float* __restrict__ y) {
     const int col = blockIdx.x * 64 + threadIdx.x;
     const int row = blockIdx.y;
-    const int c = blockIdx.z / g.batch, b = blockIdx.z % g.batch;
+    const int b = blockIdx.z;
     if (col >= g.w) return;
-    y[(((int64_t)b * cout + c) * g.h + row) * g.w + col] =
-        act[(int64_t)c * g.cs + g.sl + (int64_t)b * g.plane + (int64_t)(row + 1) * g.wp + col + 1];
+    const float* o = act + (g.sl + (int64_t)b * g.plane + (int64_t)(row + 1) * g.wp + col + 1) * 8;
+    for (int c = 0; c < cout; ++c) y[(((int64_t)b * cout + c) * g.h + row) * g.w + col] = o[c];
 }
 
 int check_geom(const dinv_act_geom* g) {
     DINV_REQUIRE(g != nullptr, "null geometry");
     DINV_REQUIRE(g->batch >= 1 && g->height >= 1 && g->width >= 1, "bad geometry %dx%dx%d", g->batch, g->height, g->width);
     DINV_REQUIRE(g->wp % 4 == 0 && g->wp >= g->width + 2 && g->hp == g->height + 2, "bad padded frame");
-    DINV_REQUIRE(g->sl % 4 == 0 && g->sl >= g->wp + HALO && g->cs % 4 == 0, "bad slack/stride");
-    DINV_REQUIRE(g->cs >= g->sl + ceil_div(g->np, NT) * NT + g->wp + HALO, "channel stride too small");
+    DINV_REQUIRE(g->sl >= g->wp + HALO, "bad leading slack");
+    DINV_REQUIRE(g->cs >= g->sl + ceil_div(g->np, NT) * NT + g->wp + HALO, "channel-block stride too small");
     return 0;
 }
 
@@ -408,8 +392,8 @@ extern "C" int dinv_act_geom_init(int32_t batch, int32_t height, int32_t width, 
     g->wp = (width + 2 + 3) / 4 * 4;
     g->plane = (int64_t)g->hp * g->wp;
     g->np = g->plane * batch;
-    g->sl = g->wp + HALO;  // multiple of 4
-    g->cs = g->sl + ceil_div(g->np, NT) * NT + g->wp + HALO;
+    g->sl = g->wp + 4;
+    g->cs = g->sl + ceil_div(g->np, NT) * NT + g->wp + 4;
     g->cs = (g->cs + 3) / 4 * 4;
     return 0;
 }
@@ -419,15 +403,15 @@ extern "C" int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float*
                             const float* res2, int32_t relu, dinv_stream_t stream) {
     if (int e = check_geom(g)) return e;
     DINV_REQUIRE(x && w_packed && y, "null tensor pointer");
-    DINV_REQUIRE(cin % KC == 0 && cin >= KC, "cin=%d must be a positive multiple of %d (pad with zero planes)", cin, KC);
+    DINV_REQUIRE(cin % KC == 0 && cin >= KC, "cin=%d must be a positive multiple of %d (pad with zero channels)", cin, KC);
     DINV_REQUIRE(cout % 32 == 0 && cout_valid >= 1 && cout_valid <= cout, "bad cout=%d/valid=%d", cout, cout_valid);
-    Conv3Args a{make_geom(*g), x, x2, w_packed, y, res1, res2, cin, cout_valid, relu};
+    const int cbv = (cout_valid + 7) / 8;  // channel blocks that exist in the output buffer
+    Conv3Args a{make_geom(*g), x, x2, w_packed, y, res1, res2, cin, cbv, relu};
     const unsigned gx = (unsigned)ceil_div(g->np, NT);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nres = (res1 ? 1 : 0) + (res2 ? 1 : 0);
     DINV_REQUIRE(res1 || !res2, "res2 given without res1");
     if (cout % 64 == 0) {
-        DINV_REQUIRE(cout_valid == cout, "partial output planes are only supported for 32-wide cout tiles");
         const dim3 grid(gx, cout / 64);
 #define DINV_LAUNCH_C3(RELU, NRES) hipLaunchKernelGGL((conv3x3_kernel<2, RELU, NRES>), grid, dim3(256), 0, s, a)
         if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }
@@ -478,9 +462,10 @@ extern "C" int dinv_act_pack(const dinv_act_geom* g, const float* x, int32_t cin
                              int32_t sigma_mode, float sigma_scalar, float* act, dinv_stream_t stream) {
     if (int e = check_geom(g)) return e;
     DINV_REQUIRE(x && act, "null tensor pointer");
+    DINV_REQUIRE(cin >= 1 && cin + 1 <= 8, "pack supports up to 7 image channels (+ noise map) in the first block");
     DINV_REQUIRE(sigma_mode == 0 || sigma != nullptr, "sigma tensor missing");
-    DINV_REQUIRE((int64_t)(cin + 1) * g->batch <= 65535 && g->height <= 65535, "pack grid too large");
-    hipLaunchKernelGGL(pack_kernel, dim3((g->width + 63) / 64, g->height, (cin + 1) * g->batch), dim3(64), 0,
+    DINV_REQUIRE(g->batch <= 65535 && g->height <= 65535, "pack grid too large");
+    hipLaunchKernelGGL(pack_kernel, dim3((g->width + 63) / 64, g->height, g->batch), dim3(64), 0,
                        reinterpret_cast<hipStream_t>(stream), make_geom(*g), x, cin, sigma, sigma_mode, sigma_scalar, act);
     DINV_CHECK_LAUNCH();
     return 0;
@@ -489,8 +474,9 @@ extern "C" int dinv_act_pack(const dinv_act_geom* g, const float* x, int32_t cin
 extern "C" int dinv_act_unpack(const dinv_act_geom* g, const float* act, int32_t cout, float* y, dinv_stream_t stream) {
     if (int e = check_geom(g)) return e;
     DINV_REQUIRE(y && act, "null tensor pointer");
-    DINV_REQUIRE((int64_t)cout * g->batch <= 65535 && g->height <= 65535, "unpack grid too large");
-    hipLaunchKernelGGL(unpack_kernel, dim3((g->width + 63) / 64, g->height, cout * g->batch), dim3(64), 0,
+    DINV_REQUIRE(cout >= 1 && cout <= 8, "unpack reads the first channel block (<= 8 channels)");
+    DINV_REQUIRE(g->batch <= 65535 && g->height <= 65535, "unpack grid too large");
+    hipLaunchKernelGGL(unpack_kernel, dim3((g->width + 63) / 64, g->height, g->batch), dim3(64), 0,
                        reinterpret_cast<hipStream_t>(stream), make_geom(*g), act, cout, y);
     DINV_CHECK_LAUNCH();
     return 0;

@@ -42,32 +42,32 @@ def geom(batch: int, h: int, w: int) -> ActGeom:
 
 
 def alloc(g: ActGeom, channels: int, device) -> torch.Tensor:
-    """zero-initialised padded-plane buffer [channels, cs]"""
-    return torch.zeros((channels, g.cs), device=device, dtype=torch.float32)
+    """zero-initialised activation buffer [ceil(channels/8), cs, 8] (padded pixel rows, channels blocked by 8)"""
+    return torch.zeros(((channels + 7) // 8, g.cs, 8), device=device, dtype=torch.float32)
 
 
 def pack_conv3x3_weight(w: torch.Tensor) -> tuple[torch.Tensor, int, int]:
-    """OIHW [Cout,Cin,3,3] -> [Cout/MT][Cin/8][9][8][MT] (zero padded). Returns (packed, cin_p, cout_p)."""
+    """OIHW [Cout,Cin,3,3] -> [Cout/MT][Cin/8][9 taps][MT][8] (zero padded). Returns (packed, cin_p, cout_p)."""
     cout, cin = w.shape[:2]
     cin_p = (cin + 7) // 8 * 8
     cout_p = (cout + 31) // 32 * 32
     mt = 64 if cout_p % 64 == 0 else 32
     wp = torch.zeros((cout_p, cin_p, 3, 3), device=w.device, dtype=torch.float32)
     wp[:cout, :cin] = w.detach().float()
-    wp = wp.reshape(cout_p // mt, mt, cin_p // 8, 8, 9).permute(0, 2, 4, 3, 1).contiguous()
+    wp = wp.reshape(cout_p // mt, mt, cin_p // 8, 8, 9).permute(0, 2, 4, 1, 3).contiguous()
     return wp, cin_p, cout_p
 
 
 def pack_down_weight(w: torch.Tensor) -> torch.Tensor:
-    """Conv2d k2 s2 weight [Cout,Cin,2,2] -> [tap=dy*2+dx][Cin][Cout]"""
+    """Conv2d k2 s2 weight [Cout,Cin,2,2] -> [tap=dy*2+dx][Cin/8][Cout][8]"""
     cout, cin = w.shape[:2]
-    return w.detach().float().permute(2, 3, 1, 0).reshape(4, cin, cout).contiguous()
+    return w.detach().float().permute(2, 3, 1, 0).reshape(4, cin // 8, 8, cout).permute(0, 1, 3, 2).contiguous()
 
 
 def pack_up_weight(w: torch.Tensor) -> torch.Tensor:
-    """ConvTranspose2d k2 s2 weight [Cin,Cout,2,2] -> [tap=dy*2+dx][Cin][Cout]"""
+    """ConvTranspose2d k2 s2 weight [Cin,Cout,2,2] -> [tap=dy*2+dx][Cin/8][Cout][8]"""
     cin, cout = w.shape[:2]
-    return w.detach().float().permute(2, 3, 0, 1).reshape(4, cin, cout).contiguous()
+    return w.detach().float().permute(2, 3, 0, 1).reshape(4, cin // 8, 8, cout).permute(0, 1, 3, 2).contiguous()
 
 
 def pack_input(g, x, sigma, act):

@@ -45,6 +45,20 @@ def bench_mri(B, coils, img, three_d):
                           "alg_MB": alg / 1e6, "GBps": alg / t / 1e9, "frac_hbm_peak": alg / t / HBM_PEAK}))
 
 
+def bench_radon(B, W, nang):
+    dev = torch.device("cuda:0")
+    phys = dinv.physics.Tomography(angles=nang, img_width=W, normalize=False, device=dev)
+    x = torch.rand(B, 1, W, W, device=dev)
+    y = phys.A(x)
+    G = y.shape[2]
+    alg = B * (W * W + G * nang) * 4
+    for name, fn in (("A", lambda: phys.A(x)), ("A_adjoint", lambda: phys.A_adjoint(y)), ("ramp", lambda: phys.filter(y)),
+                     ("fbp", lambda: phys.A_dagger(y, fbp=True))):
+        t = timeit(fn, iters=5, warmup=1)
+        print(json.dumps({"op": f"Tomography.{name}", "B": B, "W": W, "angles": nang, "ms": t * 1e3, "ms_per_img": t * 1e3 / B,
+                          "alg_MB": alg / 1e6, "GBps": alg / t / 1e9, "Gsamples_per_s": B * G * G * nang / t / 1e9}))
+
+
 def bench_drunet(B, cin, H, W, gflop_per_img):
     dev = torch.device("cuda:0")
     model = dinv.models.DRUNet(cin, cin, pretrained=None).to(dev).eval()
@@ -62,6 +76,8 @@ if __name__ == "__main__":
         bench_mri(32, 8, (320, 320), False)
     if "mri3d" in which:
         bench_mri(2, 12, (16, 256, 256), True)
+    if "radon" in which:
+        bench_radon(8, 512, 720)
     if "drunet" in which:
         bench_drunet(32, 2, 320, 320, 433.4)
     if "drunet4" in which:
