@@ -103,23 +103,24 @@ int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const float* maps,
 /* ------------------------------------------------------------------------- */
 /* DRUNet convolutions on the fp32 matrix cores                                */
 /* (deepinv/models/drunet.py:200-210 forward_unet; layers :39-101, 323-434,    */
-/*  524-602).  Activations live in "padded channel planes":                    */
-/*     act[c][sl + b*plane + r*wp + col],  (r,col) in a zero-bordered          */
-/*     (H+2) x wp frame, wp = roundup(W+2, 4); one channel row is `cs` floats. */
+/*  524-602).  Activations live in "padded pixel rows, channels blocked by 8": */
+/*     act[c/8][sl + b*plane + r*wp + col][c%8],  (r,col) in a zero-bordered   */
+/*     (H+2) x wp frame, wp = roundup(W+2, 4); one channel-block row is        */
+/*     `cs` pixels x 8 floats.                                                 */
 /* ------------------------------------------------------------------------- */
 typedef struct {
     int32_t batch, height, width; /* unpadded size of this U-Net level */
     int32_t hp, wp;               /* padded frame */
     int64_t plane;                /* hp*wp */
-    int64_t np;                   /* batch*plane : flattened padded pixels per channel */
-    int64_t sl;                   /* leading slack floats (multiple of 4) */
-    int64_t cs;                   /* channel stride in floats (multiple of 4) */
+    int64_t np;                   /* batch*plane : flattened padded pixels */
+    int64_t sl;                   /* leading slack pixels */
+    int64_t cs;                   /* pixels per channel-block row (incl. slack) */
 } dinv_act_geom;
 
-/* fills the geometry for a level; a buffer of C channels needs C*cs floats, zero-initialised once */
+/* fills the geometry for a level; a buffer of C channels needs ceil(C/8)*cs*8 floats, zero-initialised once */
 int dinv_act_geom_init(int32_t batch, int32_t height, int32_t width, dinv_act_geom* g);
 
-/* NCHW image (+ noise-level map as extra channel: drunet.py:238-251) -> padded planes.
+/* NCHW image (+ noise-level map as extra channel: drunet.py:238-251) -> first channel block (cin + 1 <= 8).
  * sigma_mode 0: scalar `sigma_scalar`; 1: per-sample tensor [B]; 2: map [B,1,H,W] */
 int dinv_act_pack(const dinv_act_geom* g, const float* x, int32_t cin, const float* sigma,
                   int32_t sigma_mode, float sigma_scalar, float* act, dinv_stream_t stream);
@@ -127,16 +128,16 @@ int dinv_act_unpack(const dinv_act_geom* g, const float* act, int32_t cout, floa
 
 /* y = [relu]( conv3x3(x (+x2)) ) (+res1) (+res2), stride 1, zero padding 1, no bias
  * (nn.Conv2d in drunet.py `conv(... mode="C")`, ResBlock :403-434).
- * w_packed: [cout/MT][cin/8][9 taps][8][MT], MT = 64 if cout % 64 == 0 else 32; cin % 8 == 0
- * (zero-pad), cout % 32 == 0 (zero-pad); only the first cout_valid output planes are written. */
+ * w_packed: [cout/MT][cin/8][9 taps][MT][8], MT = 64 if cout % 64 == 0 else 32; cin % 8 == 0
+ * (zero-pad), cout % 32 == 0 (zero-pad); only the first ceil(cout_valid/8) output channel blocks are written. */
 int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float* x2, const float* w_packed,
                  int32_t cin, int32_t cout, int32_t cout_valid, float* y, const float* res1,
                  const float* res2, int32_t relu, dinv_stream_t stream);
-/* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin][cout] */
+/* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin/8][cout][8] */
 int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                       const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
 /* 2x2 stride-2 transposed conv of (x + x2) (upsample_convtranspose, drunet.py:493-521);
- * w: [4 taps][cin][cout] */
+ * w: [4 taps][cin/8][cout][8] */
 int dinv_conv_up2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
                     const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
 
