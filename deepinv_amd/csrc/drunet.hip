@@ -102,6 +102,7 @@ struct Conv3Args {
     const float* res1; // optional residuals added in the epilogue
     const float* res2;
     int32_t cin, cblocks_valid, relu;
+    int32_t ntiles, ytiles, tiles_per_xcd;  // pixel tiles, cout tiles, ceil(ntiles / 8)
 };
 
 template <int MREP, bool RELU, int NRES>
@@ -111,7 +112,16 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     __shared__ __attribute__((aligned(16))) float ws[9 * MT * LP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int64_t p0 = (int64_t)blockIdx.x * NT;
+    // XCD-aware block -> (pixel tile, cout tile) map.  Blocks b, b+8, b+16, ... run on the same XCD (observed
+    // placement; used for speed only).  Each XCD walks a contiguous range of pixel tiles, all cout tiles of a
+    // pixel tile back to back: neighbouring tiles share 2 of their 3 staged row segments and the cout tiles
+    // share all of them, so those re-reads hit that XCD's L2 instead of the fabric (PMC: FETCH_SIZE was 3x the
+    // activation bytes at grid.y = 1 and 11x at grid.y = 8 with the plain row-major block order).
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int ty = jx % a.ytiles, tl = jx / a.ytiles;
+    const int tile = xcd * a.tiles_per_xcd + tl;
+    if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;
+    const int64_t p0 = (int64_t)tile * NT;
     const int nchunks = a.cin / KC;
     f32x16 acc[MREP][2];
 #pragma unroll
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     constexpr int WV = 9 * MT * 2;          // float4 of weights per block
     constexpr int XI = (XV + 255) / 256, WI = (WV + 255) / 256;
     static_assert(XI == 7 && WI <= 5, "prefetch slots");
-    const float4* wblk = reinterpret_cast<const float4*>(a.w) + (int64_t)blockIdx.y * nchunks * WV;
+    const float4* wblk = reinterpret_cast<const float4*>(a.w) + (int64_t)ty * nchunks * WV;
 
     // per-thread staging slots are fixed across blocks: (segment, float4-within-segment) decomposition once
     int xoff_lds[XI], xoff_g[XI];
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(av[m], s), comp(bv[n], s), acc[m][n], 0, 0, 0);
         }
     }
-    const int cb0 = blockIdx.y * (MT / 8);
+    const int cb0 = ty * (MT / 8);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int64_t p = p0 + wv * 64 + n * 32 + l31;
@@ -406,19 +416,22 @@ extern "C" int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float*
     DINV_REQUIRE(cin % KC == 0 && cin >= KC, "cin=%d must be a positive multiple of %d (pad with zero channels)", cin, KC);
     DINV_REQUIRE(cout % 32 == 0 && cout_valid >= 1 && cout_valid <= cout, "bad cout=%d/valid=%d", cout, cout_valid);
     const int cbv = (cout_valid + 7) / 8;  // channel blocks that exist in the output buffer
-    Conv3Args a{make_geom(*g), x, x2, w_packed, y, res1, res2, cin, cbv, relu};
-    const unsigned gx = (unsigned)ceil_div(g->np, NT);
+    const int ntiles = (int)ceil_div(g->np, NT);
+    const int tpx = (ntiles + 7) / 8;
+    const int ytiles = cout % 64 == 0 ? cout / 64 : cout / 32;
+    Conv3Args a{make_geom(*g), x, x2, w_packed, y, res1, res2, cin, cbv, relu, ntiles, ytiles, tpx};
+    const unsigned gx = (unsigned)(8 * tpx * ytiles);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nres = (res1 ? 1 : 0) + (res2 ? 1 : 0);
     DINV_REQUIRE(res1 || !res2, "res2 given without res1");
     if (cout % 64 == 0) {
-        const dim3 grid(gx, cout / 64);
+        const dim3 grid(gx);
 #define DINV_LAUNCH_C3(RELU, NRES) hipLaunchKernelGGL((conv3x3_kernel<2, RELU, NRES>), grid, dim3(256), 0, s, a)
         if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }
         else      { if (nres == 0) DINV_LAUNCH_C3(false, 0); else if (nres == 1) DINV_LAUNCH_C3(false, 1); else DINV_LAUNCH_C3(false, 2); }
 #undef DINV_LAUNCH_C3
     } else {
-        const dim3 grid(gx, cout / 32);
+        const dim3 grid(gx);
 #define DINV_LAUNCH_C3(RELU, NRES) hipLaunchKernelGGL((conv3x3_kernel<1, RELU, NRES>), grid, dim3(256), 0, s, a)
         if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }
         else      { if (nres == 0) DINV_LAUNCH_C3(false, 0); else if (nres == 1) DINV_LAUNCH_C3(false, 1); else DINV_LAUNCH_C3(false, 2); }
