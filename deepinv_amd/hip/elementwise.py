@@ -1,0 +1,71 @@
+"""ctypes wrappers of csrc/elementwise.hip: fused linear combinations, deterministic per-sample dot products and
+the CG vector updates.  Used by the iteration drivers when their operands live on the HIP device and no autograd
+graph is being recorded (otherwise the drivers use differentiable torch expressions)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import check, lib, ptr, stream_ptr
+
+_declared = False
+
+
+def _l():
+    global _declared
+    l = lib()
+    if not _declared:
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        l.dinv_lincomb.argtypes = [i64, f32, vp, f32, vp, f32, vp, vp, vp]
+        l.dinv_batched_dot_blocks.restype = i32
+        l.dinv_batched_dot_blocks.argtypes = [i64]
+        l.dinv_batched_dot.argtypes = [i32, i64, vp, vp, vp, vp, vp]
+        l.dinv_cg_update.argtypes = [i32, i32, i64, vp, vp, f32, vp, vp, vp, vp, vp]
+        _declared = True
+    return l
+
+
+def eligible(*tensors) -> bool:
+    """fast path only for plain fp32 contiguous device tensors outside autograd recording"""
+    for t in tensors:
+        if t is None:
+            continue
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            return False
+        if torch.is_grad_enabled() and t.requires_grad:
+            return False
+        if t.data_ptr() % 16:
+            return False
+    return True
+
+
+def lincomb(a: float, x, b: float = 0.0, y=None, c: float = 0.0, z=None):
+    """a*x + b*y + c*z in one pass"""
+    out = torch.empty_like(x)
+    check(_l().dinv_lincomb(x.numel(), float(a), ptr(x), float(b), ptr(y), float(c), ptr(z), ptr(out), stream_ptr(x.device)))
+    return out
+
+
+def batched_dot(x, y):
+    """<x[b], y[b]> per sample, shape [B] (deterministic summation order)"""
+    B = x.shape[0]
+    n = x.numel() // max(B, 1)
+    out = torch.empty(B, device=x.device, dtype=torch.float32)
+    part = torch.empty(B * _l().dinv_batched_dot_blocks(n), device=x.device, dtype=torch.float32)
+    check(_l().dinv_batched_dot(B, n, ptr(x), ptr(y), ptr(out), ptr(part), stream_ptr(x.device)))
+    return out
+
+
+def cg_update_xr(num, den, eps, x, r, p, Ap):
+    """x += s p ; r -= s Ap  with s_b = num_b / (den_b + eps), in place"""
+    B = x.shape[0]
+    check(_l().dinv_cg_update(0, B, x.numel() // B, ptr(num), ptr(den), float(eps), ptr(x), ptr(r), ptr(p), ptr(Ap),
+                              stream_ptr(x.device)))
+
+
+def cg_update_p(num, den, eps, p, r):
+    """p = r + s p  with s_b = num_b / (den_b + eps), in place"""
+    B = p.shape[0]
+    check(_l().dinv_cg_update(1, B, p.numel() // B, ptr(num), ptr(den), float(eps), ptr(p), None, ptr(r), None,
+                              stream_ptr(p.device)))

@@ -24,6 +24,8 @@ def conjugate_gradient(A: Callable, b, max_iter=1e2, tol=1e-5, eps=1e-8, paralle
         parallel_dim = [parallel_dim]
     if parallel_dim is None:
         parallel_dim = []
+    if list(parallel_dim) == [0] and b.ndim > 1 and _hip_cg_ok(b, init):
+        return _conjugate_gradient_hip(A, b, max_iter, tol, eps, init, verbose)
     dim = [i for i in range(b.ndim) if i not in parallel_dim]
     x = torch.zeros_like(b) if init is None else init
     r = b - A(x)
@@ -47,6 +49,47 @@ def conjugate_gradient(A: Callable, b, max_iter=1e2, tol=1e-5, eps=1e-8, paralle
         if i > 0 and i % 100 == 0:
             r = b - A(x)
             res_old = dot(r, r, dim=dim).real
+    else:
+        if verbose:
+            print("CG did not converge")
+    return x
+
+
+def _hip_cg_ok(b, init):
+    from ..hip import elementwise as ew
+
+    n = b.numel() // max(b.shape[0], 1)
+    return b.is_cuda and n % 4 == 0 and ew.eligible(b, init) and not torch.is_grad_enabled()
+
+
+def _conjugate_gradient_hip(A, b, max_iter, tol, eps, init, verbose):
+    """Same recurrence as above (conjugate_gradient.py:48-75) with the vector algebra in csrc/elementwise.hip:
+    per-sample scalars stay on the device, dot products are deterministic shuffle reductions.  The convergence
+    test is still one host sync per iteration, as in the reference."""
+    from ..hip import elementwise as ew
+
+    b = b.contiguous()
+    x = torch.zeros_like(b) if init is None else init.contiguous().clone()
+    r = ew.lincomb(1.0, b, -1.0, A(x).contiguous())
+    p = r.clone()
+    res_old = ew.batched_dot(r, r)
+    b_norm_sq = ew.batched_dot(b, b)
+    b_norm_sq = torch.where(b_norm_sq > 0, b_norm_sq, torch.ones_like(b_norm_sq))
+    tol2 = b_norm_sq * (tol ** 2)
+    for i in range(int(max_iter)):
+        Ap = A(p).contiguous()
+        pAp = ew.batched_dot(p, Ap)
+        ew.cg_update_xr(res_old, pAp, eps, x, r, p, Ap)          # x += alpha p ; r -= alpha Ap
+        res_new = ew.batched_dot(r, r)
+        if torch.all(res_new < tol2):
+            if verbose:
+                print("CG Converged at iteration", i + 1)
+            break
+        ew.cg_update_p(res_new, res_old, eps, p, r)               # p = r + beta p
+        res_old = res_new
+        if i > 0 and i % 100 == 0:
+            r = ew.lincomb(1.0, b, -1.0, A(x).contiguous())
+            res_old = ew.batched_dot(r, r)
     else:
         if verbose:
             print("CG did not converge")

@@ -1,6 +1,7 @@
 """One splitting step (reference deepinv/optim/optim_iterators/{optim_iterator,pgd,hqs}.py)."""
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 
@@ -30,6 +31,14 @@ class OptimIterator(nn.Module):
         self.g_step = gStep(g_first=g_first)
 
     def relaxation_step(self, u, v, beta, *args, **kwargs):
+        """beta*u + (1-beta)*v (optim_iterator.py:76-87); a no-op for the default beta = 1, one fused pass otherwise"""
+        if isinstance(beta, (int, float)) and isinstance(u, torch.Tensor) and u.is_cuda and not torch.is_grad_enabled():
+            if float(beta) == 1.0:
+                return u
+            from ..hip import elementwise as ew
+
+            if ew.eligible(u, v) and u.shape == v.shape:
+                return ew.lincomb(float(beta), u, 1.0 - float(beta), v)
         return beta * u + (1 - beta) * v
 
     def forward(self, X, cur_data_fidelity, cur_prior, cur_params, y, physics, *args, **kwargs):
@@ -52,10 +61,36 @@ def objective_function(x, data_fidelity, prior, cur_params, y, physics):
     return data_fidelity(x, y, physics) + cur_params["lambda"] * prior(x, cur_params["g_param"])
 
 
+def _fused_l2_gradient_step(x, data_fidelity, stepsize, y, physics):
+    """x - gamma/sigma^2 * (A^T A x - A^T y) as ONE pass over the image (hand-written kernel) when the fidelity is
+    L2, the physics linear, the operands live on the HIP device and no autograd graph is recorded; same arithmetic
+    as fStepPGD + L2.grad (pgd.py:137-139, data_fidelity.py:335-338), including the per-iteration A^T y."""
+    from ..physics.forward import LinearPhysics
+    from .data_fidelity import L2
+
+    if type(data_fidelity) is not L2 or not isinstance(physics, LinearPhysics) or not isinstance(x, torch.Tensor):
+        return None
+    if not x.is_cuda or isinstance(stepsize, torch.Tensor):
+        return None
+    from ..hip import elementwise as ew
+
+    if not ew.eligible(x) or torch.is_grad_enabled():
+        return None
+    AtAx = physics.A_adjoint_A(x)
+    Aty = physics.A_adjoint(y)
+    if not (ew.eligible(AtAx, Aty) and AtAx.shape == x.shape == Aty.shape):
+        return x - stepsize * data_fidelity.norm * (AtAx - Aty)
+    g = float(stepsize) * float(data_fidelity.norm)
+    return ew.lincomb(1.0, x, -g, AtAx, g, Aty)
+
+
 # ------------------------------------------------------------------ PGD (pgd.py:12-176)
 class fStepPGD(fStep):
     def forward(self, x, cur_data_fidelity, cur_params, y, physics):
         if not self.g_first:
+            fused = _fused_l2_gradient_step(x, cur_data_fidelity, cur_params["stepsize"], y, physics)
+            if fused is not None:
+                return fused
             return x - cur_params["stepsize"] * cur_data_fidelity.grad(x, y, physics)
         return cur_data_fidelity.prox(x, y, physics, gamma=cur_params["stepsize"])
 

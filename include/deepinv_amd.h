@@ -204,6 +204,24 @@ int dinv_irfft2(const float* in, float* out, int64_t P, const dinv_fft_plan* pla
                 const dinv_fft_plan* plan_w, const void* table_w, float scale, void* ws, size_t ws_bytes,
                 dinv_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Loop algebra of the iteration drivers                                       */
+/* (fStepPGD + L2.grad: optim_iterators/pgd.py:137-139, data_fidelity.py:335-338; */
+/*  conjugate_gradient: optim/linear/conjugate_gradient.py:48-75, utils.py:6-26) */
+/* ------------------------------------------------------------------------- */
+/* out = a*x + b*y + c*z  (y, z may be null); n floats, 16-byte aligned */
+int dinv_lincomb(int64_t n, float a, const float* x, float b, const float* y, float c, const float* z,
+                 float* out, dinv_stream_t stream);
+/* out[b] = <x[b,:], y[b,:]> for b < batch (n floats per sample, n % 4 == 0); deterministic two-stage reduction.
+ * `partial` is caller scratch of batch * dinv_batched_dot_blocks(n) floats. */
+int32_t dinv_batched_dot_blocks(int64_t n);
+int dinv_batched_dot(int32_t batch, int64_t n, const float* x, const float* y, float* out, float* partial,
+                     dinv_stream_t stream);
+/* CG vector updates with per-sample scalars s_b = num[b] / (den[b] + eps) kept on the device:
+ *   mode 0: v0 (x) += s_b * w0 (p) ; v1 (r) -= s_b * w1 (Ap)        mode 1: v0 (p) = w0 (r) + s_b * v0 (p) */
+int dinv_cg_update(int32_t mode, int32_t batch, int64_t n, const float* num, const float* den, float eps,
+                   float* v0, float* v1, const float* w0, const float* w1, dinv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
