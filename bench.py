@@ -155,7 +155,7 @@ def main():
                          "launches": conv_n, "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4)},
             "operators": ops,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
             res["cpu_baseline"] = cpu_baseline(denoiser, maps, mask, H, W, args.coils, args.iters)
         print(json.dumps(res))
     if world > 1:

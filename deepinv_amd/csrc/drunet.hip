@@ -409,22 +409,23 @@ extern "C" int dinv_act_geom_init(int32_t batch, int32_t height, int32_t width, 
 }
 
 extern "C" int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float* x2, const float* w_packed,
-                            int32_t cin, int32_t cout, int32_t cout_valid, float* y, const float* res1,
-                            const float* res2, int32_t relu, dinv_stream_t stream) {
+                            int32_t cin, int32_t cout, int32_t cout_valid, int32_t cout_tile, float* y,
+                            const float* res1, const float* res2, int32_t relu, dinv_stream_t stream) {
     if (int e = check_geom(g)) return e;
     DINV_REQUIRE(x && w_packed && y, "null tensor pointer");
     DINV_REQUIRE(cin % KC == 0 && cin >= KC, "cin=%d must be a positive multiple of %d (pad with zero channels)", cin, KC);
     DINV_REQUIRE(cout % 32 == 0 && cout_valid >= 1 && cout_valid <= cout, "bad cout=%d/valid=%d", cout, cout_valid);
+    DINV_REQUIRE((cout_tile == 32 || cout_tile == 64) && cout % cout_tile == 0, "cout_tile=%d must be 32 or 64 and divide cout=%d", cout_tile, cout);
     const int cbv = (cout_valid + 7) / 8;  // channel blocks that exist in the output buffer
     const int ntiles = (int)ceil_div(g->np, NT);
     const int tpx = (ntiles + 7) / 8;
-    const int ytiles = cout % 64 == 0 ? cout / 64 : cout / 32;
+    const int ytiles = cout / cout_tile;
     Conv3Args a{make_geom(*g), x, x2, w_packed, y, res1, res2, cin, cbv, relu, ntiles, ytiles, tpx};
     const unsigned gx = (unsigned)(8 * tpx * ytiles);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nres = (res1 ? 1 : 0) + (res2 ? 1 : 0);
     DINV_REQUIRE(res1 || !res2, "res2 given without res1");
-    if (cout % 64 == 0) {
+    if (cout_tile == 64) {
         const dim3 grid(gx);
 #define DINV_LAUNCH_C3(RELU, NRES) hipLaunchKernelGGL((conv3x3_kernel<2, RELU, NRES>), grid, dim3(256), 0, s, a)
         if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }

@@ -28,7 +28,7 @@ def _l():
         l.dinv_act_geom_init.argtypes = [i32, i32, i32, G]
         l.dinv_act_pack.argtypes = [G, vp, i32, vp, i32, f32, vp, vp]
         l.dinv_act_unpack.argtypes = [G, vp, i32, vp, vp]
-        l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
+        l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
         _declared = True
@@ -46,12 +46,13 @@ def alloc(g: ActGeom, channels: int, device) -> torch.Tensor:
     return torch.zeros(((channels + 7) // 8, g.cs, 8), device=device, dtype=torch.float32)
 
 
-def pack_conv3x3_weight(w: torch.Tensor) -> tuple[torch.Tensor, int, int]:
+def pack_conv3x3_weight(w: torch.Tensor, mt: int | None = None) -> tuple[torch.Tensor, int, int]:
     """OIHW [Cout,Cin,3,3] -> [Cout/MT][Cin/8][9 taps][MT][8] (zero padded). Returns (packed, cin_p, cout_p)."""
     cout, cin = w.shape[:2]
     cin_p = (cin + 7) // 8 * 8
     cout_p = (cout + 31) // 32 * 32
-    mt = 64 if cout_p % 64 == 0 else 32
+    if mt is None:
+        mt = 64 if cout_p % 64 == 0 else 32
     wp = torch.zeros((cout_p, cin_p, 3, 3), device=w.device, dtype=torch.float32)
     wp[:cout, :cin] = w.detach().float()
     wp = wp.reshape(cout_p // mt, mt, cin_p // 8, 8, 9).permute(0, 2, 4, 1, 3).contiguous()
@@ -111,6 +112,7 @@ def profile_end():
 
 
 def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False, cin_valid=None):
+    """wpk: packed weight tensor [cout/MT][cin/8][9][MT][8]; MT is read off its shape"""
     if _prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -125,7 +127,7 @@ def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=N
 
 def _conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False):
     check(_l().dinv_conv3x3(ctypes.byref(g), ptr(x), ptr(x2), ptr(wpk), cin, cout, cout if cout_valid is None else cout_valid,
-                            ptr(y), ptr(res1), ptr(res2), int(relu), stream_ptr(y.device)))
+                            int(wpk.shape[3]), ptr(y), ptr(res1), ptr(res2), int(relu), stream_ptr(y.device)))
 
 
 def down2x2(gi, go, x, w, cin, cout, y):

@@ -12,6 +12,7 @@ so reference ``state_dict``s / ``.pth`` checkpoints load unchanged.
 """
 from __future__ import annotations
 
+import os
 from itertools import chain
 
 import numpy as np
@@ -169,7 +170,11 @@ class DRUNet(Denoiser):
         e = {"ver": ver, "device": device, "ws": {}}
 
         def c3(m):
-            return K.pack_conv3x3_weight(m.weight.to(device))
+            # both cout-tile widths are kept; _pick() chooses per launch geometry
+            w = m.weight.to(device)
+            p64 = K.pack_conv3x3_weight(w)
+            p32 = K.pack_conv3x3_weight(w, mt=32) if p64[0].shape[3] == 64 else p64
+            return (p64, p32)
 
         e["head"] = c3(self.m_head)
         e["tail"] = c3(self.m_tail)
@@ -192,7 +197,7 @@ class DRUNet(Denoiser):
             e["ws"].clear()  # one geometry at a time keeps the footprint bounded
             nc = self.nc
             g = [K.geom(B, H >> i, W >> i) for i in range(4)]
-            cin_p = e["head"][1]
+            cin_p = e["head"][0][1]
             ws = {"g": g, "in": K.alloc(g[0], cin_p, device), "out": K.alloc(g[0], self.out_channels, device)}
             for i in range(4):
                 # skip tensor x_{i+1}, two ping-pong buffers and the ResBlock temporary
@@ -201,11 +206,25 @@ class DRUNet(Denoiser):
             e["ws"][key] = ws
         return ws
 
+    @staticmethod
+    def _pick(g, packs):
+        """64-wide cout tiles unless that grid would leave the chip under-filled (< 3 rounds of the 512 resident
+        workgroup slots): then 32-wide tiles double the number of workgroups (small per-GPU batches)."""
+        p64, p32 = packs
+        if p64[0].shape[3] == 64:
+            n64 = ((g.np + 255) // 256) * (p64[2] // 64)
+            if n64 < 1536 and os.environ.get("DINV_CONV_TILE", "") != "64":
+                return p32
+            if os.environ.get("DINV_CONV_TILE", "") == "32":
+                return p32
+        return p64
+
     def _res_chain(self, g, blocks, c, x, a, b, t, last_extra=None):
         """run ResBlocks: returns the buffer holding the result (never `x` itself is overwritten)"""
         cur = x
         bufs = [a, b]
-        for i, ((w1, ci, co), (w2, _, _)) in enumerate(blocks):
+        for i, (pk1, pk2) in enumerate(blocks):
+            (w1, ci, co), (w2, _, _) = self._pick(g, pk1), self._pick(g, pk2)
             K.conv3x3(g, cur, w1, ci, co, t, relu=True)
             dst = bufs[i % 2]
             extra = last_extra if i == len(blocks) - 1 else None
@@ -223,7 +242,7 @@ class DRUNet(Denoiser):
         nc = self.nc
         x = x.contiguous().float()
         K.pack_input(g[0], x, sigma_map, ws["in"])
-        (wh, cih, coh) = e["head"]
+        (wh, cih, coh) = self._pick(g[0], e["head"])
         K.conv3x3(g[0], ws["in"], wh, cih, coh, ws["skip0"], cin_valid=self.in_channels + 1)  # x1
         cur = ws["skip0"]
         downs = ("m_down1", "m_down2", "m_down3")
@@ -238,7 +257,7 @@ class DRUNet(Denoiser):
             # t{i} holds the up-conv output; run the ResBlocks with a/b ping-pong and a fresh temporary
             r = self._res_chain_from_t(g[i], e[name], ws[f"t{i}"], ws[f"a{i}"], ws[f"b{i}"])
             skip_add = ws[f"skip{i}"]
-        (wt, cit, cot) = e["tail"]
+        (wt, cit, cot) = self._pick(g[0], e["tail"])
         K.conv3x3(g[0], r, wt, cit, cot, ws["out"], cout_valid=self.out_channels, x2=ws["skip0"])  # m_tail(x + x1)
         y = torch.empty((B, self.out_channels, H, W), device=dev, dtype=torch.float32)
         K.unpack_output(g[0], ws["out"], self.out_channels, y)
@@ -247,7 +266,8 @@ class DRUNet(Denoiser):
     def _res_chain_from_t(self, g, blocks, t_in, a, b):
         """ResBlocks whose input lives in the `t` buffer: rotate roles so nothing is clobbered."""
         cur, tmp, other = t_in, a, b
-        for ((w1, ci, co), (w2, _, _)) in blocks:
+        for (pk1, pk2) in blocks:
+            (w1, ci, co), (w2, _, _) = self._pick(g, pk1), self._pick(g, pk2)
             K.conv3x3(g, cur, w1, ci, co, tmp, relu=True)
             K.conv3x3(g, tmp, w2, ci, co, other, res1=cur)
             cur, other = other, cur

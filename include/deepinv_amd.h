@@ -128,10 +128,11 @@ int dinv_act_unpack(const dinv_act_geom* g, const float* act, int32_t cout, floa
 
 /* y = [relu]( conv3x3(x (+x2)) ) (+res1) (+res2), stride 1, zero padding 1, no bias
  * (nn.Conv2d in drunet.py `conv(... mode="C")`, ResBlock :403-434).
- * w_packed: [cout/MT][cin/8][9 taps][MT][8], MT = 64 if cout % 64 == 0 else 32; cin % 8 == 0
- * (zero-pad), cout % 32 == 0 (zero-pad); only the first ceil(cout_valid/8) output channel blocks are written. */
+ * w_packed: [cout/MT][cin/8][9 taps][MT][8], MT = cout_tile in {32, 64} (64: fewer, fatter workgroups; 32:
+ * twice as many workgroups, used when the 64-wide grid would not fill the chip); cin % 8 == 0 (zero-pad),
+ * cout % MT == 0 (zero-pad); only the first ceil(cout_valid/8) output channel blocks are written. */
 int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float* x2, const float* w_packed,
-                 int32_t cin, int32_t cout, int32_t cout_valid, float* y, const float* res1,
+                 int32_t cin, int32_t cout, int32_t cout_valid, int32_t cout_tile, float* y, const float* res1,
                  const float* res2, int32_t relu, dinv_stream_t stream);
 /* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin/8][cout][8] */
 int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
