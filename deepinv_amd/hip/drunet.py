@@ -29,6 +29,7 @@ def _l():
         l.dinv_act_pack.argtypes = [G, vp, i32, vp, i32, f32, vp, vp]
         l.dinv_act_unpack.argtypes = [G, vp, i32, vp, vp]
         l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+        l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
         _declared = True
@@ -57,6 +58,17 @@ def pack_conv3x3_weight(w: torch.Tensor, mt: int | None = None) -> tuple[torch.T
     wp[:cout, :cin] = w.detach().float()
     wp = wp.reshape(cout_p // mt, mt, cin_p // 8, 8, 9).permute(0, 2, 4, 1, 3).contiguous()
     return wp, cin_p, cout_p
+
+
+def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> U = G g G^T (fp64, rounded once) packed [Cout/64][Cin/8][ci 8][co 64][16];
+    needs Cin % 8 == 0 and Cout % 64 == 0 (the ResBlock convs)."""
+    cout, cin = w.shape[:2]
+    if cin % 8 or cout % 64:
+        raise ValueError(f"winograd packing needs cin % 8 == 0 and cout % 64 == 0, got {cin},{cout}")
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
+    u = (G @ w.detach().double() @ G.t()).float().reshape(cout // 64, 64, cin // 8, 8, 16)
+    return u.permute(0, 2, 3, 1, 4).contiguous()
 
 
 def pack_down_weight(w: torch.Tensor) -> torch.Tensor:
@@ -128,6 +140,18 @@ def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=N
 def _conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False):
     check(_l().dinv_conv3x3(ctypes.byref(g), ptr(x), ptr(x2), ptr(wpk), cin, cout, cout if cout_valid is None else cout_valid,
                             int(wpk.shape[3]), ptr(y), ptr(res1), ptr(res2), int(relu), stream_ptr(y.device)))
+
+
+def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):
+    """y = [relu](conv3x3(x)) (+res1) via Winograd F(2x2,3x3); wino from pack_winograd_weight"""
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_l().dinv_conv3x3_winograd(ctypes.byref(g), ptr(x), ptr(wino), cin, cout, ptr(y), ptr(res1), int(relu),
+                                     stream_ptr(y.device)))
+    if _prof is not None:
+        e1.record()
+        _prof.append((e0, e1, 2.0 * 9 * cin * cout * g.batch * g.height * g.width))
 
 
 def down2x2(gi, go, x, w, cin, cout, y):

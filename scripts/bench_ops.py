@@ -70,6 +70,25 @@ def bench_drunet(B, cin, H, W, gflop_per_img):
                       "frac_fp32_mfma_peak": tf / 157.3}))
 
 
+def bench_conv_levels(B):
+    """direct vs Winograd ResBlock conv at the four DRUNet levels"""
+    from deepinv_amd.hip import drunet as K
+    dev = torch.device("cuda:0")
+    for lvl, c in enumerate((64, 128, 256, 512)):
+        H = 320 >> lvl
+        g = K.geom(B, H, H)
+        x, y = K.alloc(g, c, dev), K.alloc(g, c, dev)
+        x.normal_()
+        w = torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5)
+        wd, ci, co = K.pack_conv3x3_weight(w)
+        ww = K.pack_winograd_weight(w)
+        fl = 2.0 * 9 * c * c * B * H * H
+        td = timeit(lambda: K.conv3x3(g, x, wd, ci, co, y, relu=True), iters=20, warmup=3)
+        tw = timeit(lambda: K.conv3x3_winograd(g, x, ww, c, c, y, relu=True), iters=20, warmup=3)
+        print(json.dumps({"op": "conv3x3", "B": B, "hw": H, "c": c, "direct_ms": td * 1e3, "wino_ms": tw * 1e3,
+                          "direct_TF": fl / td / 1e12, "wino_effTF": fl / tw / 1e12}))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["mri2d", "mri3d"]
     if "mri2d" in which:
@@ -80,5 +99,8 @@ if __name__ == "__main__":
         bench_radon(8, 512, 720)
     if "drunet" in which:
         bench_drunet(32, 2, 320, 320, 433.4)
+    if "convlv" in which:
+        bench_conv_levels(32)
+        bench_conv_levels(4)
     if "drunet4" in which:
         bench_drunet(4, 2, 320, 320, 433.4)

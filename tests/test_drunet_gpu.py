@@ -51,3 +51,63 @@ def test_drunet_unsafe_shapes(dev):
         z = model(torch.rand(1, 1, 70, 100, device=dev), 0.1)   # test_onesplit branch
     assert y.shape == (1, 1, 37, 41) and z.shape == (1, 1, 70, 100)
     assert torch.isfinite(y).all() and torch.isfinite(z).all()
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 64, 64, 64, 64), (3, 40, 40, 128, 128), (1, 80, 80, 64, 128),
+                                              (2, 20, 20, 512, 512), (1, 37, 51, 64, 64), (5, 10, 10, 64, 64),
+                                              (1, 320, 320, 64, 64)])
+@pytest.mark.parametrize("mode", ["plain", "relu", "res"])
+def test_winograd_conv_matches_fp32_conv(dev, B, H, W, cin, cout, mode):
+    """Winograd F(2x2,3x3) ResBlock convolution against torch's fp32 conv2d of the same op (tolerance 1e-5:
+    the transforms only add a few fp32 roundings) and against the direct MFMA kernel."""
+    from deepinv_amd.hip import drunet as K
+
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)).to(dev)
+    r = torch.randn(B, cout, H, W, generator=g).to(dev)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+
+    geo = K.geom(B, H, W)
+
+    def to_act(t):
+        a = K.alloc(geo, t.shape[1], dev)
+        av = a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+        av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    def from_act(a, c):
+        av = a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+        return av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, c, H, W)
+
+    xa, ra = to_act(x), to_act(r)
+    ya, yd = K.alloc(geo, cout, dev), K.alloc(geo, cout, dev)
+    K.conv3x3_winograd(geo, xa, K.pack_winograd_weight(w), cin, cout, ya, res1=ra if mode == "res" else None,
+                       relu=mode == "relu")
+    wd, ci, co = K.pack_conv3x3_weight(w)
+    K.conv3x3(geo, xa, wd, ci, co, yd, res1=ra if mode == "res" else None, relu=mode == "relu")
+    out, direct = from_act(ya, cout), from_act(yd, cout)
+    assert rel_err(out, ref) < 1e-5
+    assert rel_err(out, direct) < 1e-5
+    # the zero border of the padded frame must stay zero (the next layer reads it as padding)
+    full = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+    assert full[:, :, 0].abs().max() == 0 and full[:, :, H + 1:].abs().max() == 0
+    assert full[:, :, :, 0].abs().max() == 0 and full[:, :, :, W + 1:].abs().max() == 0
+
+
+def test_drunet_winograd_matches_oracle(dev, monkeypatch):
+    import deepinv_amd as dinv
+
+    monkeypatch.setenv("DINV_WINOGRAD", "1")
+    sd = OD.init_state_dict(2, 2, seed=1)
+    model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
+    model.load_state_dict(sd)
+    model.eval()
+    x = torch.rand(2, 2, 64, 96, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        out = model(x.to(dev), 0.05)
+    assert rel_err(out, OD.drunet(sd, x, 0.05)) < 1e-4
