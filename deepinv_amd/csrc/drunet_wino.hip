@@ -6,17 +6,25 @@
 //
 //   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A          d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
 //
+// Measured facts that shape the kernel (scripts/ubench/mfma_coissue.hip): the fp32 MFMA shares the vector ALU,
+// so every VALU instruction a wave issues costs MFMA time (4.5 cycles with one wave per SIMD, 2.2 with two;
+// LDS reads are free).  The design therefore minimises VALU instructions per MFMA and runs two waves per SIMD:
+//
 // * U = G g G^T is precomputed on the host (fp64 -> fp32), packed [cout/64][cin/8][ci 8][co 64][xi 16].
-// * Workgroup = 4 waves = 64 couts x 64 tile positions; wave (wc, wq) owns 32 couts x 32 positions x all 16
-//   Winograd points xi: 16 MFMA accumulators (256 AGPRs), one wave per SIMD, one workgroup per CU.
+// * Workgroup = 8 waves = 64 couts x 64 tile positions x 16 Winograd points.  Wave (xr, wq) owns Winograd ROW
+//   xr (4 points) for all 64 couts and 32 positions: 8 accumulators (128 AGPRs), two waves per SIMD.  Row xr
+//   of V = B^T d B needs only two rows of the patch: 8 ds_read_b128 + 16 FMAs + 16 adds feed 32 MFMAs per
+//   8-channel block (1 VALU per MFMA; the all-points-per-wave layout needs 4).
 // * Per 8-channel block the raw input region (zero border included, so no edge cases) and the 32 KB slice of U
-//   are staged in LDS (double buffered, one barrier per block, next block prefetched into registers during
-//   the MFMAs).  Each lane builds V = B^T d B for its own position and its 4 channels (4h..4h+3, h = lane>>5
-//   = MFMA k index) from 16 ds_read_b128 and 128 adds, and feeds 64 MFMAs with it.
+//   are staged in LDS, double buffered, one barrier per block; the staging registers always hold loads issued
+//   a full block earlier, invalid pixels are redirected to a zero border pixel (no selects).
 // * The 64 positions of a workgroup are NSUB rectangles of TH x TW tiles enumerated over (batch, tile rows,
 //   tile cols), so the 40x40 and 80x80 levels fill the MFMA columns as well as 320x320 does.
-// * Epilogue: per-lane A^T M A, fused ReLU / residual add, float4 stores of interior pixels only.
+// * Epilogue: each wave reduces its row to s = M A (2 values), the four row-waves exchange s through LDS and
+//   wave xr finishes A^T s for channel sub-block xr: fused ReLU / residual add, float4 stores of interior
+//   pixels only.
 #include "drunet_common.hpp"
+#include <type_traits>
 
 using namespace dinv;
 using namespace dinv_drunet;
@@ -26,6 +34,8 @@ namespace {
 constexpr int WP = 20;                 // LDS pitch of one (ci, co) row of U: 16 xi + 4 pad (conflict-free b128)
 constexpr int WLDS = 8 * 64 * WP;      // floats of U per channel block in LDS
 constexpr int RP = 12;                 // LDS pitch of one staged pixel: 8 channels + 4 pad
+constexpr int NTHR = 512;
+constexpr int EXCH = 8 * 4 * 2 * 2 * 256;   // floats of the epilogue exchange buffer (128 KB)
 
 struct WinoArgs {
     Geom g;
@@ -45,19 +55,20 @@ struct Shape {
     static constexpr int RW2 = TW + 1;             // staged columns per parity
     static constexpr int RAWF = NSUB * RH * 2 * RW2 * RP;
     static constexpr int RAW4 = NSUB * RH * 2 * RW2 * 2;   // float4 loads to stage one block
-    static constexpr int NLD = (RAW4 + 255) / 256;
+    static constexpr int NLD = (RAW4 + NTHR - 1) / NTHR;
     static constexpr int BUF = WLDS + RAWF;        // floats per LDS buffer
+    static constexpr int LDSF = 2 * BUF > EXCH ? 2 * BUF : EXCH;
     static_assert(PT <= 64 && 64 % PT == 0, "rectangle must divide the 64 positions");
 };
 
 template <int TH, int TW, bool RELU, int NRES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_wino_kernel(WinoArgs a) {
     using S = Shape<TH, TW>;
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int wc = wave & 1, wq = wave >> 1;
+    const int xr = wave & 3, wq = wave >> 2;
 
     // consecutive block ids land on different XCDs: give each XCD a contiguous range of the logical order so
     // the cout tiles of one position tile (and neighbouring position tiles) share an L2
@@ -68,13 +79,12 @@ void conv3x3_wino_kernel(WinoArgs a) {
     const int64_t pw = logical / a.nct;
     const int64_t per_img = (int64_t)a.nty * a.ntx;
 
-    // ---- staging descriptors (independent of the channel block)
-    int64_t goff[S::NLD];
+    // ---- staging descriptors (independent of the channel block); offsets are relative to the channel block
+    uint32_t goff[S::NLD];
     int loff[S::NLD];
-    bool gok[S::NLD];
 #pragma unroll
     for (int i = 0; i < S::NLD; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + NTHR * i;
         const int half = e & 1, px = e >> 1;
         const int c = px % (2 * S::RW2);
         const int r = (px / (2 * S::RW2)) % S::RH;
@@ -84,94 +94,166 @@ void conv3x3_wino_kernel(WinoArgs a) {
         const int rem = (int)(s - b * per_img);
         const int tyb = rem / a.ntx, txb = rem - tyb * a.ntx;
         const int gr = 2 * tyb * TH + r, gc = 2 * txb * TW + c;
-        gok[i] = e < S::RAW4 && s < a.nsr && gr < a.g.hp && gc < a.g.wp;
-        goff[i] = (a.g.sl + b * a.g.plane + (int64_t)gr * a.g.wp + gc) * 8 + half * 4;
+        const bool ok = e < S::RAW4 && s < a.nsr && gr < a.g.hp && gc < a.g.wp;
+        // out-of-frame pixels read the (always zero) top-left border pixel of image 0 instead
+        goff[i] = ok ? (uint32_t)((a.g.sl + b * a.g.plane + (int64_t)gr * a.g.wp + gc) * 8 + half * 4)
+                     : (uint32_t)(a.g.sl * 8);
         loff[i] = WLDS + (((sub * S::RH + r) * 2 + (c & 1)) * S::RW2 + (c >> 1)) * RP + half * 4;
     }
     const float* wsrc = a.w + (int64_t)ct * a.ncb * 8192 + tid * 4;
     const int64_t xcs = a.g.cs * 8;
-
-    float4 pr[S::NLD], pwt[8];
-    auto fetch = [&](int cb) {
-        const float* xb = a.x + cb * xcs;
-#pragma unroll
-        for (int i = 0; i < S::NLD; ++i) pr[i] = gok[i] ? ld4(xb + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* wb = wsrc + (int64_t)cb * 8192;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pwt[i] = ld4(wb + i * 1024);
-    };
-    auto stash = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < S::NLD; ++i)
-            if (S::RAW4 % 256 == 0 || i + 1 < S::NLD || tid + 256 * i < S::RAW4) st4(buf + loff[i], pr[i]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = tid + 256 * i;          // float4 index: (ci*64 + co)*4 + q
-            st4(buf + (f >> 2) * WP + (f & 3) * 4, pwt[i]);
-        }
-    };
+    const int woff = (tid >> 2) * WP + (tid & 3) * 4;   // LDS offset of weight float4 #tid (+ i*128*WP for #tid+512i)
 
     // ---- this lane's operand addresses
     const int p = wq * 32 + l31;
     const int sub = p / S::PT, ty = (p % S::PT) / TW, tx = p % TW;
+    // row xr of B^T d:  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3   ->   t = d[ra] + sigma * d[rb]
+    const int ra = xr == 0 ? 0 : xr == 2 ? 2 : 1;
+    const int rb = xr == 2 ? 1 : xr == 3 ? 3 : 2;
+    const float sigma = xr == 1 ? 1.f : -1.f;
     const int rbase = WLDS + ((sub * S::RH + 2 * ty) * 2 * S::RW2 + tx) * RP + 4 * h;
-    const int abase = ((4 * h) * 64 + wc * 32 + l31) * WP;
+    const int rA = rbase + ra * 2 * S::RW2 * RP, rB = rbase + rb * 2 * S::RW2 * RP;
+    const int abase = ((4 * h) * 64 + l31) * WP + 4 * xr;
 
-    f32x16 acc[16];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c2][j][r] = 0.f;
 
-    fetch(0);
-    stash(lds);
-    __syncthreads();
+    float4 pr[S::NLD], pwt[4];
+    float4 uA[2], uB[2], uC[2];
+    float vA[4], vB[4];
+    float tc[4][4];   // row xr of B^T d for the current block: [channel m][col j]
 
-    for (int cb = 0; cb < a.ncb; ++cb) {
-        const float* buf = lds + (cb & 1) * S::BUF;
-        const bool more = cb + 1 < a.ncb;
-        if (more) fetch(cb + 1);
+#define DINV_MFMA8(U, V)                                                                                         \
+    _Pragma("unroll") for (int c2_ = 0; c2_ < 2; ++c2_)                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                             \
+        acc[c2_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(U[c2_], j_), V[j_], acc[c2_][j_], 0, 0, 0)
+#define DINV_VCALC(V, T)                                                                                         \
+    do { V[0] = T[0] - T[2]; V[1] = T[1] + T[2]; V[2] = T[2] - T[1]; V[3] = T[1] - T[3]; } while (0)
+#define DINV_COL(j) ((((j) & 1) * S::RW2 + ((j) >> 1)) * RP)
+#define DINV_UREAD(U, buf, m)                                                                                    \
+    do { U[0] = ld4((buf) + abase + (m) * 64 * WP); U[1] = ld4((buf) + abase + ((m) * 64 + 32) * WP); } while (0)
 
-        float4 d[16];
+    auto fetch_w = [&](int cb, int i) { pwt[i] = ld4(wsrc + (int64_t)cb * 8192 + i * 2048); };
+    auto fetch_r = [&](int cb, int i) { pr[i] = ld4(a.x + cb * xcs + goff[i]); };
+    auto stash_w = [&](float* buf, int i) { st4(buf + woff + i * 128 * WP, pwt[i]); };
+    auto stash_r = [&](float* buf, int i) {
+        if (S::RAW4 % NTHR == 0 || i + 1 < S::NLD || tid + NTHR * i < S::RAW4) st4(buf + loff[i], pr[i]);
+    };
+    auto tcalc = [&](const float* buf) {
+        float4 dA[4], dB[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { dA[j] = ld4(buf + rA + DINV_COL(j)); dB[j] = ld4(buf + rB + DINV_COL(j)); }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                d[i * 4 + j] = ld4(buf + rbase + ((i * 2 + (j & 1)) * S::RW2 + (j >> 1)) * RP);
-        // B^T d along rows, for the 4 channels at once
-        float4 t[16];
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
-            t[j] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-            t[4 + j] = add4(d1, d2);
-            t[8 + j] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-            t[12 + j] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
-        }
+            for (int j = 0; j < 4; ++j) tc[m][j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
+    };
+
+    // ---- prologue: block 0 to LDS, block 1 in flight, first operands in registers
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float4 u[4];
+    for (int i = 0; i < 4; ++i) fetch_w(0, i);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = ld4(buf + abase + m * 64 * WP + q * 4);
-            float v[16];
+    for (int i = 0; i < S::NLD; ++i) fetch_r(0, i);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float t0 = comp(t[4 * i], m), t1 = comp(t[4 * i + 1], m), t2 = comp(t[4 * i + 2], m),
-                            t3 = comp(t[4 * i + 3], m);
-                v[4 * i] = t0 - t2;
-                v[4 * i + 1] = t1 + t2;
-                v[4 * i + 2] = t2 - t1;
-                v[4 * i + 3] = t1 - t3;
-            }
+    for (int i = 0; i < 4; ++i) stash_w(lds, i);
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi)
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(u[xi >> 2], xi & 3), v[xi], acc[xi], 0, 0, 0);
-        }
-        if (more) stash(lds + ((cb + 1) & 1) * S::BUF);
-        __syncthreads();
+    for (int i = 0; i < S::NLD; ++i) stash_r(lds, i);
+    {
+        const int c1 = a.ncb > 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fetch_w(c1, i);
+#pragma unroll
+        for (int i = 0; i < S::NLD; ++i) fetch_r(c1, i);
     }
+    __syncthreads();
+    tcalc(lds);
+    DINV_UREAD(uA, lds, 0);
+    DINV_VCALC(vA, tc[0]);
 
-    // ---- epilogue: Y = A^T M A per (co, position); lane holds co = 8*rj + 4*h + (0..3) for rj = 0..3
+    // One 8-channel block = 4 steps (m = channel 4h+m) of 8 MFMAs.  Everything else rides one step ahead:
+    //   step 0: read U(m=1); V(m=1); write the staged weights of block cb+1 to LDS, re-issue the loads for cb+2
+    //   step 1: read U(m=2), U(m=3); V(m=2); same for the staged input pixels;   barrier
+    //   step 2: V(m=3); read the two patch rows of block cb+1
+    //   step 3: row xr of B^T d for block cb+1; read U(cb+1, m=0); V(cb+1, m=0)
+    auto block = [&](int cb, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const float* cur = lds + (cb & 1) * S::BUF;
+        float* nxt = lds + ((cb + 1) & 1) * S::BUF;
+        const int cb2 = cb + 2 < a.ncb ? cb + 2 : a.ncb - 1;   // re-issued loads past the end re-read the last block
+        float4 dA[4], dB[4];
+        // ---- step 0
+        DINV_MFMA8(uA, vA);
+        DINV_UREAD(uB, cur, 1);
+        DINV_VCALC(vB, tc[1]);
+        if (!LAST) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { stash_w(nxt, i); fetch_w(cb2, i); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 1
+        DINV_MFMA8(uB, vB);
+        DINV_UREAD(uA, cur, 2);
+        DINV_UREAD(uC, cur, 3);
+        DINV_VCALC(vA, tc[2]);
+        if (!LAST) {
+#pragma unroll
+            for (int i = 0; i < S::NLD; ++i) { stash_r(nxt, i); fetch_r(cb2, i); }
+            __syncthreads();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 2
+        DINV_MFMA8(uA, vA);
+        DINV_VCALC(vB, tc[3]);
+        if (!LAST) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dA[j] = ld4(nxt + rA + DINV_COL(j)); dB[j] = ld4(nxt + rB + DINV_COL(j)); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 3
+        DINV_MFMA8(uC, vB);
+        if (!LAST) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tc[m][j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
+            DINV_UREAD(uA, nxt, 0);
+            DINV_VCALC(vA, tc[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int cb = 0; cb + 1 < a.ncb; ++cb) block(cb, std::false_type{});
+    block(a.ncb - 1, std::true_type{});
+#undef DINV_MFMA8
+#undef DINV_VCALC
+#undef DINV_COL
+#undef DINV_UREAD
+
+    // ---- epilogue: s = M A for this wave's Winograd row, exchange, then A^T s for channel sub-block rj = xr
+    __syncthreads();   // the staging buffers are dead: reuse LDS as E[wq][src row][rj][c2][dx][lane][4]
+    float* ex = lds + wq * (4 * 4 * 2 * 2 * 256) + lane * 4;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int rj = 0; rj < 4; ++rj) {
+            float s0[4], s1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * rj + k;
+                const float m0 = acc[c2][0][r], m1 = acc[c2][1][r], m2 = acc[c2][2][r], m3 = acc[c2][3][r];
+                s0[k] = m0 + m1 + m2;
+                s1[k] = m1 - m2 - m3;
+            }
+            float* e = ex + (((xr * 4 + rj) * 2 + c2) * 2) * 256;
+            st4(e, make_float4(s0[0], s0[1], s0[2], s0[3]));
+            st4(e + 256, make_float4(s1[0], s1[1], s1[2], s1[3]));
+        }
+    __syncthreads();
     const int64_t s = pw * S::NSUB + sub;
     if (s >= a.nsr) return;
     const int64_t b = s / per_img;
@@ -182,32 +264,25 @@ void conv3x3_wino_kernel(WinoArgs a) {
     const bool okx = ox + 1 < a.g.w, oky = oy + 1 < a.g.h;
     const int64_t pix = a.g.sl + b * a.g.plane + (int64_t)(oy + 1) * a.g.wp + ox + 1;
 #pragma unroll
-    for (int rj = 0; rj < 4; ++rj) {
-        float o[4][4];  // [output pixel dy*2+dx][channel]
+    for (int c2 = 0; c2 < 2; ++c2) {
+        float4 o[4];   // [dy*2+dx], channels 4h..4h+3 of block ct*8 + c2*4 + xr
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = 4 * rj + k;
-            float sv[4][2];
+        for (int dx = 0; dx < 2; ++dx) {
+            float4 q[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float m0 = acc[4 * i][r], m1 = acc[4 * i + 1][r], m2 = acc[4 * i + 2][r], m3 = acc[4 * i + 3][r];
-                sv[i][0] = m0 + m1 + m2;
-                sv[i][1] = m1 - m2 - m3;
-            }
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                o[dx][k] = sv[0][dx] + sv[1][dx] + sv[2][dx];
-                o[2 + dx][k] = sv[1][dx] - sv[2][dx] - sv[3][dx];
-            }
+            for (int i = 0; i < 4; ++i) q[i] = ld4(ex + (((i * 4 + xr) * 2 + c2) * 2 + dx) * 256);
+            o[dx] = add4(add4(q[0], q[1]), q[2]);
+            o[2 + dx] = make_float4(q[1].x - q[2].x - q[3].x, q[1].y - q[2].y - q[3].y, q[1].z - q[2].z - q[3].z,
+                                    q[1].w - q[2].w - q[3].w);
         }
-        const int64_t cbo = (int64_t)ct * 8 + wc * 4 + rj;
+        const int64_t cbo = (int64_t)ct * 8 + c2 * 4 + xr;
         const int64_t base = (cbo * a.g.cs + pix) * 8 + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int dy = q >> 1, dx = q & 1;
             if ((dy && !oky) || (dx && !okx)) continue;
             const int64_t off = base + ((int64_t)dy * a.g.wp + dx) * 8;
-            float4 val = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+            float4 val = o[q];
             if (RELU) val = make_float4(fmaxf(val.x, 0.f), fmaxf(val.y, 0.f), fmaxf(val.z, 0.f), fmaxf(val.w, 0.f));
             if (NRES) val = add4(val, ld4(a.res + off));
             st4(a.y + off, val);
@@ -223,7 +298,7 @@ int launch_shape(WinoArgs a, int tiles_y, int tiles_x, hipStream_t st) {
     a.nsr = (int64_t)a.g.batch * a.nty * a.ntx;
     a.nwg = ceil_div(a.nsr, S::NSUB) * a.nct;
     a.per_xcd = ceil_div(a.nwg, 8);
-    const size_t shm = 2 * S::BUF * sizeof(float);
+    const size_t shm = S::LDSF * sizeof(float);
     static bool once = false;  // per instantiation
     auto kern = conv3x3_wino_kernel<TH, TW, RELU, NRES>;
     if (!once) {
@@ -231,7 +306,7 @@ int launch_shape(WinoArgs a, int tiles_y, int tiles_x, hipStream_t st) {
             return fail(3, "hipFuncSetAttribute(max dynamic LDS) failed");
         once = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.per_xcd * 8)), dim3(256), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.per_xcd * 8)), dim3(NTHR), shm, st, a);
     DINV_CHECK_LAUNCH();
     return 0;
 }
