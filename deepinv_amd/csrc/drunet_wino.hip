@@ -96,11 +96,11 @@ void conv3x3_wino_kernel(WinoArgs a) {
         const int gr = 2 * tyb * TH + r, gc = 2 * txb * TW + c;
         const bool ok = e < S::RAW4 && s < a.nsr && gr < a.g.hp && gc < a.g.wp;
         // out-of-frame pixels read the (always zero) top-left border pixel of image 0 instead
-        goff[i] = ok ? (uint32_t)((a.g.sl + b * a.g.plane + (int64_t)gr * a.g.wp + gc) * 8 + half * 4)
-                     : (uint32_t)(a.g.sl * 8);
+        goff[i] = 4u * (ok ? (uint32_t)((a.g.sl + b * a.g.plane + (int64_t)gr * a.g.wp + gc) * 8 + half * 4)
+                          : (uint32_t)(a.g.sl * 8));   // byte offset
         loff[i] = WLDS + (((sub * S::RH + r) * 2 + (c & 1)) * S::RW2 + (c >> 1)) * RP + half * 4;
     }
-    const float* wsrc = a.w + (int64_t)ct * a.ncb * 8192 + tid * 4;
+    const float* wsrc = a.w + (int64_t)ct * a.ncb * 8192;   // + tid*16 bytes per lane
     const int64_t xcs = a.g.cs * 8;
     const int woff = (tid >> 2) * WP + (tid & 3) * 4;   // LDS offset of weight float4 #tid (+ i*128*WP for #tid+512i)
 
@@ -138,8 +138,15 @@ void conv3x3_wino_kernel(WinoArgs a) {
 #define DINV_UREAD(U, buf, m)                                                                                    \
     do { U[0] = ld4((buf) + abase + (m) * 64 * WP); U[1] = ld4((buf) + abase + ((m) * 64 + 32) * WP); } while (0)
 
-    auto fetch_w = [&](int cb, int i) { pwt[i] = ld4(wsrc + (int64_t)cb * 8192 + i * 2048); };
-    auto fetch_r = [&](int cb, int i) { pr[i] = ld4(a.x + cb * xcs + goff[i]); };
+    // buffer loads: uniform base in an SGPR resource + 32-bit per-lane byte offset, so staging costs no address
+    // VALU (every VALU instruction is paid for in MFMA time); the per-lane offset stays below 4 GB by construction
+    auto ld4_so = [](const float* sbase, uint32_t byte_off) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, 0xffffffff, 0x00020000);
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
+    };
+    auto fetch_w = [&](int cb, int i) { pwt[i] = ld4_so(wsrc + (int64_t)cb * 8192 + i * 2048, (uint32_t)tid * 16u); };
+    auto fetch_r = [&](int cb, int i) { pr[i] = ld4_so(a.x + cb * xcs, goff[i]); };
     auto stash_w = [&](float* buf, int i) { st4(buf + woff + i * 128 * WP, pwt[i]); };
     auto stash_r = [&](float* buf, int i) {
         if (S::RAW4 % NTHR == 0 || i + 1 < S::NLD || tid + NTHR * i < S::RAW4) st4(buf + loff[i], pr[i]);
@@ -180,10 +187,11 @@ void conv3x3_wino_kernel(WinoArgs a) {
     //   step 1: read U(m=2), U(m=3); V(m=2); same for the staged input pixels;   barrier
     //   step 2: V(m=3); read the two patch rows of block cb+1
     //   step 3: row xr of B^T d for block cb+1; read U(cb+1, m=0); V(cb+1, m=0)
-    auto block = [&](int cb, auto last_tag) {
+    auto block = [&](int cb, auto parity_tag, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        const float* cur = lds + (cb & 1) * S::BUF;
-        float* nxt = lds + ((cb + 1) & 1) * S::BUF;
+        constexpr int PAR = decltype(parity_tag)::value;   // cb & 1, compile time: LDS addresses fold to immediates
+        const float* cur = lds + PAR * S::BUF;
+        float* nxt = lds + (1 - PAR) * S::BUF;
         const int cb2 = cb + 2 < a.ncb ? cb + 2 : a.ncb - 1;   // re-issued loads past the end re-read the last block
         float4 dA[4], dB[4];
         // ---- step 0
@@ -226,9 +234,18 @@ void conv3x3_wino_kernel(WinoArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    {
+        // two blocks per trip so the register state returns to the same names (no copies on the back edge) and
+        // the LDS buffer parity is a compile-time constant.  The last block also stages/reads a (clamped,
+        // unused) "next" block: one block of redundant fillers is cheaper than a second code path.
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
 #pragma unroll 1
-    for (int cb = 0; cb + 1 < a.ncb; ++cb) block(cb, std::false_type{});
-    block(a.ncb - 1, std::true_type{});
+        for (int cb = 0; cb < a.ncb; cb += 2) {
+            block(cb, P0{}, std::false_type{});
+            if (cb + 1 < a.ncb) block(cb + 1, P1{}, std::false_type{});
+        }
+    }
 #undef DINV_MFMA8
 #undef DINV_VCALC
 #undef DINV_COL
