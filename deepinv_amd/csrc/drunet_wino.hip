@@ -252,6 +252,27 @@ void conv3x3_wino_kernel(WinoArgs a) {
 #undef DINV_UREAD
 
     // ---- epilogue: s = M A for this wave's Winograd row, exchange, then A^T s for channel sub-block rj = xr
+    const int64_t s = pw * S::NSUB + sub;
+    const int64_t b = s / per_img;
+    const int rem = (int)(s - b * per_img);
+    const int tyb = rem / a.ntx, txb = rem - tyb * a.ntx;
+    const int oy = 2 * (tyb * TH + ty), ox = 2 * (txb * TW + tx);
+    const bool live = s < a.nsr && oy < a.g.h && ox < a.g.w;
+    const bool okx = ox + 1 < a.g.w, oky = oy + 1 < a.g.h;
+    const int64_t pix = a.g.sl + b * a.g.plane + (int64_t)(oy + 1) * a.g.wp + ox + 1;
+    int64_t ooff[2][4];
+    float4 rv[2][4];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+        const int64_t cbo = (int64_t)ct * 8 + c2 * 4 + xr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ooff[c2][q] = (cbo * a.g.cs + pix + (int64_t)(q >> 1) * a.g.wp + (q & 1)) * 8 + 4 * h;
+            // residual values are fetched now so that their latency hides behind the exchange
+            if (NRES) rv[c2][q] = (live && !((q >> 1) && !oky) && !((q & 1) && !okx)) ? ld4(a.res + ooff[c2][q])
+                                                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     __syncthreads();   // the staging buffers are dead: reuse LDS as E[wq][src row][rj][c2][dx][lane][4]
     float* ex = lds + wq * (4 * 4 * 2 * 2 * 256) + lane * 4;
 #pragma unroll
@@ -271,15 +292,7 @@ void conv3x3_wino_kernel(WinoArgs a) {
             st4(e + 256, make_float4(s1[0], s1[1], s1[2], s1[3]));
         }
     __syncthreads();
-    const int64_t s = pw * S::NSUB + sub;
-    if (s >= a.nsr) return;
-    const int64_t b = s / per_img;
-    const int rem = (int)(s - b * per_img);
-    const int tyb = rem / a.ntx, txb = rem - tyb * a.ntx;
-    const int oy = 2 * (tyb * TH + ty), ox = 2 * (txb * TW + tx);
-    if (oy >= a.g.h || ox >= a.g.w) return;
-    const bool okx = ox + 1 < a.g.w, oky = oy + 1 < a.g.h;
-    const int64_t pix = a.g.sl + b * a.g.plane + (int64_t)(oy + 1) * a.g.wp + ox + 1;
+    if (!live) return;
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) {
         float4 o[4];   // [dy*2+dx], channels 4h..4h+3 of block ct*8 + c2*4 + xr
@@ -292,17 +305,14 @@ void conv3x3_wino_kernel(WinoArgs a) {
             o[2 + dx] = make_float4(q[1].x - q[2].x - q[3].x, q[1].y - q[2].y - q[3].y, q[1].z - q[2].z - q[3].z,
                                     q[1].w - q[2].w - q[3].w);
         }
-        const int64_t cbo = (int64_t)ct * 8 + c2 * 4 + xr;
-        const int64_t base = (cbo * a.g.cs + pix) * 8 + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int dy = q >> 1, dx = q & 1;
             if ((dy && !oky) || (dx && !okx)) continue;
-            const int64_t off = base + ((int64_t)dy * a.g.wp + dx) * 8;
             float4 val = o[q];
             if (RELU) val = make_float4(fmaxf(val.x, 0.f), fmaxf(val.y, 0.f), fmaxf(val.z, 0.f), fmaxf(val.w, 0.f));
-            if (NRES) val = add4(val, ld4(a.res + off));
-            st4(a.y + off, val);
+            if (NRES) val = add4(val, rv[c2][q]);
+            st4(a.y + ooff[c2][q], val);
         }
     }
 }

@@ -114,13 +114,22 @@ def profile_begin():
 
 
 def profile_end():
-    """returns (total ms, total algorithmic FLOPs, launches) of the conv3x3 launches since profile_begin()"""
+    """per-kernel totals of the 3x3 conv launches since profile_begin():
+    {kernel: {"ms", "launches", "direct_flops" (2*9*Cin*Cout*pixels), "mfma_flops" (executed on the MFMA pipe:
+    the same for the direct kernel, 16/36 of it per 2x2 tile for Winograd F(2x2,3x3))}}"""
     global _prof
     rec, _prof = _prof, None
+    out = {}
     if not rec:
-        return 0.0, 0.0, 0
+        return out
     torch.cuda.synchronize()
-    return sum(a.elapsed_time(b) for a, b, _ in rec), float(sum(f for _, _, f in rec)), len(rec)
+    for e0, e1, name, direct, mfma in rec:
+        d = out.setdefault(name, {"ms": 0.0, "launches": 0, "direct_flops": 0.0, "mfma_flops": 0.0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["launches"] += 1
+        d["direct_flops"] += direct
+        d["mfma_flops"] += mfma
+    return out
 
 
 def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False, cin_valid=None):
@@ -132,7 +141,8 @@ def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=N
         e1.record()
         co = cout if cout_valid is None else cout_valid
         ci = cin if cin_valid is None else cin_valid
-        _prof.append((e0, e1, 2.0 * 9 * ci * co * g.batch * g.height * g.width))
+        fl = 2.0 * 9 * ci * co * g.batch * g.height * g.width
+        _prof.append((e0, e1, "conv3x3_kernel", fl, fl))
         return
     _conv3x3(g, x, wpk, cin, cout, y, cout_valid, x2, res1, res2, relu)
 
@@ -151,7 +161,9 @@ def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):
                                      stream_ptr(y.device)))
     if _prof is not None:
         e1.record()
-        _prof.append((e0, e1, 2.0 * 9 * cin * cout * g.batch * g.height * g.width))
+        tiles = g.batch * ((g.height + 1) // 2) * ((g.width + 1) // 2)
+        _prof.append((e0, e1, "conv3x3_wino_kernel", 2.0 * 9 * cin * cout * g.batch * g.height * g.width,
+                      2.0 * 16 * cin * cout * tiles))
 
 
 def down2x2(gi, go, x, w, cin, cout, y):
