@@ -31,6 +31,7 @@ using namespace dinv_drunet;
 
 namespace {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WP = 20;                 // LDS pitch of one (ci, co) row of U: 16 xi + 4 pad (conflict-free b128)
 constexpr int WLDS = 8 * 64 * WP;      // floats of U per channel block in LDS
 constexpr int RP = 12;                 // LDS pitch of one staged pixel: 8 channels + 4 pad
@@ -45,6 +46,10 @@ struct WinoArgs {
     const float* res;
     int32_t ncb, nct, nty, ntx;
     int64_t nsr, nwg, per_xcd;
+    int32_t slots;   // resident workgroups per XCD
+#ifdef DINV_WINO_TIMING
+    long long* dbg;  // phase timestamps (s_memtime) of wave 0, 8 per tile, first 4 tiles of every workgroup
+#endif
 };
 
 template <int TH, int TW>
@@ -61,23 +66,33 @@ struct Shape {
     static_assert(PT <= 64 && 64 % PT == 0, "rectangle must divide the 64 positions");
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory: it drains the
+// in-flight residual loads and output stores (measured 1-2.3k cycles per tile with s_memtime stamps).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int TH, int TW, bool RELU, int NRES>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_wino_kernel(WinoArgs a) {
     using S = Shape<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int l31 = lane & 31, h = lane >> 5;
     const int xr = wave & 3, wq = wave >> 2;
 
     // consecutive block ids land on different XCDs: give each XCD a contiguous range of the logical order so
     // the cout tiles of one position tile (and neighbouring position tiles) share an L2
+    // Persistent workgroups (one per CU: LDS and registers allow no second one, so a fresh workgroup per tile
+    // would leave the CU idle during every dispatch turnover): slot j of XCD x walks tiles x*per_xcd + j + k*slots.
     const int64_t bid = blockIdx.x;
-    const int64_t logical = (bid & 7) * a.per_xcd + (bid >> 3);
-    if (logical >= a.nwg) return;
+    const int64_t per_img = (int64_t)a.nty * a.ntx;
+    for (int64_t jt = bid >> 3; jt < a.per_xcd; jt += a.slots) {
+    const int64_t logical = (bid & 7) * a.per_xcd + jt;
+    if (logical >= a.nwg) break;
     const int ct = (int)(logical % a.nct);
     const int64_t pw = logical / a.nct;
-    const int64_t per_img = (int64_t)a.nty * a.ntx;
 
     // ---- staging descriptors (independent of the channel block); offsets are relative to the channel block
     uint32_t goff[S::NLD];
@@ -124,14 +139,27 @@ void conv3x3_wino_kernel(WinoArgs a) {
             for (int r = 0; r < 16; ++r) acc[c2][j][r] = 0.f;
 
     float4 pr[S::NLD], pwt[4];
-    float4 uA[2], uB[2], uC[2];
+    float4 uA[2], uB[2], uC[2], uD[2], uE[2];
     float vA[4], vB[4];
     float tc[4][4];   // row xr of B^T d for the current block: [channel m][col j]
 
+#ifdef DINV_WINO_TIMING
+    const int tile_k = (int)((jt - (bid >> 3)) / a.slots);
+#define DINV_STAMP(i) do { if (a.dbg && tid == 0 && tile_k < 4) a.dbg[(bid * 4 + tile_k) * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DINV_STAMP(i) do { } while (0)
+#endif
+    DINV_STAMP(0);
 #define DINV_MFMA8(U, V)                                                                                         \
     _Pragma("unroll") for (int c2_ = 0; c2_ < 2; ++c2_)                                                          \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                             \
         acc[c2_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(U[c2_], j_), V[j_], acc[c2_][j_], 0, 0, 0)
+#define DINV_MFMA2(U, V, c2_, j0_)                                                                              \
+    do {                                                                                                         \
+        acc[c2_][j0_] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(U[c2_], j0_), V[j0_], acc[c2_][j0_], 0, 0, 0); \
+        acc[c2_][(j0_) + 1] =                                                                                    \
+            __builtin_amdgcn_mfma_f32_32x32x2f32(comp(U[c2_], (j0_) + 1), V[(j0_) + 1], acc[c2_][(j0_) + 1], 0, 0, 0); \
+    } while (0)
 #define DINV_VCALC(V, T)                                                                                         \
     do { V[0] = T[0] - T[2]; V[1] = T[1] + T[2]; V[2] = T[2] - T[1]; V[3] = T[1] - T[3]; } while (0)
 #define DINV_COL(j) ((((j) & 1) * S::RW2 + ((j) >> 1)) * RP)
@@ -161,78 +189,107 @@ void conv3x3_wino_kernel(WinoArgs a) {
             for (int j = 0; j < 4; ++j) tc[m][j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
     };
 
-    // ---- prologue: block 0 to LDS, block 1 in flight, first operands in registers
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fetch_w(0, i);
-#pragma unroll
-    for (int i = 0; i < S::NLD; ++i) fetch_r(0, i);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stash_w(lds, i);
-#pragma unroll
-    for (int i = 0; i < S::NLD; ++i) stash_r(lds, i);
+    // ---- prologue.  Staging parts: W0..W3 (weight float4s) and R0,R1 (pixels).  In steady state W0-W2 run one
+    // block ahead (written to LDS in steps 0/1) and W3,R0,R1 two blocks ahead (written in steps 2/3, when the
+    // current buffer is already dead), so the 6 ds_write_b128 per wave are spread over the whole block.
     {
-        const int c1 = a.ncb > 1 ? 1 : 0;
+        const int c1 = a.ncb > 1 ? 1 : 0, c2b = a.ncb > 2 ? 2 : a.ncb - 1;
+        float4 w3, r1[S::NLD];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fetch_w(c1, i);
+        for (int i = 0; i < 4; ++i) fetch_w(0, i);
 #pragma unroll
-        for (int i = 0; i < S::NLD; ++i) fetch_r(c1, i);
+        for (int i = 0; i < S::NLD; ++i) fetch_r(0, i);
+        w3 = ld4_so(wsrc + (int64_t)c1 * 8192 + 3 * 2048, (uint32_t)tid * 16u);
+#pragma unroll
+        for (int i = 0; i < S::NLD; ++i) r1[i] = ld4_so(a.x + c1 * xcs, goff[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stash_w(lds, i);
+#pragma unroll
+        for (int i = 0; i < S::NLD; ++i) stash_r(lds, i);
+        st4(lds + S::BUF + woff + 3 * 128 * WP, w3);
+#pragma unroll
+        for (int i = 0; i < S::NLD; ++i) { pr[i] = r1[i]; stash_r(lds + S::BUF, i); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fetch_w(c1, i);
+        fetch_w(c2b, 3);
+#pragma unroll
+        for (int i = 0; i < S::NLD; ++i) fetch_r(c2b, i);
     }
     __syncthreads();
     tcalc(lds);
     DINV_UREAD(uA, lds, 0);
     DINV_VCALC(vA, tc[0]);
 
+    DINV_STAMP(1);
     // One 8-channel block = 4 steps (m = channel 4h+m) of 8 MFMAs.  Everything else rides one step ahead:
     //   step 0: read U(m=1); V(m=1); write the staged weights of block cb+1 to LDS, re-issue the loads for cb+2
     //   step 1: read U(m=2), U(m=3); V(m=2); same for the staged input pixels;   barrier
     //   step 2: V(m=3); read the two patch rows of block cb+1
     //   step 3: row xr of B^T d for block cb+1; read U(cb+1, m=0); V(cb+1, m=0)
-    auto block = [&](int cb, auto parity_tag, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
+    auto block = [&](int cb, auto parity_tag, float4 (&u0)[2], float4 (&u0n)[2]) {
         constexpr int PAR = decltype(parity_tag)::value;   // cb & 1, compile time: LDS addresses fold to immediates
         const float* cur = lds + PAR * S::BUF;
         float* nxt = lds + (1 - PAR) * S::BUF;
         const int cb2 = cb + 2 < a.ncb ? cb + 2 : a.ncb - 1;   // re-issued loads past the end re-read the last block
+        const int cb3 = cb + 3 < a.ncb ? cb + 3 : a.ncb - 1;
+        float* curw = lds + PAR * S::BUF;
         float4 dA[4], dB[4];
-        // ---- step 0
-        DINV_MFMA8(uA, vA);
-        DINV_UREAD(uB, cur, 1);
-        DINV_VCALC(vB, tc[1]);
-        if (!LAST) {
+        // Issue is in order and the older wave of a SIMD wins the MFMA pipe, so a wave often runs alone: every
+        // filler is therefore placed by hand between MFMA pairs (sched_barrier pins it), LDS reads right after the
+        // first pair of the step BEFORE the one that consumes them (>= 6 MFMAs = 384 cycles of cover).
+#define DINV_SB() __builtin_amdgcn_sched_barrier(0)
+        // ---- step 0 (m = 0)
+        if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 0);
+        DINV_MFMA2(u0, vA, 0, 0); DINV_SB();
+        DINV_UREAD(uB, cur, 1); DINV_SB();
+        DINV_MFMA2(u0, vA, 0, 2); DINV_SB();
+        DINV_VCALC(vB, tc[1]); DINV_SB();
+        DINV_MFMA2(u0, vA, 1, 0); DINV_SB();
+        stash_w(nxt, 0); stash_w(nxt, 1);
+        fetch_w(cb2, 0); fetch_w(cb2, 1); DINV_SB();
+        DINV_MFMA2(u0, vA, 1, 2); DINV_SB();
+        if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 1);
+        // ---- step 1 (m = 1)
+        DINV_MFMA2(uB, vB, 0, 0); DINV_SB();
+        DINV_UREAD(uE, cur, 2);
+        DINV_UREAD(uC, cur, 3); DINV_SB();
+        DINV_MFMA2(uB, vB, 0, 2); DINV_SB();
+        DINV_VCALC(vA, tc[2]); DINV_SB();
+        DINV_MFMA2(uB, vB, 1, 0); DINV_SB();
+        stash_w(nxt, 2);
+        fetch_w(cb2, 2); DINV_SB();
+        DINV_MFMA2(uB, vB, 1, 2); DINV_SB();
+        if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 2);
+        lds_barrier();
+        if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 3);
+        DINV_SB();
+        // ---- step 2 (m = 2): everything the next block needs first is read right behind the barrier
+        DINV_MFMA2(uE, vA, 0, 0); DINV_SB();
+        DINV_UREAD(u0n, nxt, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { stash_w(nxt, i); fetch_w(cb2, i); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- step 1
-        DINV_MFMA8(uB, vB);
-        DINV_UREAD(uA, cur, 2);
-        DINV_UREAD(uC, cur, 3);
-        DINV_VCALC(vA, tc[2]);
-        if (!LAST) {
+        for (int j = 0; j < 4; ++j) { dA[j] = ld4(nxt + rA + DINV_COL(j)); dB[j] = ld4(nxt + rB + DINV_COL(j)); }
+        DINV_SB();
+        DINV_MFMA2(uE, vA, 0, 2); DINV_SB();
+        DINV_VCALC(vB, tc[3]); DINV_SB();
+        DINV_MFMA2(uE, vA, 1, 0); DINV_SB();
+        stash_w(curw, 3); stash_r(curw, 0);     // block cb+2: this buffer's block cb is dead behind the barrier
+        fetch_w(cb3, 3); fetch_r(cb3, 0); DINV_SB();
+        DINV_MFMA2(uE, vA, 1, 2); DINV_SB();
+        if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 4);
+        // ---- step 3 (m = 3)
+        DINV_MFMA2(uC, vB, 0, 0); DINV_SB();
 #pragma unroll
-            for (int i = 0; i < S::NLD; ++i) { stash_r(nxt, i); fetch_r(cb2, i); }
-            __syncthreads();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- step 2
-        DINV_MFMA8(uA, vA);
-        DINV_VCALC(vB, tc[3]);
-        if (!LAST) {
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { dA[j] = ld4(nxt + rA + DINV_COL(j)); dB[j] = ld4(nxt + rB + DINV_COL(j)); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- step 3
-        DINV_MFMA8(uC, vB);
-        if (!LAST) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tc[m][j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
-            DINV_UREAD(uA, nxt, 0);
-            DINV_VCALC(vA, tc[0]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 4; ++j) tc[m][j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
+        DINV_SB();
+        DINV_MFMA2(uC, vB, 0, 2); DINV_SB();
+        DINV_VCALC(vA, tc[0]); DINV_SB();
+        DINV_MFMA2(uC, vB, 1, 0); DINV_SB();
+        if (S::NLD > 1) { stash_r(curw, S::NLD - 1); fetch_r(cb3, S::NLD - 1); }
+        DINV_SB();
+        DINV_MFMA2(uC, vB, 1, 2); DINV_SB();
+#undef DINV_SB
     };
     {
         // two blocks per trip so the register state returns to the same names (no copies on the back edge) and
@@ -242,15 +299,22 @@ void conv3x3_wino_kernel(WinoArgs a) {
         using P1 = std::integral_constant<int, 1>;
 #pragma unroll 1
         for (int cb = 0; cb < a.ncb; cb += 2) {
-            block(cb, P0{}, std::false_type{});
-            if (cb + 1 < a.ncb) block(cb + 1, P1{}, std::false_type{});
+            block(cb, P0{}, uA, uD);
+            if (cb + 1 < a.ncb) {
+                block(cb + 1, P1{}, uD, uA);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) uA[i] = uD[i];   // odd block count: keep the naming invariant
+            }
         }
     }
 #undef DINV_MFMA8
+#undef DINV_MFMA2
 #undef DINV_VCALC
 #undef DINV_COL
 #undef DINV_UREAD
 
+    DINV_STAMP(2);
     // ---- epilogue: s = M A for this wave's Winograd row, exchange, then A^T s for channel sub-block rj = xr
     const int64_t s = pw * S::NSUB + sub;
     const int64_t b = s / per_img;
@@ -259,21 +323,26 @@ void conv3x3_wino_kernel(WinoArgs a) {
     const int oy = 2 * (tyb * TH + ty), ox = 2 * (txb * TW + tx);
     const bool live = s < a.nsr && oy < a.g.h && ox < a.g.w;
     const bool okx = ox + 1 < a.g.w, oky = oy + 1 < a.g.h;
+    // per-lane byte offsets inside one channel block; lanes/pixels outside the image get an out-of-range offset:
+    // buffer loads then return 0 and buffer stores are dropped, so the epilogue has no branches
     const int64_t pix = a.g.sl + b * a.g.plane + (int64_t)(oy + 1) * a.g.wp + ox + 1;
-    int64_t ooff[2][4];
-    float4 rv[2][4];
+    uint32_t loffs[4];
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-        const int64_t cbo = (int64_t)ct * 8 + c2 * 4 + xr;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ooff[c2][q] = (cbo * a.g.cs + pix + (int64_t)(q >> 1) * a.g.wp + (q & 1)) * 8 + 4 * h;
-            // residual values are fetched now so that their latency hides behind the exchange
-            if (NRES) rv[c2][q] = (live && !((q >> 1) && !oky) && !((q & 1) && !okx)) ? ld4(a.res + ooff[c2][q])
-                                                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int q = 0; q < 4; ++q) {
+        const bool ok = live && !((q >> 1) && !oky) && !((q & 1) && !okx);
+        loffs[q] = ok ? (uint32_t)((pix + (int64_t)(q >> 1) * a.g.wp + (q & 1)) * 32 + 16 * h) : 0xffffffffu;
     }
-    __syncthreads();   // the staging buffers are dead: reuse LDS as E[wq][src row][rj][c2][dx][lane][4]
+    float4 rv[2][4];
+    if (NRES) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)   // fetched now so that their latency hides behind the exchange
+                rv[c2][q] = ld4_so(a.res + ((int64_t)ct * 8 + c2 * 4 + xr) * xcs, loffs[q]);
+    }
+    DINV_STAMP(3);
+    lds_barrier();   // the staging buffers are dead: reuse LDS as E[wq][src row][rj][c2][dx][lane][4]
+    DINV_STAMP(4);
     float* ex = lds + wq * (4 * 4 * 2 * 2 * 256) + lane * 4;
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
@@ -291,8 +360,9 @@ void conv3x3_wino_kernel(WinoArgs a) {
             st4(e, make_float4(s0[0], s0[1], s0[2], s0[3]));
             st4(e + 256, make_float4(s1[0], s1[1], s1[2], s1[3]));
         }
-    __syncthreads();
-    if (!live) return;
+    lds_barrier();
+    DINV_STAMP(5);
+    {
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) {
         float4 o[4];   // [dy*2+dx], channels 4h..4h+3 of block ct*8 + c2*4 + xr
@@ -305,16 +375,34 @@ void conv3x3_wino_kernel(WinoArgs a) {
             o[2 + dx] = make_float4(q[1].x - q[2].x - q[3].x, q[1].y - q[2].y - q[3].y, q[1].z - q[2].z - q[3].z,
                                     q[1].w - q[2].w - q[3].w);
         }
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            a.y + ((int64_t)ct * 8 + c2 * 4 + xr) * xcs, 0, 0xffffffff, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int dy = q >> 1, dx = q & 1;
-            if ((dy && !oky) || (dx && !okx)) continue;
             float4 val = o[q];
             if (RELU) val = make_float4(fmaxf(val.x, 0.f), fmaxf(val.y, 0.f), fmaxf(val.z, 0.f), fmaxf(val.w, 0.f));
             if (NRES) val = add4(val, rv[c2][q]);
-            st4(a.y + ooff[c2][q], val);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), yrsrc, loffs[q], 0, 0);
         }
     }
+    }
+    DINV_STAMP(6);
+    lds_barrier();   // the exchange buffer is restaged by the next tile
+    DINV_STAMP(7);
+    }   // tile loop
+}
+
+// compute units per XCD of the current device (32 on MI355X: 256 CUs in 8 XCDs)
+int cus_per_xcd() {
+    static int v = 0;
+    if (v == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+            n = 256;
+        v = n / 8;
+    }
+    return v;
 }
 
 template <int TH, int TW, bool RELU, int NRES>
@@ -333,7 +421,8 @@ int launch_shape(WinoArgs a, int tiles_y, int tiles_x, hipStream_t st) {
             return fail(3, "hipFuncSetAttribute(max dynamic LDS) failed");
         once = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.per_xcd * 8)), dim3(NTHR), shm, st, a);
+    a.slots = (int32_t)(a.per_xcd < cus_per_xcd() ? a.per_xcd : cus_per_xcd());
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.slots * 8)), dim3(NTHR), shm, st, a);
     DINV_CHECK_LAUNCH();
     return 0;
 }
@@ -358,6 +447,11 @@ int launch_any(const WinoArgs& a, hipStream_t st) {
 
 }  // namespace
 
+#ifdef DINV_WINO_TIMING
+static long long* g_wino_dbg = nullptr;
+extern "C" void dinv_debug_wino_timing(long long* p) { g_wino_dbg = p; }
+#endif
+
 extern "C" int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w_wino, int32_t cin,
                                      int32_t cout, float* y, const float* res1, int32_t relu, dinv_stream_t stream) {
     if (check_geom(g)) return 1;
@@ -369,6 +463,9 @@ extern "C" int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, con
     a.g = make_geom(*g);
     a.x = x; a.w = w_wino; a.y = y; a.res = res1;
     a.ncb = cin / 8; a.nct = cout / 64;
+#ifdef DINV_WINO_TIMING
+    a.dbg = g_wino_dbg;
+#endif
     hipStream_t st = (hipStream_t)stream;
     if (relu) return launch_any<true, 0>(a, st);
     if (res1) return launch_any<false, 1>(a, st);

@@ -8,6 +8,8 @@ lvl, B = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device("cuda:0")
 c, H = 64 << lvl, 320 >> lvl
+if os.environ.get('WINO_C'):
+    c = int(os.environ['WINO_C'])
 g = K.geom(B, H, H)
 x, y = K.alloc(g, c, dev), K.alloc(g, c, dev)
 x.normal_()
