@@ -38,6 +38,24 @@ constexpr int RP = 12;                 // LDS pitch of one staged pixel: 8 chann
 constexpr int NTHR = 512;
 constexpr int EXCH = 8 * 4 * 2 * 2 * 256;   // floats of the epilogue exchange buffer (128 KB)
 
+// exact unsigned division by a runtime constant (Granlund-Montgomery round-up multiplier): n / d for all 32-bit n
+struct FastDiv {
+    uint32_t m, s1, s2;
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        const uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDiv f;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+
 struct WinoArgs {
     Geom g;
     const float* x;
@@ -47,6 +65,7 @@ struct WinoArgs {
     int32_t ncb, nct, nty, ntx;
     int64_t nsr, nwg, per_xcd;
     int32_t slots;   // resident workgroups per XCD
+    FastDiv d_img, d_ntx, d_nct;   // / (nty*ntx), / ntx, / nct
 #ifdef DINV_WINO_TIMING
     long long* dbg;  // phase timestamps (s_memtime) of wave 0, 8 per tile, first 4 tiles of every workgroup
 #endif
@@ -82,44 +101,15 @@ void conv3x3_wino_kernel(WinoArgs a) {
     const int l31 = lane & 31, h = lane >> 5;
     const int xr = wave & 3, wq = wave >> 2;
 
-    // consecutive block ids land on different XCDs: give each XCD a contiguous range of the logical order so
-    // the cout tiles of one position tile (and neighbouring position tiles) share an L2
-    // Persistent workgroups (one per CU: LDS and registers allow no second one, so a fresh workgroup per tile
-    // would leave the CU idle during every dispatch turnover): slot j of XCD x walks tiles x*per_xcd + j + k*slots.
+    // Persistent workgroups (one per CU: LDS and registers allow no second one): slot j of XCD x walks tiles
+    // x*per_xcd + j + k*slots of the logical order, so each XCD owns a contiguous range of it and the cout
+    // tiles of one position tile (and neighbouring position tiles) share an L2.
     const int64_t bid = blockIdx.x;
     const int64_t per_img = (int64_t)a.nty * a.ntx;
-    for (int64_t jt = bid >> 3; jt < a.per_xcd; jt += a.slots) {
-    const int64_t logical = (bid & 7) * a.per_xcd + jt;
-    if (logical >= a.nwg) break;
-    const int ct = (int)(logical % a.nct);
-    const int64_t pw = logical / a.nct;
-
-    // ---- staging descriptors (independent of the channel block); offsets are relative to the channel block
-    uint32_t goff[S::NLD];
-    int loff[S::NLD];
-#pragma unroll
-    for (int i = 0; i < S::NLD; ++i) {
-        const int e = tid + NTHR * i;
-        const int half = e & 1, px = e >> 1;
-        const int c = px % (2 * S::RW2);
-        const int r = (px / (2 * S::RW2)) % S::RH;
-        const int sub = px / (2 * S::RW2 * S::RH);
-        const int64_t s = pw * S::NSUB + sub;
-        const int64_t b = s / per_img;
-        const int rem = (int)(s - b * per_img);
-        const int tyb = rem / a.ntx, txb = rem - tyb * a.ntx;
-        const int gr = 2 * tyb * TH + r, gc = 2 * txb * TW + c;
-        const bool ok = e < S::RAW4 && s < a.nsr && gr < a.g.hp && gc < a.g.wp;
-        // out-of-frame pixels read the (always zero) top-left border pixel of image 0 instead
-        goff[i] = 4u * (ok ? (uint32_t)((a.g.sl + b * a.g.plane + (int64_t)gr * a.g.wp + gc) * 8 + half * 4)
-                          : (uint32_t)(a.g.sl * 8));   // byte offset
-        loff[i] = WLDS + (((sub * S::RH + r) * 2 + (c & 1)) * S::RW2 + (c >> 1)) * RP + half * 4;
-    }
-    const float* wsrc = a.w + (int64_t)ct * a.ncb * 8192;   // + tid*16 bytes per lane
     const int64_t xcs = a.g.cs * 8;
     const int woff = (tid >> 2) * WP + (tid & 3) * 4;   // LDS offset of weight float4 #tid (+ i*128*WP for #tid+512i)
 
-    // ---- this lane's operand addresses
+    // ---- this lane's operand addresses (tile independent)
     const int p = wq * 32 + l31;
     const int sub = p / S::PT, ty = (p % S::PT) / TW, tx = p % TW;
     // row xr of B^T d:  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3   ->   t = d[ra] + sigma * d[rb]
@@ -130,26 +120,58 @@ void conv3x3_wino_kernel(WinoArgs a) {
     const int rA = rbase + ra * 2 * S::RW2 * RP, rB = rbase + rb * 2 * S::RW2 * RP;
     const int abase = ((4 * h) * 64 + l31) * WP + 4 * xr;
 
-    f32x16 acc[2][4];
+    // ---- staging descriptors: LDS side is tile independent, global side is recomputed per tile
+    int loff[S::NLD];
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
+    for (int i = 0; i < S::NLD; ++i) {
+        const int e = tid + NTHR * i;
+        const int half = e & 1, px = e >> 1;
+        const int c = px % (2 * S::RW2);
+        const int r = (px / (2 * S::RW2)) % S::RH;
+        const int sb = px / (2 * S::RW2 * S::RH);
+        loff[i] = WLDS + (((sb * S::RH + r) * 2 + (c & 1)) * S::RW2 + (c >> 1)) * RP + half * 4;
+    }
+    uint32_t goff[S::NLD];      // byte offsets inside one channel block of x
+    const float* wsrc;          // packed U of the tile's cout block (+ tid*16 bytes per lane)
+    int ct;                     // tile coordinates: cout block, position group
+    uint32_t pw;
+    auto describe = [&](int64_t logical) {
+        pw = a.d_nct.div((uint32_t)logical);
+        ct = (int)((uint32_t)logical - (uint32_t)pw * (uint32_t)a.nct);
+        wsrc = a.w + (int64_t)ct * a.ncb * 8192;
+        int t = tid;
+        asm volatile("" : "+v"(t));   // recompute the per-lane constants per tile instead of keeping them live
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c2][j][r] = 0.f;
+        for (int i = 0; i < S::NLD; ++i) {
+            const int e = t + NTHR * i;
+            const int half = e & 1, px = e >> 1;
+            const int c = px % (2 * S::RW2);
+            const int r = (px / (2 * S::RW2)) % S::RH;
+            const int sb = px / (2 * S::RW2 * S::RH);
+            const uint32_t s = (uint32_t)pw * S::NSUB + sb;
+            const uint32_t b = a.d_img.div(s);
+            const uint32_t rem = s - b * (uint32_t)per_img;
+            const uint32_t tyb = a.d_ntx.div(rem), txb = rem - tyb * a.ntx;
+            const int gr = 2 * tyb * TH + r, gc = 2 * txb * TW + c;
+            const bool ok = e < S::RAW4 && s < (uint32_t)a.nsr && gr < a.g.hp && gc < a.g.wp;
+            // out-of-frame pixels read the (always zero) top-left border pixel of image 0 instead
+            goff[i] = 4u * (ok ? (uint32_t)((a.g.sl + (int64_t)b * a.g.plane + (int64_t)gr * a.g.wp + gc) * 8 + half * 4)
+                              : (uint32_t)(a.g.sl * 8));
+        }
+    };
 
+    f32x16 acc[2][4];
     float4 pr[S::NLD], pwt[4];
     float4 uA[2], uB[2], uC[2], uD[2], uE[2];
     float vA[4], vB[4];
     float tc[4][4];   // row xr of B^T d for the current block: [channel m][col j]
 
 #ifdef DINV_WINO_TIMING
-    const int tile_k = (int)((jt - (bid >> 3)) / a.slots);
+    int tile_k = 0;
 #define DINV_STAMP(i) do { if (a.dbg && tid == 0 && tile_k < 4) a.dbg[(bid * 4 + tile_k) * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define DINV_STAMP(i) do { } while (0)
 #endif
-    DINV_STAMP(0);
 #define DINV_MFMA8(U, V)                                                                                         \
     _Pragma("unroll") for (int c2_ = 0; c2_ < 2; ++c2_)                                                          \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                             \
@@ -189,33 +211,49 @@ void conv3x3_wino_kernel(WinoArgs a) {
             for (int j = 0; j < 4; ++j) tc[m][j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
     };
 
-    // ---- prologue.  Staging parts: W0..W3 (weight float4s) and R0,R1 (pixels).  In steady state W0-W2 run one
-    // block ahead (written to LDS in steps 0/1) and W3,R0,R1 two blocks ahead (written in steps 2/3, when the
-    // current buffer is already dead), so the 6 ds_write_b128 per wave are spread over the whole block.
-    {
-        const int c1 = a.ncb > 1 ? 1 : 0, c2b = a.ncb > 2 ? 2 : a.ncb - 1;
-        float4 w3, r1[S::NLD];
+    // ---- Staging parts: W0..W3 (weight float4s) and R0,R1 (pixels).  In steady state W0-W2 run one block ahead
+    // (written to LDS in steps 0/1) and W3,R0,R1 two blocks ahead (written in steps 2/3, when the current buffer
+    // is already dead), so the 6 ds_write_b128 per wave are spread over the whole block.
+    float4 w3x, r1x[S::NLD];    // block 1's W3 / R parts of the tile being entered
+    auto first_loads = [&]() {  // everything the first barrier of a tile needs, straight from the descriptors
+        const int c1 = a.ncb > 1 ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) fetch_w(0, i);
 #pragma unroll
         for (int i = 0; i < S::NLD; ++i) fetch_r(0, i);
-        w3 = ld4_so(wsrc + (int64_t)c1 * 8192 + 3 * 2048, (uint32_t)tid * 16u);
+        w3x = ld4_so(wsrc + (int64_t)c1 * 8192 + 3 * 2048, (uint32_t)tid * 16u);
 #pragma unroll
-        for (int i = 0; i < S::NLD; ++i) r1[i] = ld4_so(a.x + c1 * xcs, goff[i]);
+        for (int i = 0; i < S::NLD; ++i) r1x[i] = ld4_so(a.x + c1 * xcs, goff[i]);
+    };
+
+    int64_t jt = bid >> 3;
+    if (jt >= a.per_xcd || (bid & 7) * a.per_xcd + jt >= a.nwg) return;
+    describe((bid & 7) * a.per_xcd + jt);
+    first_loads();
+    for (;;) {
+    DINV_STAMP(0);
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c2][j][r] = 0.f;
+    {   // ---- tile prologue: the loads were issued before the previous tile's epilogue
+        const int c1 = a.ncb > 1 ? 1 : 0, c2b = a.ncb > 2 ? 2 : a.ncb - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) stash_w(lds, i);
 #pragma unroll
         for (int i = 0; i < S::NLD; ++i) stash_r(lds, i);
-        st4(lds + S::BUF + woff + 3 * 128 * WP, w3);
+        st4(lds + S::BUF + woff + 3 * 128 * WP, w3x);
 #pragma unroll
-        for (int i = 0; i < S::NLD; ++i) { pr[i] = r1[i]; stash_r(lds + S::BUF, i); }
+        for (int i = 0; i < S::NLD; ++i) { pr[i] = r1x[i]; stash_r(lds + S::BUF, i); }
 #pragma unroll
         for (int i = 0; i < 3; ++i) fetch_w(c1, i);
         fetch_w(c2b, 3);
 #pragma unroll
         for (int i = 0; i < S::NLD; ++i) fetch_r(c2b, i);
     }
-    __syncthreads();
+    lds_barrier();
     tcalc(lds);
     DINV_UREAD(uA, lds, 0);
     DINV_VCALC(vA, tc[0]);
@@ -233,7 +271,7 @@ void conv3x3_wino_kernel(WinoArgs a) {
         const int cb2 = cb + 2 < a.ncb ? cb + 2 : a.ncb - 1;   // re-issued loads past the end re-read the last block
         const int cb3 = cb + 3 < a.ncb ? cb + 3 : a.ncb - 1;
         float* curw = lds + PAR * S::BUF;
-        float4 dA[4], dB[4];
+        float4 dA[2], dB[2];
         // Issue is in order and the older wave of a SIMD wins the MFMA pipe, so a wave often runs alone: every
         // filler is therefore placed by hand between MFMA pairs (sched_barrier pins it), LDS reads right after the
         // first pair of the step BEFORE the one that consumes them (>= 6 MFMAs = 384 cycles of cover).
@@ -263,27 +301,34 @@ void conv3x3_wino_kernel(WinoArgs a) {
         lds_barrier();
         if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 3);
         DINV_SB();
-        // ---- step 2 (m = 2): everything the next block needs first is read right behind the barrier
+        // ---- step 2 (m = 2): everything the next block needs first is read right behind the barrier; the patch
+        // rows come in two column pairs so that only 16 registers of raw pixels are live at a time
         DINV_MFMA2(uE, vA, 0, 0); DINV_SB();
         DINV_UREAD(u0n, nxt, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dA[j] = ld4(nxt + rA + DINV_COL(j)); dB[j] = ld4(nxt + rB + DINV_COL(j)); }
+        for (int j = 0; j < 2; ++j) { dA[j] = ld4(nxt + rA + DINV_COL(j)); dB[j] = ld4(nxt + rB + DINV_COL(j)); }
         DINV_SB();
         DINV_MFMA2(uE, vA, 0, 2); DINV_SB();
-        DINV_VCALC(vB, tc[3]); DINV_SB();
+        DINV_VCALC(vB, tc[3]); DINV_SB();     // last use of this block's tc: it is overwritten in place below
         DINV_MFMA2(uE, vA, 1, 0); DINV_SB();
         stash_w(curw, 3); stash_r(curw, 0);     // block cb+2: this buffer's block cb is dead behind the barrier
         fetch_w(cb3, 3); fetch_r(cb3, 0); DINV_SB();
         DINV_MFMA2(uE, vA, 1, 2); DINV_SB();
-        if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 4);
-        // ---- step 3 (m = 3)
-        DINV_MFMA2(uC, vB, 0, 0); DINV_SB();
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tc[m][j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
+            for (int j = 0; j < 2; ++j) tc[m][j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { dA[j] = ld4(nxt + rA + DINV_COL(2 + j)); dB[j] = ld4(nxt + rB + DINV_COL(2 + j)); }
         DINV_SB();
+        if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 4);
+        // ---- step 3 (m = 3)
+        DINV_MFMA2(uC, vB, 0, 0); DINV_SB();
         DINV_MFMA2(uC, vB, 0, 2); DINV_SB();
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tc[m][2 + j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
         DINV_VCALC(vA, tc[0]); DINV_SB();
         DINV_MFMA2(uC, vB, 1, 0); DINV_SB();
         if (S::NLD > 1) { stash_r(curw, S::NLD - 1); fetch_r(cb3, S::NLD - 1); }
@@ -316,34 +361,39 @@ void conv3x3_wino_kernel(WinoArgs a) {
 
     DINV_STAMP(2);
     // ---- epilogue: s = M A for this wave's Winograd row, exchange, then A^T s for channel sub-block rj = xr
-    const int64_t s = pw * S::NSUB + sub;
-    const int64_t b = s / per_img;
-    const int rem = (int)(s - b * per_img);
-    const int tyb = rem / a.ntx, txb = rem - tyb * a.ntx;
-    const int oy = 2 * (tyb * TH + ty), ox = 2 * (txb * TW + tx);
-    const bool live = s < a.nsr && oy < a.g.h && ox < a.g.w;
+    int te = tid;
+    asm volatile("" : "+v"(te));      // same: (sub, ty, tx, h) are cheaper to recompute than to keep across the loop
+    const int ep = wq * 32 + (te & 31), eh = (te >> 5) & 1;
+    const int esub = ep / S::PT, ety = (ep % S::PT) / TW, etx = ep % TW;
+    const uint32_t s = (uint32_t)pw * S::NSUB + esub;
+    const uint32_t b = a.d_img.div(s);
+    const uint32_t rem = s - b * (uint32_t)per_img;
+    const uint32_t tyb = a.d_ntx.div(rem), txb = rem - tyb * a.ntx;
+    const int oy = 2 * (tyb * TH + ety), ox = 2 * (txb * TW + etx);
+    const bool live = s < (uint32_t)a.nsr && oy < a.g.h && ox < a.g.w;
     const bool okx = ox + 1 < a.g.w, oky = oy + 1 < a.g.h;
     // per-lane byte offsets inside one channel block; lanes/pixels outside the image get an out-of-range offset:
     // buffer loads then return 0 and buffer stores are dropped, so the epilogue has no branches
-    const int64_t pix = a.g.sl + b * a.g.plane + (int64_t)(oy + 1) * a.g.wp + ox + 1;
+    const int64_t pix = a.g.sl + (int64_t)b * a.g.plane + (int64_t)(oy + 1) * a.g.wp + ox + 1;
     uint32_t loffs[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const bool ok = live && !((q >> 1) && !oky) && !((q & 1) && !okx);
-        loffs[q] = ok ? (uint32_t)((pix + (int64_t)(q >> 1) * a.g.wp + (q & 1)) * 32 + 16 * h) : 0xffffffffu;
+        loffs[q] = ok ? (uint32_t)((pix + (int64_t)(q >> 1) * a.g.wp + (q & 1)) * 32 + 16 * eh) : 0xffffffffu;
     }
+    const int ect = ct;          // this tile's cout block is still needed below
     float4 rv[2][4];
     if (NRES) {
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
             for (int q = 0; q < 4; ++q)   // fetched now so that their latency hides behind the exchange
-                rv[c2][q] = ld4_so(a.res + ((int64_t)ct * 8 + c2 * 4 + xr) * xcs, loffs[q]);
+                rv[c2][q] = ld4_so(a.res + ((int64_t)ect * 8 + c2 * 4 + xr) * xcs, loffs[q]);
     }
     DINV_STAMP(3);
     lds_barrier();   // the staging buffers are dead: reuse LDS as E[wq][src row][rj][c2][dx][lane][4]
     DINV_STAMP(4);
-    float* ex = lds + wq * (4 * 4 * 2 * 2 * 256) + lane * 4;
+    float* ex = lds + wq * (4 * 4 * 2 * 2 * 256) + (te & 63) * 4;
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
@@ -360,23 +410,39 @@ void conv3x3_wino_kernel(WinoArgs a) {
             st4(e, make_float4(s0[0], s0[1], s0[2], s0[3]));
             st4(e + 256, make_float4(s1[0], s1[1], s1[2], s1[3]));
         }
+    // ---- next tile: describe it and issue its first loads now, the accumulators are dead, so there are
+    // registers for them; they fly during the exchange reads, the output stores and the tile turnover
+    jt += a.slots;
+    const bool more = jt < a.per_xcd && (bid & 7) * a.per_xcd + jt < a.nwg;
+    if (more) {
+        describe((bid & 7) * a.per_xcd + jt);
+        first_loads();
+    }
     lds_barrier();
     DINV_STAMP(5);
-    {
+    float4 qv[2][2][4];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qv[c2][dx][i] = ld4(ex + (((i * 4 + xr) * 2 + c2) * 2 + dx) * 256);
+    // Last LDS access of the tile: barrier here, so the output stores (store-issue bound: ~4k cycles for the
+    // workgroup's 64 KB) overlap with the next tile's staging instead of holding every wave at a barrier.
+    lds_barrier();
+    DINV_STAMP(6);
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) {
-        float4 o[4];   // [dy*2+dx], channels 4h..4h+3 of block ct*8 + c2*4 + xr
+        float4 o[4];   // [dy*2+dx], channels 4h..4h+3 of block ect*8 + c2*4 + xr
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            float4 q[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = ld4(ex + (((i * 4 + xr) * 2 + c2) * 2 + dx) * 256);
+            const float4* q = qv[c2][dx];
             o[dx] = add4(add4(q[0], q[1]), q[2]);
             o[2 + dx] = make_float4(q[1].x - q[2].x - q[3].x, q[1].y - q[2].y - q[3].y, q[1].z - q[2].z - q[3].z,
                                     q[1].w - q[2].w - q[3].w);
         }
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            a.y + ((int64_t)ct * 8 + c2 * 4 + xr) * xcs, 0, 0xffffffff, 0x00020000);
+            a.y + ((int64_t)ect * 8 + c2 * 4 + xr) * xcs, 0, 0xffffffff, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 val = o[q];
@@ -385,10 +451,11 @@ void conv3x3_wino_kernel(WinoArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), yrsrc, loffs[q], 0, 0);
         }
     }
-    }
-    DINV_STAMP(6);
-    lds_barrier();   // the exchange buffer is restaged by the next tile
     DINV_STAMP(7);
+    if (!more) break;
+#ifdef DINV_WINO_TIMING
+    ++tile_k;
+#endif
     }   // tile loop
 }
 
@@ -413,6 +480,10 @@ int launch_shape(WinoArgs a, int tiles_y, int tiles_x, hipStream_t st) {
     a.nsr = (int64_t)a.g.batch * a.nty * a.ntx;
     a.nwg = ceil_div(a.nsr, S::NSUB) * a.nct;
     a.per_xcd = ceil_div(a.nwg, 8);
+    DINV_REQUIRE(a.nsr + 64 < (1ll << 31) && a.nwg < (1ll << 31), "winograd conv: too many tiles for 32-bit indexing");
+    a.d_img = make_fastdiv((uint32_t)(a.nty * a.ntx));
+    a.d_ntx = make_fastdiv((uint32_t)a.ntx);
+    a.d_nct = make_fastdiv((uint32_t)a.nct);
     const size_t shm = S::LDSF * sizeof(float);
     static bool once = false;  // per instantiation
     auto kern = conv3x3_wino_kernel<TH, TW, RELU, NRES>;

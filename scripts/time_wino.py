@@ -25,7 +25,7 @@ torch.cuda.synchronize()
 l.dinv_debug_wino_timing(None)
 d32 = dbg.view(256, 4, 32).cpu().double()
 d = d32[:, :, :8]
-names = ["setup+prologue", "main loop", "ooff/res issue", "barrier", "s-calc+exch write+barrier", "finalise+stores", "last barrier"]
+names = ["prologue", "main loop", "offsets+res+next-tile loads", "barrier", "s-calc+exch write+barrier", "exch read+barrier", "finalise+stores"]
 ok = d[:, :, 7] > 0
 for k in range(4):
     m = ok[:, k]
