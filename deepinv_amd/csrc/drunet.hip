@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void down2x2_kernel(DownArgs a) {
         if (gidx + 1 < ngroups) DINV_MMA_GROUP(a10, a11, b10, b11)
     }
 #undef DINV_LOAD_GROUP
+#undef DINV_MMA_GROUP
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int64_t q = q0 + n * 32 + l31;
@@ -265,59 +266,78 @@ struct UpArgs {
     int32_t cin, cout;
 };
 
+// Workgroup = 4 waves x 32 input pixels; every wave computes all four output parities (taps) and 64 couts of its
+// pixels, so each input pixel (and its skip partner) is read from HBM exactly once: 8 accumulators (128
+// registers), operands double buffered in registers straight from global memory (weights are L1/L2 resident).
 __global__ __launch_bounds__(256) void up2x2_kernel(UpArgs a) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int64_t p0 = (int64_t)blockIdx.x * NT + wv * 64;
     const int co0 = blockIdx.y * 64;
-    const int tap = blockIdx.z;
-    int64_t ioff[2], ooff[2];
-    bool in[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int64_t p = p0 + n * 32 + l31;
-        in[n] = interior(a.gi, p);
-        ioff[n] = a.gi.sl + (in[n] ? p : 0);
-        ooff[n] = 0;
-        if (in[n]) {
-            const int64_t b = p / a.gi.plane;
-            const int pi = (int)(p - b * a.gi.plane);
-            const int r = pi / a.gi.wp, c = pi - r * a.gi.wp;
-            ooff[n] = a.go.sl + b * a.go.plane + (int64_t)(2 * (r - 1) + (tap >> 1) + 1) * a.go.wp + (2 * (c - 1) + (tap & 1) + 1);
-        }
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int64_t p = (int64_t)blockIdx.x * 128 + wv * 32 + l31;
+    const bool in = interior(a.gi, p);
     const int ncb = a.cin / 8;
-    float4 a00, a01, b00, b01, a10, a11, b10, b11;
-#define DINV_LOAD_GROUP(CB, A0, A1, B0, B1)                                                                      \
-    {                                                                                                           \
-        const float* wt_ = a.w + (((int64_t)tap * ncb + (CB)) * a.cout + co0 + l31) * 8 + 4 * lhi;              \
-        A0 = ld4(wt_); A1 = ld4(wt_ + 32 * 8);                                                                  \
-        const int64_t o0_ = ((int64_t)(CB) * a.gi.cs + ioff[0]) * 8 + 4 * lhi;                                  \
-        const int64_t o1_ = ((int64_t)(CB) * a.gi.cs + ioff[1]) * 8 + 4 * lhi;                                  \
-        B0 = ld4(a.x + o0_); B1 = ld4(a.x + o1_);                                                               \
-        if (a.x2) { B0 = add4(B0, ld4(a.x2 + o0_)); B1 = add4(B1, ld4(a.x2 + o1_)); }                           \
+    // per-lane byte offsets inside one channel block (buffer addressing: SGPR base + 32-bit lane offset)
+    const uint32_t xoff = (uint32_t)((a.gi.sl + (in ? p : 0)) * 32 + 16 * lhi);
+    const uint32_t woff = (uint32_t)((co0 + l31) * 32 + 16 * lhi);
+    uint32_t yoff = 0xffffffffu;   // out of range: the stores of border lanes are dropped
+    if (in) {
+        const int64_t b = p / a.gi.plane;
+        const int pi = (int)(p - b * a.gi.plane);
+        const int r = pi / a.gi.wp, c = pi - r * a.gi.wp;
+        yoff = (uint32_t)((a.go.sl + b * a.go.plane + (int64_t)(2 * (r - 1) + 1) * a.go.wp + (2 * (c - 1) + 1)) * 32 + 16 * lhi);
     }
-    DINV_LOAD_GROUP(0, a00, a01, b00, b01)
+    auto bld = [](const float* sbase, uint32_t off) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, 0xffffffff, 0x00020000);
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
+    float4 A0[4][2], A1[4][2], B0, B1;
+#define DINV_LOAD_GROUP(CB, A, B)                                                                               \
+    {                                                                                                           \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                         \
+            const float* wt_ = a.w + ((int64_t)t * ncb + (CB)) * a.cout * 8;                                    \
+            A[t][0] = bld(wt_, woff); A[t][1] = bld(wt_, woff + 32 * 32);                                       \
+        }                                                                                                       \
+        B = bld(a.x + (int64_t)(CB) * a.gi.cs * 8, xoff);                                                       \
+        if (a.x2) B = add4(B, bld(a.x2 + (int64_t)(CB) * a.gi.cs * 8, xoff));                                   \
+    }
+#define DINV_MMA_GROUP(A, B)                                                                                    \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                               \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                             \
+        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(A[t][0], s), comp(B, s), acc[t][0], 0, 0, 0);     \
+        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(A[t][1], s), comp(B, s), acc[t][1], 0, 0, 0);     \
+    }
+    DINV_LOAD_GROUP(0, A0, B0)
     for (int cb = 0; cb < ncb; cb += 2) {
-        if (cb + 1 < ncb) DINV_LOAD_GROUP(cb + 1, a10, a11, b10, b11)
-        DINV_MMA_GROUP(a00, a01, b00, b01)
-        if (cb + 2 < ncb) DINV_LOAD_GROUP(cb + 2, a00, a01, b00, b01)
-        if (cb + 1 < ncb) DINV_MMA_GROUP(a10, a11, b10, b11)
+        if (cb + 1 < ncb) DINV_LOAD_GROUP(cb + 1, A1, B1)
+        DINV_MMA_GROUP(A0, B0)
+        if (cb + 2 < ncb) DINV_LOAD_GROUP(cb + 2, A0, B0)
+        if (cb + 1 < ncb) DINV_MMA_GROUP(A1, B1)
     }
 #undef DINV_LOAD_GROUP
 #undef DINV_MMA_GROUP
+    // lane holds co = co0 + 32 m + 8 rj + 4 lhi + (0..3) in registers 4 rj .. 4 rj + 3 of acc[t][m]
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        if (!in[n]) continue;
-        store_tile<2, false, 0>(acc, n, ooff[n], true, co0 / 8, a.cout / 8, a.go.cs, lhi, a.y, nullptr, nullptr);
-    }
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int rj = 0; rj < 4; ++rj) {
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+                a.y + (int64_t)(co0 / 8 + m * 4 + rj) * a.go.cs * 8, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t o = yoff == 0xffffffffu ? yoff : yoff + (uint32_t)(((t >> 1) * a.go.wp + (t & 1)) * 32);
+                typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                const float4 v = make_float4(acc[t][m][4 * rj], acc[t][m][4 * rj + 1], acc[t][m][4 * rj + 2], acc[t][m][4 * rj + 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yr, o, 0, 0);
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -426,7 +446,7 @@ extern "C" int dinv_conv_up2x2(const dinv_act_geom* gin, const dinv_act_geom* go
                  "up2x2 geometry mismatch");
     DINV_REQUIRE(cin % 8 == 0 && cout % 64 == 0, "up2x2 needs cin %% 8 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
     UpArgs a{make_geom(*gin), make_geom(*gout), x, x2, w, y, cin, cout};
-    hipLaunchKernelGGL(up2x2_kernel, dim3((unsigned)ceil_div(gin->np, NT), cout / 64, 4), dim3(256), 0,
+    hipLaunchKernelGGL(up2x2_kernel, dim3((unsigned)ceil_div(gin->np, 128), cout / 64), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     DINV_CHECK_LAUNCH();
     return 0;
