@@ -445,6 +445,8 @@ extern "C" int dinv_conv_up2x2(const dinv_act_geom* gin, const dinv_act_geom* go
     DINV_REQUIRE(gout->height == 2 * gin->height && gout->width == 2 * gin->width && gin->batch == gout->batch,
                  "up2x2 geometry mismatch");
     DINV_REQUIRE(cin % 8 == 0 && cout % 64 == 0, "up2x2 needs cin %% 8 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
+    DINV_REQUIRE(gout->cs * 32 < (1ll << 32) && (int64_t)cout * 32 < (1ll << 31),
+                 "up2x2: one channel block must stay below 4 GB (32-bit buffer offsets)");
     UpArgs a{make_geom(*gin), make_geom(*gout), x, x2, w, y, cin, cout};
     hipLaunchKernelGGL(up2x2_kernel, dim3((unsigned)ceil_div(gin->np, 128), cout / 64), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);

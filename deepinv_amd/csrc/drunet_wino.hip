@@ -530,6 +530,7 @@ extern "C" int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, con
     DINV_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= 64 && cout % 64 == 0,
                  "winograd conv needs cin %% 8 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
     DINV_REQUIRE(!(relu && res1), "relu and residual are not combined in DRUNet");
+    DINV_REQUIRE(g->cs * 32 < (1ll << 32), "winograd conv: one channel block must stay below 4 GB (32-bit buffer offsets)");
     WinoArgs a{};
     a.g = make_geom(*g);
     a.x = x; a.w = w_wino; a.y = y; a.res = res1;

@@ -55,7 +55,10 @@ def test_drunet_unsafe_shapes(dev):
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 64, 64, 64, 64), (3, 40, 40, 128, 128), (1, 80, 80, 64, 128),
                                               (2, 20, 20, 512, 512), (1, 37, 51, 64, 64), (5, 10, 10, 64, 64),
-                                              (1, 320, 320, 64, 64)])
+                                              (1, 320, 320, 64, 64),
+                                              # odd / single channel-block counts, one-pixel images, many tiny images
+                                              (1, 24, 40, 24, 64), (2, 16, 16, 8, 64), (3, 1, 1, 64, 64), (70, 4, 6, 16, 128),
+                                              (1, 2, 330, 64, 64)])
 @pytest.mark.parametrize("mode", ["plain", "relu", "res"])
 def test_winograd_conv_matches_fp32_conv(dev, B, H, W, cin, cout, mode):
     """Winograd F(2x2,3x3) ResBlock convolution against torch's fp32 conv2d of the same op (tolerance 1e-5:
