@@ -341,6 +341,40 @@ __global__ __launch_bounds__(256) void up2x2_kernel(UpArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Last layer (m_tail, drunet.py:39-101: nc[0] -> image channels, input = x + skip).  With 1-4 output channels the
+// 32-row MFMA tile computes 8-16x more than needed (measured 1.12 ms); here one lane produces one pixel x COUT
+// channels on the vector ALU; weights are wave-uniform (scalar loads), the 9 taps of neighbouring lanes hit L1.
+template <int COUT>
+__global__ __launch_bounds__(256) void tail3x3_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ x2,
+                                                      const float* __restrict__ w, float* __restrict__ y, int ncb) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one pixel per lane: neighbours share cache lines
+    if (p >= g.np) return;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const int64_t base = ((int64_t)cb * g.cs + g.sl + p) * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int64_t o = base + ((int64_t)(t / 3 - 1) * g.wp + (t % 3 - 1)) * 8;
+            float4 a = ld4(x + o), b = ld4(x + o + 4);
+            if (x2) { a = add4(a, ld4(x2 + o)); b = add4(b, ld4(x2 + o + 4)); }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float* wv = w + (((int64_t)cb * 9 + t) * COUT + co) * 8;   // uniform: scalar loads
+                acc[co] += a.x * wv[0] + a.y * wv[1] + a.z * wv[2] + a.w * wv[3] + b.x * wv[4] + b.y * wv[5] +
+                           b.z * wv[6] + b.w * wv[7];
+            }
+        }
+    }
+    if (!interior(g, p)) return;   // the zero frame is never written
+    float o4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) o4[co] = acc[co];
+    st4(y + (g.sl + p) * 8, make_float4(o4[0], o4[1], o4[2], o4[3]));
+}
+
+// ---------------------------------------------------------------------------------------
 // NCHW <-> blocked padded rows.  pack also writes the noise-level map channel (drunet.py:238-251:
 // x = cat(x, sigma map)); one thread per pixel writes the whole first channel block (cin+1 <= 8).
 __global__ void pack_kernel(Geom g, const float* __restrict__ x, int cin, const float* __restrict__ sigma,
@@ -417,6 +451,24 @@ extern "C" int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float*
         if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }
         else      { if (nres == 0) DINV_LAUNCH_C3(false, 0); else if (nres == 1) DINV_LAUNCH_C3(false, 1); else DINV_LAUNCH_C3(false, 2); }
 #undef DINV_LAUNCH_C3
+    }
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const float* x2, const float* w_tail,
+                                 int32_t cin, int32_t cout, float* y, dinv_stream_t stream) {
+    if (int e = check_geom(g)) return e;
+    DINV_REQUIRE(x && w_tail && y, "null tensor pointer");
+    DINV_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= 1 && cout <= 4, "tail conv needs cin %% 8 == 0 and 1 <= cout <= 4 (got %d,%d)", cin, cout);
+    const dim3 grid((unsigned)ceil_div(g->np, 256)), block(256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const Geom gg = make_geom(*g);
+    switch (cout) {
+        case 1: hipLaunchKernelGGL(tail3x3_kernel<1>, grid, block, 0, st, gg, x, x2, w_tail, y, cin / 8); break;
+        case 2: hipLaunchKernelGGL(tail3x3_kernel<2>, grid, block, 0, st, gg, x, x2, w_tail, y, cin / 8); break;
+        case 3: hipLaunchKernelGGL(tail3x3_kernel<3>, grid, block, 0, st, gg, x, x2, w_tail, y, cin / 8); break;
+        default: hipLaunchKernelGGL(tail3x3_kernel<4>, grid, block, 0, st, gg, x, x2, w_tail, y, cin / 8); break;
     }
     DINV_CHECK_LAUNCH();
     return 0;

@@ -29,6 +29,7 @@ def _l():
         l.dinv_act_pack.argtypes = [G, vp, i32, vp, i32, f32, vp, vp]
         l.dinv_act_unpack.argtypes = [G, vp, i32, vp, vp]
         l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+        l.dinv_conv3x3_tail.argtypes = [G, vp, vp, vp, i32, i32, vp, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
@@ -58,6 +59,14 @@ def pack_conv3x3_weight(w: torch.Tensor, mt: int | None = None) -> tuple[torch.T
     wp[:cout, :cin] = w.detach().float()
     wp = wp.reshape(cout_p // mt, mt, cin_p // 8, 8, 9).permute(0, 2, 4, 1, 3).contiguous()
     return wp, cin_p, cout_p
+
+
+def pack_tail_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout<=4, Cin, 3, 3] -> [Cin/8][9 taps][Cout][8] for conv3x3_tail"""
+    cout, cin = w.shape[:2]
+    if cout > 4 or cin % 8:
+        raise ValueError(f"tail packing needs cout <= 4 and cin % 8 == 0, got {cout},{cin}")
+    return w.detach().float().reshape(cout, cin // 8, 8, 9).permute(1, 3, 0, 2).contiguous()
 
 
 def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
@@ -150,6 +159,11 @@ def conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=N
 def _conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=None, relu=False):
     check(_l().dinv_conv3x3(ctypes.byref(g), ptr(x), ptr(x2), ptr(wpk), cin, cout, cout if cout_valid is None else cout_valid,
                             int(wpk.shape[3]), ptr(y), ptr(res1), ptr(res2), int(relu), stream_ptr(y.device)))
+
+
+def conv3x3_tail(g, x, wtail, cin, cout, y, x2=None):
+    """last layer on the vector ALU: y[:cout] = conv3x3(x (+x2)); wtail from pack_tail_weight"""
+    check(_l().dinv_conv3x3_tail(ctypes.byref(g), ptr(x), ptr(x2), ptr(wtail), cin, cout, ptr(y), stream_ptr(y.device)))
 
 
 def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):

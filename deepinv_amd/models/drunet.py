@@ -185,6 +185,8 @@ class DRUNet(Denoiser):
 
         e["head"] = c3(self.m_head)
         e["tail"] = c3(self.m_tail)
+        wt = self.m_tail.weight
+        e["tail_valu"] = K.pack_tail_weight(wt.to(device)) if (wt.shape[0] <= 4 and wt.shape[1] % 8 == 0) else None
         for name in ("m_down1", "m_down2", "m_down3"):
             seq = getattr(self, name)
             e[name] = [(c3(b.res[0]), c3(b.res[2])) for b in list(seq)[:-1]]
@@ -276,8 +278,11 @@ class DRUNet(Denoiser):
             # t{i} holds the up-conv output; run the ResBlocks with a/b ping-pong and a fresh temporary
             r = self._res_chain_from_t(g[i], e[name], ws[f"t{i}"], ws[f"a{i}"], ws[f"b{i}"])
             skip_add = ws[f"skip{i}"]
-        (wt, cit, cot) = self._pick(g[0], e["tail"])
-        K.conv3x3(g[0], r, wt, cit, cot, ws["out"], cout_valid=self.out_channels, x2=ws["skip0"])  # m_tail(x + x1)
+        if e["tail_valu"] is not None:   # m_tail(x + x1)
+            K.conv3x3_tail(g[0], r, e["tail_valu"], nc[0], self.out_channels, ws["out"], x2=ws["skip0"])
+        else:
+            (wt, cit, cot) = self._pick(g[0], e["tail"])
+            K.conv3x3(g[0], r, wt, cit, cot, ws["out"], cout_valid=self.out_channels, x2=ws["skip0"])
         y = torch.empty((B, self.out_channels, H, W), device=dev, dtype=torch.float32)
         K.unpack_output(g[0], ws["out"], self.out_channels, y)
         return y

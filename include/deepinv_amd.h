@@ -134,6 +134,11 @@ int dinv_act_unpack(const dinv_act_geom* g, const float* act, int32_t cout, floa
 int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float* x2, const float* w_packed,
                  int32_t cin, int32_t cout, int32_t cout_valid, int32_t cout_tile, float* y, const float* res1,
                  const float* res2, int32_t relu, dinv_stream_t stream);
+/* Last DRUNet layer: y[first channel block, channels 0..cout-1] = conv3x3(x (+x2)), 1 <= cout <= 4, stride 1,
+ * zero padding 1, no bias (m_tail, drunet.py:39-101, input x + x1 at :210), on the vector ALU (HBM-bound).
+ * w_tail: [cin/8][9 taps][cout][8]; cin % 8 == 0. */
+int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const float* x2, const float* w_tail, int32_t cin,
+                      int32_t cout, float* y, dinv_stream_t stream);
 /* Same operator as dinv_conv3x3 (no x2, one optional residual) through Winograd F(2x2,3x3): 2.25x fewer MFMA
  * flops, results equal up to fp32 rounding of the transforms (~1e-6 relative).
  * w_wino: U = G g G^T per (cout, cin), packed [cout/64][cin/8][ci 8][co 64][16]; cin % 8 == 0, cout % 64 == 0;
