@@ -33,6 +33,45 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
     out[blockIdx.x * NT + threadIdx.x] = s;
 }
 
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+// same experiment with the bf16 matrix core (v_mfma_f32_32x32x16_bf16, 8 passes = 32 cycles): does VALU hide there?
+template <int NV, int NT = 256>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT / 256))) void kb(float* out, int iters) {
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(threadIdx.x + i); b[i] = (short)(0x3f80); }
+    float f[8], c = 1.0f;
+    for (int i = 0; i < 8; ++i) f[i] = threadIdx.x + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[m]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int v = 0; v < NV; ++v) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[v % 8]) : "v"(c));
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += f[i] + acc[i][0] + acc[i][7];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+}
+template <int NV, int NT = 256>
+void runb(const char* name, float* d) {
+    const int iters = 4000, blocks = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    kb<NV, NT><<<blocks, NT>>>(d, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kb<NV, NT><<<blocks, NT>>>(d, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("bf16 %-22s NV=%2d waves/simd=%d : %.1f ns per MFMA per SIMD (32 cyc @2.4GHz = 13.3 ns)\n", name, NV, NT / 256,
+           ms * 1e6 / (iters * 8.0 * (NT / 256)));
+}
+
 template <int NV, int NL, bool AGPR, int NT = 256>
 void run(const char* name, float* d) {
     const int iters = 2000, blocks = 256;
@@ -72,5 +111,12 @@ int main() {
     run<8, 1, true, 512>("2w: mfma + 8 valu + 1 ds", d);
     run<8, 0, true, 1024>("4w: mfma + 8 valu", d);
     run<16, 0, true, 1024>("4w: mfma + 16 valu", d);
+    runb<0>("mfma only", d);
+    runb<2>("mfma + 2 valu", d);
+    runb<4>("mfma + 4 valu", d);
+    runb<8>("mfma + 8 valu", d);
+    runb<0, 512>("2w: mfma only", d);
+    runb<4, 512>("2w: mfma + 4 valu", d);
+    runb<8, 512>("2w: mfma + 8 valu", d);
     return 0;
 }
