@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
+WINO_PMC_TRAFFIC = 1.4675e9   # bytes per conv3x3_wino_kernel launch, B=32 320x320 (see roofline below)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s dense fp32 matrix (v_mfma_f32_32x32x2_f32)
 
 
@@ -158,7 +159,12 @@ def main():
             # separately as the effective rate of all 3x3 convs (it may exceed the fp32 MFMA peak).
             "roofline": {"bound": "mfma", "kernel": kname + " (DRUNet 3x3 conv, v_mfma_f32_32x32x2_f32)",
                          "achieved": round(achieved / 1e12, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_F32_PEAK, 4),
+                         # HBM bytes per launch from separate PMC passes (profiles/pmc/r01_drunet_{rdreq,wrreq}.csv:
+                         # TCC_EA0_RDREQ x 64 B x 2 (gfx950 wide-load correction) + TCC_EA0_WRREQ x 64 B, averaged
+                         # over the 56 Winograd launches of one DRUNet call at this configuration); algorithmic
+                         # bytes are ~1.1e9 (activations in + out + residual, weights): the kernel is MFMA-bound
+                         "traffic": WINO_PMC_TRAFFIC if (B_local == 32 and H == 320 and W == 320) else None,
                          "launches": kp["launches"] if kp else 0,
                          "avg_launch_ms": round(kp["ms"] / max(kp["launches"], 1), 4) if kp else 0.0,
                          "share_of_step": round(kp["ms"] * 1e-3 / elapsed, 4) if kp else 0.0,
