@@ -31,3 +31,4 @@ def test_required_top_level_files():
     for name in ("bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/deepinv_amd.h",
                  "oracle/__init__.py", "tests/golden/make_golden.py"):
         assert os.path.exists(os.path.join(ROOT, name)), name
+
