@@ -16,8 +16,12 @@
 //   of V = B^T d B needs only two rows of the patch: 8 ds_read_b128 + 16 FMAs + 16 adds feed 32 MFMAs per
 //   8-channel block (1 VALU per MFMA; the all-points-per-wave layout needs 4).
 // * Per 8-channel block the raw input region (zero border included, so no edge cases) and the 32 KB slice of U
-//   are staged in LDS, double buffered, one barrier per block; the staging registers always hold loads issued
-//   a full block earlier, invalid pixels are redirected to a zero border pixel (no selects).
+//   are staged global -> registers -> LDS, double buffered, one LDS-only barrier per block; the 6 ds_write_b128
+//   per wave are spread over the block (U parts 0-2 run one block ahead, U part 3 and the pixels two blocks
+//   ahead), every staging register holds a load issued a full block earlier; buffer loads with SGPR bases (no
+//   address VALU); invalid pixels are redirected to a zero border pixel (no selects).
+// * Persistent workgroups (one per CU, 32 per XCD walking a contiguous range of the tile order); the next tile's
+//   first loads are issued as soon as the accumulators are dead.
 // * The 64 positions of a workgroup are NSUB rectangles of TH x TW tiles enumerated over (batch, tile rows,
 //   tile cols), so the 40x40 and 80x80 levels fill the MFMA columns as well as 320x320 does.
 // * Epilogue: each wave reduces its row to s = M A (2 values), the four row-waves exchange s through LDS and
@@ -85,8 +89,8 @@ struct Shape {
     static_assert(PT <= 64 && 64 % PT == 0, "rectangle must divide the 64 positions");
 };
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory: it drains the
-// in-flight residual loads and output stores (measured 1-2.3k cycles per tile with s_memtime stamps).
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also fences global memory, i.e. it would wait for
+// the in-flight staging / residual loads and the output stores, which are meant to overlap the next phase.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -172,10 +176,6 @@ void conv3x3_wino_kernel(WinoArgs a) {
 #else
 #define DINV_STAMP(i) do { } while (0)
 #endif
-#define DINV_MFMA8(U, V)                                                                                         \
-    _Pragma("unroll") for (int c2_ = 0; c2_ < 2; ++c2_)                                                          \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                             \
-        acc[c2_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(U[c2_], j_), V[j_], acc[c2_][j_], 0, 0, 0)
 #define DINV_MFMA2(U, V, c2_, j0_)                                                                              \
     do {                                                                                                         \
         acc[c2_][j0_] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(U[c2_], j0_), V[j0_], acc[c2_][j0_], 0, 0, 0); \
@@ -353,7 +353,6 @@ void conv3x3_wino_kernel(WinoArgs a) {
             }
         }
     }
-#undef DINV_MFMA8
 #undef DINV_MFMA2
 #undef DINV_VCALC
 #undef DINV_COL
