@@ -190,13 +190,20 @@ struct DownArgs {
     const float* w;  // [4][cin/8][cout][8]
     float* y;        // [cout/8][go.cs][8]
     int32_t cin, cout;
+    int64_t ntiles, per_xcd;   // workgroups, and workgroups per XCD of the XCD-aware order
 };
 
 __global__ __launch_bounds__(256) void down2x2_kernel(DownArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int64_t q0 = (int64_t)blockIdx.x * NT + wv * 64;
-    const int co0 = blockIdx.y * 64;
+    // Consecutive block ids go to different XCDs.  Give each XCD a contiguous range of the (pixel tile, cout tile)
+    // order with the cout tile fastest, so the cout/64 workgroups that read the same input pixels run next to each
+    // other on one L2 instead of fetching them cout/64 times from HBM.
+    const int64_t logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.ntiles) return;
+    const int nct = a.cout / 64;
+    const int64_t q0 = (logical / nct) * NT + wv * 64;
+    const int co0 = (int)(logical % nct) * 64;
     int64_t ioff[2];
     bool in[2];
 #pragma unroll
@@ -482,8 +489,10 @@ extern "C" int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* 
     DINV_REQUIRE(gin->height == 2 * gout->height && gin->width == 2 * gout->width && gin->batch == gout->batch,
                  "down2x2 geometry mismatch");
     DINV_REQUIRE(cin % 8 == 0 && cout % 64 == 0, "down2x2 needs cin %% 8 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
-    DownArgs a{make_geom(*gin), make_geom(*gout), x, w, y, cin, cout};
-    hipLaunchKernelGGL(down2x2_kernel, dim3((unsigned)ceil_div(gout->np, NT), cout / 64), dim3(256), 0,
+    DownArgs a{make_geom(*gin), make_geom(*gout), x, w, y, cin, cout, 0, 0};
+    a.ntiles = ceil_div(gout->np, NT) * (cout / 64);
+    a.per_xcd = ceil_div(a.ntiles, 8);
+    hipLaunchKernelGGL(down2x2_kernel, dim3((unsigned)(a.per_xcd * 8)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     DINV_CHECK_LAUNCH();
     return 0;
