@@ -135,14 +135,20 @@ void conv3x3_wino_kernel(WinoArgs a) {
         const int sb = px / (2 * S::RW2 * S::RH);
         loff[i] = WLDS + (((sb * S::RH + r) * 2 + (c & 1)) * S::RW2 + (c >> 1)) * RP + half * 4;
     }
-    uint32_t goff[S::NLD];      // byte offsets inside one channel block of x
-    const float* wsrc;          // packed U of the tile's cout block (+ tid*16 bytes per lane)
-    int ct;                     // tile coordinates: cout block, position group
-    uint32_t pw;
-    auto describe = [&](int64_t logical) {
-        pw = a.d_nct.div((uint32_t)logical);
-        ct = (int)((uint32_t)logical - (uint32_t)pw * (uint32_t)a.nct);
-        wsrc = a.w + (int64_t)ct * a.ncb * 8192;
+    // current tile (no suffix) and next tile of this workgroup (suffix n)
+    uint32_t goff[S::NLD], goffn[S::NLD];   // byte offsets inside one channel block of x
+    const float *wsrc, *wsrcn;              // packed U of the tile's cout block (+ tid*16 bytes per lane)
+    int ct, ctn;                            // tile coordinates: cout block, position group
+    uint32_t pw, pwn;
+    auto advance = [&]() {                  // next -> current
+        ct = ctn; pw = pwn; wsrc = wsrcn;
+#pragma unroll
+        for (int i = 0; i < S::NLD; ++i) goff[i] = goffn[i];
+    };
+    auto describe = [&](int64_t logical) {  // fills the "next" set
+        pwn = a.d_nct.div((uint32_t)logical);
+        ctn = (int)((uint32_t)logical - (uint32_t)pwn * (uint32_t)a.nct);
+        wsrcn = a.w + (int64_t)ctn * a.ncb * 8192;
         int t = tid;
         asm volatile("" : "+v"(t));   // recompute the per-lane constants per tile instead of keeping them live
 #pragma unroll
@@ -152,14 +158,14 @@ void conv3x3_wino_kernel(WinoArgs a) {
             const int c = px % (2 * S::RW2);
             const int r = (px / (2 * S::RW2)) % S::RH;
             const int sb = px / (2 * S::RW2 * S::RH);
-            const uint32_t s = (uint32_t)pw * S::NSUB + sb;
+            const uint32_t s = (uint32_t)pwn * S::NSUB + sb;
             const uint32_t b = a.d_img.div(s);
             const uint32_t rem = s - b * (uint32_t)per_img;
             const uint32_t tyb = a.d_ntx.div(rem), txb = rem - tyb * a.ntx;
             const int gr = 2 * tyb * TH + r, gc = 2 * txb * TW + c;
             const bool ok = e < S::RAW4 && s < (uint32_t)a.nsr && gr < a.g.hp && gc < a.g.wp;
             // out-of-frame pixels read the (always zero) top-left border pixel of image 0 instead
-            goff[i] = 4u * (ok ? (uint32_t)((a.g.sl + (int64_t)b * a.g.plane + (int64_t)gr * a.g.wp + gc) * 8 + half * 4)
+            goffn[i] = 4u * (ok ? (uint32_t)((a.g.sl + (int64_t)b * a.g.plane + (int64_t)gr * a.g.wp + gc) * 8 + half * 4)
                               : (uint32_t)(a.g.sl * 8));
         }
     };
@@ -214,39 +220,52 @@ void conv3x3_wino_kernel(WinoArgs a) {
     // ---- Staging parts: W0..W3 (weight float4s) and R0,R1 (pixels).  In steady state W0-W2 run one block ahead
     // (written to LDS in steps 0/1) and W3,R0,R1 two blocks ahead (written in steps 2/3, when the current buffer
     // is already dead), so the 6 ds_write_b128 per wave are spread over the whole block.
-    float4 w3x, r1x[S::NLD];    // block 1's W3 / R parts of the tile being entered
-    auto first_loads = [&]() {  // everything the first barrier of a tile needs, straight from the descriptors
+    // State at a tile's entry: pwt[0..2] = block 0 U parts 0-2, (w3x, r1x) = block 0 U part 3 + pixels,
+    // (pwt[3], pr) = block 1 U part 3 + pixels.  Produced by first_loads() or by the last blocks of the previous tile.
+    float4 w3x, r1x0, r1x1;
+    static_assert(S::NLD <= 2, "staging assumes at most two pixel float4s per thread");
+    auto first_loads = [&]() {
         const int c1 = a.ncb > 1 ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fetch_w(0, i);
+        for (int i = 0; i < 3; ++i) fetch_w(0, i);
+        w3x = ld4_so(wsrc + 3 * 2048, (uint32_t)tid * 16u);
+        r1x0 = ld4_so(a.x, goff[0]);
+        if (S::NLD > 1) r1x1 = ld4_so(a.x, goff[S::NLD - 1]);
+        fetch_w(c1, 3);
 #pragma unroll
-        for (int i = 0; i < S::NLD; ++i) fetch_r(0, i);
-        w3x = ld4_so(wsrc + (int64_t)c1 * 8192 + 3 * 2048, (uint32_t)tid * 16u);
-#pragma unroll
-        for (int i = 0; i < S::NLD; ++i) r1x[i] = ld4_so(a.x + c1 * xcs, goff[i]);
+        for (int i = 0; i < S::NLD; ++i) fetch_r(c1, i);
     };
 
     int64_t jt = bid >> 3;
     if (jt >= a.per_xcd || (bid & 7) * a.per_xcd + jt >= a.nwg) return;
     describe((bid & 7) * a.per_xcd + jt);
+    advance();
     first_loads();
     for (;;) {
     DINV_STAMP(0);
+    // the next tile of this workgroup: its first loads are issued from the last three blocks of this tile (peeled
+    // below: no branch in the steady-state loop)
+    const bool more = jt + a.slots < a.per_xcd && (bid & 7) * a.per_xcd + jt + a.slots < a.nwg;
+    // (the last tile of a workgroup "prefetches" itself again: valid addresses, unused data, no second code path)
+    describe((bid & 7) * a.per_xcd + jt + (more ? a.slots : 0));
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c2][j][r] = 0.f;
-    {   // ---- tile prologue: the loads were issued before the previous tile's epilogue
+    {   // ---- tile prologue: stage the entry state, re-issue for blocks 1 and 2
         const int c1 = a.ncb > 1 ? 1 : 0, c2b = a.ncb > 2 ? 2 : a.ncb - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stash_w(lds, i);
+        for (int i = 0; i < 3; ++i) stash_w(lds, i);
+        st4(lds + woff + 3 * 128 * WP, w3x);
+        stash_w(lds + S::BUF, 3);
+#pragma unroll
+        for (int i = 0; i < S::NLD; ++i) stash_r(lds + S::BUF, i);
+        pr[0] = r1x0;
+        if (S::NLD > 1) pr[S::NLD - 1] = r1x1;
 #pragma unroll
         for (int i = 0; i < S::NLD; ++i) stash_r(lds, i);
-        st4(lds + S::BUF + woff + 3 * 128 * WP, w3x);
-#pragma unroll
-        for (int i = 0; i < S::NLD; ++i) { pr[i] = r1x[i]; stash_r(lds + S::BUF, i); }
 #pragma unroll
         for (int i = 0; i < 3; ++i) fetch_w(c1, i);
         fetch_w(c2b, 3);
@@ -264,8 +283,11 @@ void conv3x3_wino_kernel(WinoArgs a) {
     //   step 1: read U(m=2), U(m=3); V(m=2); same for the staged input pixels;   barrier
     //   step 2: V(m=3); read the two patch rows of block cb+1
     //   step 3: row xr of B^T d for block cb+1; read U(cb+1, m=0); V(cb+1, m=0)
-    auto block = [&](int cb, auto parity_tag, float4 (&u0)[2], float4 (&u0n)[2]) {
+    // rel_tag: 0 = steady state; 3, 2, 1 = third-last ... last block of a tile whose successor's first loads are
+    // issued from here (compile-time variants, peeled behind the loop)
+    auto block = [&](int cb, auto parity_tag, auto rel_tag, float4 (&u0)[2], float4 (&u0n)[2]) {
         constexpr int PAR = decltype(parity_tag)::value;   // cb & 1, compile time: LDS addresses fold to immediates
+        constexpr int REL = decltype(rel_tag)::value;
         const float* cur = lds + PAR * S::BUF;
         float* nxt = lds + (1 - PAR) * S::BUF;
         const int cb2 = cb + 2 < a.ncb ? cb + 2 : a.ncb - 1;   // re-issued loads past the end re-read the last block
@@ -283,8 +305,13 @@ void conv3x3_wino_kernel(WinoArgs a) {
         DINV_MFMA2(u0, vA, 0, 2); DINV_SB();
         DINV_VCALC(vB, tc[1]); DINV_SB();
         DINV_MFMA2(u0, vA, 1, 0); DINV_SB();
-        stash_w(nxt, 0); stash_w(nxt, 1);
-        fetch_w(cb2, 0); fetch_w(cb2, 1); DINV_SB();
+        if (REL != 1) { stash_w(nxt, 0); stash_w(nxt, 1); }
+        if (REL == 2) {          // block ncb: the next tile's block 0
+            pwt[0] = ld4_so(wsrcn, (uint32_t)tid * 16u); pwt[1] = ld4_so(wsrcn + 2048, (uint32_t)tid * 16u);
+        } else if (REL != 1) {
+            fetch_w(cb2, 0); fetch_w(cb2, 1);
+        }
+        DINV_SB();
         DINV_MFMA2(u0, vA, 1, 2); DINV_SB();
         if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 1);
         // ---- step 1 (m = 1)
@@ -294,8 +321,10 @@ void conv3x3_wino_kernel(WinoArgs a) {
         DINV_MFMA2(uB, vB, 0, 2); DINV_SB();
         DINV_VCALC(vA, tc[2]); DINV_SB();
         DINV_MFMA2(uB, vB, 1, 0); DINV_SB();
-        stash_w(nxt, 2);
-        fetch_w(cb2, 2); DINV_SB();
+        if (REL != 1) stash_w(nxt, 2);
+        if (REL == 2) pwt[2] = ld4_so(wsrcn + 2 * 2048, (uint32_t)tid * 16u);
+        else if (REL != 1) fetch_w(cb2, 2);
+        DINV_SB();
         DINV_MFMA2(uB, vB, 1, 2); DINV_SB();
         if (cb == 2 || cb == 3) DINV_STAMP(8 + (cb - 2) * 8 + 2);
         lds_barrier();
@@ -311,8 +340,13 @@ void conv3x3_wino_kernel(WinoArgs a) {
         DINV_MFMA2(uE, vA, 0, 2); DINV_SB();
         DINV_VCALC(vB, tc[3]); DINV_SB();     // last use of this block's tc: it is overwritten in place below
         DINV_MFMA2(uE, vA, 1, 0); DINV_SB();
-        stash_w(curw, 3); stash_r(curw, 0);     // block cb+2: this buffer's block cb is dead behind the barrier
-        fetch_w(cb3, 3); fetch_r(cb3, 0); DINV_SB();
+        // block cb+2's U part 3 + pixels: this buffer's block cb is dead behind the barrier
+        if (REL == 0 || REL == 3) { stash_w(curw, 3); stash_r(curw, 0); }
+        if (REL == 2) { w3x = pwt[3]; r1x0 = pr[0]; }      // they are the next tile's block 0 parts: park them
+        if (REL == 0) { fetch_w(cb3, 3); fetch_r(cb3, 0); }
+        if (REL == 3) { pwt[3] = ld4_so(wsrcn + 3 * 2048, (uint32_t)tid * 16u); pr[0] = ld4_so(a.x, goffn[0]); }
+        if (REL == 2) { pwt[3] = ld4_so(wsrcn + 8192 + 3 * 2048, (uint32_t)tid * 16u); pr[0] = ld4_so(a.x + xcs, goffn[0]); }
+        DINV_SB();
         DINV_MFMA2(uE, vA, 1, 2); DINV_SB();
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -331,27 +365,33 @@ void conv3x3_wino_kernel(WinoArgs a) {
             for (int j = 0; j < 2; ++j) tc[m][2 + j] = fmaf(comp(dB[j], m), sigma, comp(dA[j], m));
         DINV_VCALC(vA, tc[0]); DINV_SB();
         DINV_MFMA2(uC, vB, 1, 0); DINV_SB();
-        if (S::NLD > 1) { stash_r(curw, S::NLD - 1); fetch_r(cb3, S::NLD - 1); }
+        if (S::NLD > 1) {
+            if (REL == 0 || REL == 3) stash_r(curw, S::NLD - 1);
+            if (REL == 2) r1x1 = pr[S::NLD - 1];
+            if (REL == 0) fetch_r(cb3, S::NLD - 1);
+            if (REL == 3) pr[S::NLD - 1] = ld4_so(a.x, goffn[S::NLD - 1]);
+            if (REL == 2) pr[S::NLD - 1] = ld4_so(a.x + xcs, goffn[S::NLD - 1]);
+        }
         DINV_SB();
         DINV_MFMA2(uC, vB, 1, 2); DINV_SB();
 #undef DINV_SB
     };
     {
         // two blocks per trip so the register state returns to the same names (no copies on the back edge) and
-        // the LDS buffer parity is a compile-time constant.  The last block also stages/reads a (clamped,
-        // unused) "next" block: one block of redundant fillers is cheaper than a second code path.
+        // the LDS buffer parity is a compile-time constant
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
+        using R0 = std::integral_constant<int, 0>;
+        // steady-state pairs, then the last four blocks peeled (block count even and >= 4: checked on the host)
 #pragma unroll 1
-        for (int cb = 0; cb < a.ncb; cb += 2) {
-            block(cb, P0{}, uA, uD);
-            if (cb + 1 < a.ncb) {
-                block(cb + 1, P1{}, uD, uA);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) uA[i] = uD[i];   // odd block count: keep the naming invariant
-            }
+        for (int cb = 0; cb + 4 < a.ncb; cb += 2) {
+            block(cb, P0{}, R0{}, uA, uD);
+            block(cb + 1, P1{}, R0{}, uD, uA);
         }
+        block(a.ncb - 4, P0{}, R0{}, uA, uD);
+        block(a.ncb - 3, P1{}, std::integral_constant<int, 3>{}, uD, uA);
+        block(a.ncb - 2, P0{}, std::integral_constant<int, 2>{}, uA, uD);
+        block(a.ncb - 1, P1{}, std::integral_constant<int, 1>{}, uD, uA);
     }
 #undef DINV_MFMA2
 #undef DINV_VCALC
@@ -412,11 +452,7 @@ void conv3x3_wino_kernel(WinoArgs a) {
     // ---- next tile: describe it and issue its first loads now, the accumulators are dead, so there are
     // registers for them; they fly during the exchange reads, the output stores and the tile turnover
     jt += a.slots;
-    const bool more = jt < a.per_xcd && (bid & 7) * a.per_xcd + jt < a.nwg;
-    if (more) {
-        describe((bid & 7) * a.per_xcd + jt);
-        first_loads();
-    }
+    if (more) advance();
     lds_barrier();
     DINV_STAMP(5);
     float4 qv[2][2][4];
@@ -526,8 +562,8 @@ extern "C" int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, con
                                      int32_t cout, float* y, const float* res1, int32_t relu, dinv_stream_t stream) {
     if (check_geom(g)) return 1;
     DINV_REQUIRE(x && w_wino && y, "null pointer");
-    DINV_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= 64 && cout % 64 == 0,
-                 "winograd conv needs cin %% 8 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
+    DINV_REQUIRE(cin >= 32 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0,
+                 "winograd conv needs cin %% 16 == 0, cin >= 32 and cout %% 64 == 0 (got %d,%d)", cin, cout);
     DINV_REQUIRE(!(relu && res1), "relu and residual are not combined in DRUNet");
     DINV_REQUIRE(g->cs * 32 < (1ll << 32), "winograd conv: one channel block must stay below 4 GB (32-bit buffer offsets)");
     WinoArgs a{};

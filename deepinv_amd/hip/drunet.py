@@ -71,10 +71,11 @@ def pack_tail_weight(w: torch.Tensor) -> torch.Tensor:
 
 def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
     """OIHW [Cout,Cin,3,3] -> U = G g G^T (fp64, rounded once) packed [Cout/64][Cin/8][ci 8][co 64][16];
-    needs Cin % 8 == 0 and Cout % 64 == 0 (the ResBlock convs)."""
+    needs Cin % 16 == 0, Cin >= 32 and Cout % 64 == 0 (the ResBlock convs; the kernel pipelines channel blocks
+    in pairs and peels the last four)."""
     cout, cin = w.shape[:2]
-    if cin % 8 or cout % 64:
-        raise ValueError(f"winograd packing needs cin % 8 == 0 and cout % 64 == 0, got {cin},{cout}")
+    if cin % 16 or cin < 32 or cout % 64:
+        raise ValueError(f"winograd packing needs cin % 16 == 0, cin >= 32 and cout % 64 == 0, got {cin},{cout}")
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
     u = (G @ w.detach().double() @ G.t()).float().reshape(cout // 64, 64, cin // 8, 8, 16)
     return u.permute(0, 2, 3, 1, 4).contiguous()

@@ -180,7 +180,7 @@ class DRUNet(Denoiser):
             w = m.weight.to(device)
             p64 = K.pack_conv3x3_weight(w)
             p32 = K.pack_conv3x3_weight(w, mt=32) if p64[0].shape[3] == 64 else p64
-            wino = K.pack_winograd_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0) else None
+            wino = K.pack_winograd_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0 and w.shape[1] >= 32) else None
             return (p64, p32, wino)
 
         e["head"] = c3(self.m_head)

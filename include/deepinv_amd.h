@@ -141,7 +141,8 @@ int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const float* x2, c
                       int32_t cout, float* y, dinv_stream_t stream);
 /* Same operator as dinv_conv3x3 (no x2, one optional residual) through Winograd F(2x2,3x3): 2.25x fewer MFMA
  * flops, results equal up to fp32 rounding of the transforms (~1e-6 relative).
- * w_wino: U = G g G^T per (cout, cin), packed [cout/64][cin/8][ci 8][co 64][16]; cin % 8 == 0, cout % 64 == 0;
+ * w_wino: U = G g G^T per (cout, cin), packed [cout/64][cin/8][ci 8][co 64][16]; cin % 16 == 0, cin >= 32,
+ * cout % 64 == 0 (other shapes: dinv_conv3x3);
  * relu and res1 are mutually exclusive (ResBlock conv1 / conv2, drunet.py:403-434). */
 int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w_wino, int32_t cin, int32_t cout,
                           float* y, const float* res1, int32_t relu, dinv_stream_t stream);

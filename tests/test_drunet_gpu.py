@@ -56,8 +56,8 @@ def test_drunet_unsafe_shapes(dev):
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 64, 64, 64, 64), (3, 40, 40, 128, 128), (1, 80, 80, 64, 128),
                                               (2, 20, 20, 512, 512), (1, 37, 51, 64, 64), (5, 10, 10, 64, 64),
                                               (1, 320, 320, 64, 64),
-                                              # odd / single channel-block counts, one-pixel images, many tiny images
-                                              (1, 24, 40, 24, 64), (2, 16, 16, 8, 64), (3, 1, 1, 64, 64), (70, 4, 6, 16, 128),
+                                              # smallest channel counts, one-pixel images, many tiny images
+                                              (1, 24, 40, 32, 64), (2, 16, 16, 48, 64), (3, 1, 1, 64, 64), (70, 4, 6, 32, 128),
                                               (1, 2, 330, 64, 64)])
 @pytest.mark.parametrize("mode", ["plain", "relu", "res"])
 def test_winograd_conv_matches_fp32_conv(dev, B, H, W, cin, cout, mode):
@@ -100,6 +100,18 @@ def test_winograd_conv_matches_fp32_conv(dev, B, H, W, cin, cout, mode):
     full = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
     assert full[:, :, 0].abs().max() == 0 and full[:, :, H + 1:].abs().max() == 0
     assert full[:, :, :, 0].abs().max() == 0 and full[:, :, :, W + 1:].abs().max() == 0
+
+
+def test_winograd_conv_rejects_unsupported_channel_counts(dev):
+    """cin must be a multiple of 16 and >= 32 (channel blocks are pipelined in pairs, the last four peeled)"""
+    from deepinv_amd.hip import drunet as K
+
+    geo = K.geom(1, 8, 8)
+    x, y = K.alloc(geo, 24, dev), K.alloc(geo, 64, dev)
+    with pytest.raises(ValueError):
+        K.pack_winograd_weight(torch.zeros(64, 24, 3, 3, device=dev))
+    with pytest.raises(RuntimeError, match="winograd conv needs"):
+        K.conv3x3_winograd(geo, x, torch.zeros(1, 3, 8, 64, 16, device=dev), 24, 64, y)
 
 
 def test_drunet_winograd_matches_oracle(dev, monkeypatch):
