@@ -28,6 +28,7 @@
 //   wave xr finishes A^T s for channel sub-block xr: fused ReLU / residual add, float4 stores of interior
 //   pixels only.
 #include "drunet_common.hpp"
+#include <atomic>
 #include <type_traits>
 
 using namespace dinv;
@@ -495,14 +496,14 @@ void conv3x3_wino_kernel(WinoArgs a) {
 }
 
 // compute units per XCD of the current device (32 on MI355X: 256 CUs in 8 XCDs)
-int cus_per_xcd() {
-    static int v = 0;
+int cus_per_xcd(int dev) {
+    static std::atomic<int> cache[64];
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
     if (v == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
-            n = 256;
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
         v = n / 8;
+        cache[dev & 63].store(v, std::memory_order_relaxed);
     }
     return v;
 }
@@ -520,14 +521,18 @@ int launch_shape(WinoArgs a, int tiles_y, int tiles_x, hipStream_t st) {
     a.d_ntx = make_fastdiv((uint32_t)a.ntx);
     a.d_nct = make_fastdiv((uint32_t)a.nct);
     const size_t shm = S::LDSF * sizeof(float);
-    static bool once = false;  // per instantiation
+    static std::atomic<uint64_t> configured{0};   // per instantiation: bit d = attribute set on device d
     auto kern = conv3x3_wino_kernel<TH, TW, RELU, NRES>;
-    if (!once) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(3, "hipGetDevice failed");
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(configured.load(std::memory_order_relaxed) & bit)) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return fail(3, "hipFuncSetAttribute(max dynamic LDS) failed");
-        once = true;
+        configured.fetch_or(bit, std::memory_order_relaxed);
     }
-    a.slots = (int32_t)(a.per_xcd < cus_per_xcd() ? a.per_xcd : cus_per_xcd());
+    const int cpx = cus_per_xcd(dev);
+    a.slots = (int32_t)(a.per_xcd < cpx ? a.per_xcd : cpx);
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.slots * 8)), dim3(NTHR), shm, st, a);
     DINV_CHECK_LAUNCH();
     return 0;
