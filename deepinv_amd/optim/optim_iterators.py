@@ -61,10 +61,31 @@ def objective_function(x, data_fidelity, prior, cur_params, y, physics):
     return data_fidelity(x, y, physics) + cur_params["lambda"] * prior(x, cur_params["g_param"])
 
 
+_ATY_CACHE = {}  # id(physics) -> (key, A^T y): one entry per operator, replaced when anything in the key changes
+
+
+def _cached_adjoint(physics, y):
+    """A^T y is the same tensor in every iteration of a reconstruction (the reference recomputes it each time,
+    data_fidelity.py:335-338).  Reuse it while y and every parameter / buffer of the operator are untouched
+    (storage address + in-place version counter): identical value, one adjoint less per iteration."""
+    key = (y.data_ptr(), y._version, tuple(y.shape), tuple(y.stride()), y.device,
+           tuple((t.data_ptr(), t._version) for t in list(physics.buffers()) + list(physics.parameters())))
+    hit = _ATY_CACHE.get(id(physics))
+    if hit is not None and hit[0] == key and hit[2]() is physics:
+        return hit[1]
+    import weakref
+
+    val = physics.A_adjoint(y)
+    if len(_ATY_CACHE) > 16:
+        _ATY_CACHE.clear()
+    _ATY_CACHE[id(physics)] = (key, val, weakref.ref(physics))
+    return val
+
+
 def _fused_l2_gradient_step(x, data_fidelity, stepsize, y, physics):
     """x - gamma/sigma^2 * (A^T A x - A^T y) as ONE pass over the image (hand-written kernel) when the fidelity is
     L2, the physics linear, the operands live on the HIP device and no autograd graph is recorded; same arithmetic
-    as fStepPGD + L2.grad (pgd.py:137-139, data_fidelity.py:335-338), including the per-iteration A^T y."""
+    as fStepPGD + L2.grad (pgd.py:137-139, data_fidelity.py:335-338); A^T y is reused across iterations."""
     from ..physics.forward import LinearPhysics
     from .data_fidelity import L2
 
@@ -77,7 +98,7 @@ def _fused_l2_gradient_step(x, data_fidelity, stepsize, y, physics):
     if not ew.eligible(x) or torch.is_grad_enabled():
         return None
     AtAx = physics.A_adjoint_A(x)
-    Aty = physics.A_adjoint(y)
+    Aty = _cached_adjoint(physics, y)
     if not (ew.eligible(AtAx, Aty) and AtAx.shape == x.shape == Aty.shape):
         return x - stepsize * data_fidelity.norm * (AtAx - Aty)
     g = float(stepsize) * float(data_fidelity.norm)
