@@ -20,6 +20,15 @@ from .prior import ZeroPrior
 
 
 @dataclass
+class AndersonAccelerationConfig:
+    """Anderson acceleration of the fixed-point iterations (optimizers.py:64-77)."""
+    history_size: int = 10
+    beta: float = 0.9
+    eps: float = 0.1
+    full_backprop: bool = False
+
+
+@dataclass
 class BacktrackingConfig:
     gamma: float = 0.1
     eta: float = 0.9
@@ -42,8 +51,10 @@ class BaseOptim(Reconstructor):
         super().__init__()
         if DEQ:
             raise NotImplementedError("DEQ is not on the accelerated path")
-        if anderson_acceleration:
-            raise NotImplementedError("Anderson acceleration is not on the accelerated path")
+        if isinstance(anderson_acceleration, bool) or anderson_acceleration is None:   # optimizers.py:327-332
+            self.anderson_acceleration_config = AndersonAccelerationConfig() if anderson_acceleration else None
+        else:
+            self.anderson_acceleration_config = anderson_acceleration
         self.early_stop, self.crit_conv, self.verbose = early_stop, crit_conv, verbose
         self.show_progress_bar, self.max_iter = show_progress_bar, max_iter
         if isinstance(backtracking, bool):
@@ -98,7 +109,9 @@ class BaseOptim(Reconstructor):
             backtracking_check_fn=self.backtracking_check_fn, check_conv_fn=self.check_conv_fn,
             init_metrics_fn=self.init_metrics_fn, init_iterate_fn=self.init_iterate_fn,
             update_metrics_fn=self.update_metrics_fn, max_iter=max_iter, early_stop=early_stop,
-            backtracking_config=self.backtracking_config, verbose=verbose, show_progress_bar=show_progress_bar)
+            backtracking_config=self.backtracking_config,
+            anderson_acceleration_config=self.anderson_acceleration_config, verbose=verbose,
+            show_progress_bar=show_progress_bar)
 
     # ---- per-iteration lookups (optimizers.py:464-500)
     def update_params_fn(self, it):

@@ -138,3 +138,57 @@ def test_dpir_schedule():
     s, step, n = dinv.optim.get_DPIR_params(0.05)
     assert n == 8 and abs(float(s[0]) - 49 / 255) < 1e-6 and abs(float(s[-1]) - 0.05) < 1e-6
     assert torch.allclose(step, (1 / 0.23) * (s / 0.05) ** 2)
+
+
+def test_loop_options_match_reference_golden():
+    """Anderson acceleration (fixed_point.py:116-260) and backtracking against vectors produced by the real
+    reference (tests/golden/make_golden_optim.py): same lasso problem, matrix physics, float64, 12 iterations."""
+    import os
+
+    import numpy as np
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "optim_loop_options.npz"))
+    M, y, step = torch.from_numpy(gold["M"]), torch.from_numpy(gold["y"]), float(gold["step"])
+    phys = MatPhysics(M)
+
+    class L1(dinv.optim.Prior):
+        def __init__(self):
+            super().__init__()
+            self.explicit_prior = True
+
+        def fn(self, x, *a, **k):
+            return x.abs().sum(dim=-1)
+
+        def prox(self, x, *a, gamma=1.0, **k):
+            return torch.sign(x) * torch.clamp(x.abs() - gamma, min=0)
+
+    AA, BT = dinv.optim.AndersonAccelerationConfig, dinv.optim.BacktrackingConfig
+    cases = {
+        "pgd_plain": (dict(), 1.0),
+        "pgd_anderson_default": (dict(anderson_acceleration=True), 1.0),
+        "pgd_anderson_h3": (dict(anderson_acceleration=AA(history_size=3, beta=0.8, eps=1e-4)), 1.0),
+        "pgd_anderson_full": (dict(anderson_acceleration=AA(history_size=4, beta=1.0, eps=1e-3, full_backprop=True)), 1.0),
+        "pgd_backtracking": (dict(backtracking=BT(gamma=0.1, eta=0.5, max_iter=20)), 8.0),
+    }
+    for name, (kw, scale) in cases.items():
+        model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=L1(), lambda_reg=0.2, stepsize=step * scale,
+                               max_iter=12, early_stop=False, **kw)
+        with torch.no_grad():
+            x = model(y, phys)
+        ref = torch.from_numpy(gold[name])
+        assert torch.allclose(x, ref, rtol=1e-9, atol=1e-11), (name, float((x - ref).abs().max()))
+
+
+def test_anderson_gradient_flows_through_current_iterate():
+    """non-full-backprop mode keeps a gradient path through the newest history slot only (fixed_point.py:206-224)"""
+    torch.manual_seed(0)
+    M = torch.randn(5, 4, dtype=torch.float64)
+    phys = MatPhysics(M)
+    y = torch.randn(2, 5, dtype=torch.float64, requires_grad=True)
+    model = dinv.optim.GD(data_fidelity=dinv.optim.L2(), stepsize=0.05, max_iter=6, anderson_acceleration=True,
+                          unfold=True, trainable_params=["stepsize"])
+    x = model(y, phys)
+    x.sum().backward()
+    assert y.grad is not None and torch.isfinite(y.grad).all() and y.grad.abs().sum() > 0
+    step = [p for p in model.parameters()][0]
+    assert step.grad is not None and torch.isfinite(step.grad).all()
