@@ -5,7 +5,7 @@ from .prior import Prior, PnP, ZeroPrior
 from .optim_iterators import (OptimIterator, fStep, gStep, PGDIteration, HQSIteration, FISTAIteration, GDIteration)
 from .fixed_point import FixedPoint
 from .optimizers import (BaseOptim, PGD, HQS, FISTA, GD, optim_builder, create_iterator, BacktrackingConfig,
-                         AndersonAccelerationConfig)
+                         AndersonAccelerationConfig, DEQConfig)
 from .linear import conjugate_gradient, least_squares, least_squares_implicit_backward, dot
 from .dpir import DPIR, get_DPIR_params
 from . import linear

@@ -20,6 +20,17 @@ from .prior import ZeroPrior
 
 
 @dataclass
+class DEQConfig:
+    """Deep-equilibrium (implicit differentiation) options (optimizers.py:44-61)."""
+    jacobian_free: bool = False
+    anderson_acceleration_backward: bool = False
+    history_size_backward: int = 5
+    beta_backward: float = 1.0
+    eps_backward: float = 1e-4
+    max_iter_backward: int = 50
+
+
+@dataclass
 class AndersonAccelerationConfig:
     """Anderson acceleration of the fixed-point iterations (optimizers.py:64-77)."""
     history_size: int = 10
@@ -49,8 +60,10 @@ class BaseOptim(Reconstructor):
                  unfold=False, trainable_params=None, DEQ=None, anderson_acceleration=False, verbose=False,
                  show_progress_bar=False, **kwargs):
         super().__init__()
-        if DEQ:
-            raise NotImplementedError("DEQ is not on the accelerated path")
+        if isinstance(DEQ, bool) or DEQ is None:   # optimizers.py:321-326
+            self.DEQ, self.DEQ_config = bool(DEQ), (DEQConfig() if DEQ else None)
+        else:
+            self.DEQ, self.DEQ_config = True, DEQ
         if isinstance(anderson_acceleration, bool) or anderson_acceleration is None:   # optimizers.py:327-332
             self.anderson_acceleration_config = AndersonAccelerationConfig() if anderson_acceleration else None
         else:
@@ -65,7 +78,7 @@ class BaseOptim(Reconstructor):
             self.backtracking_config = backtracking or BacktrackingConfig()
         self.has_converged = False
         self.thres_conv, self.custom_metrics, self.custom_init = thres_conv, custom_metrics, custom_init
-        self.get_output, self.unfold, self.DEQ = get_output, unfold, False
+        self.get_output, self.unfold = get_output, unfold
         self.prior = [ZeroPrior()] if prior is None else ([prior] if not isinstance(prior, Iterable) else prior)
         self.data_fidelity = ([ZeroFidelity()] if data_fidelity is None else
                               ([data_fidelity] if not isinstance(data_fidelity, Iterable) else data_fidelity))
@@ -199,11 +212,50 @@ class BaseOptim(Reconstructor):
             return True
         return False
 
+    def _deq_output(self, X, y, physics, **kwargs):
+        """Implicit differentiation at the equilibrium (optimizers.py:741-824): the loop ran without a graph; one
+        more tracked application of the iteration map T gives x* = T(x*) with d x*/d theta from T alone
+        (Jacobian-free mode), or - default - a gradient hook on x* that replaces the incoming gradient v by the
+        solution g of  g = J_T(x*)^T g + v  found by fixed-point iterations (optionally Anderson accelerated)."""
+        last = self.max_iter - 1
+        cur_df = self.update_data_fidelity_fn(last) if self.update_data_fidelity_fn else None
+        cur_prior = self.update_prior_fn(last) if self.update_prior_fn else None
+        cur_params = self.update_params_fn(last) if self.update_params_fn else None
+        T = self.fixed_point.iterator
+        x = T(X, cur_df, cur_prior, cur_params, y, physics, **kwargs)["est"][0]
+        cfg = self.DEQ_config
+        if cfg.jacobian_free or not x.requires_grad:
+            return x
+        x0 = x.clone().detach().requires_grad_()
+        f0 = T({"est": (x0,)}, cur_df, cur_prior, cur_params, y, physics, **kwargs)["est"][0]
+
+        class _AdjointMap(nn.Module):   # g -> J^T g + v, in the iterate-dictionary protocol of FixedPoint
+            cost_fn = None
+            has_cost = False
+
+            def __init__(self, v):
+                super().__init__()
+                self.v = v
+
+            def forward(self, G, *args, **kw):
+                return {"est": (torch.autograd.grad(f0, x0, G["est"][0], retain_graph=True)[0] + self.v,)}
+
+        def solve_adjoint(v):
+            aa = (AndersonAccelerationConfig(cfg.history_size_backward, cfg.beta_backward, cfg.eps_backward)
+                  if cfg.anderson_acceleration_backward else None)
+            solver = FixedPoint(_AdjointMap(v), init_iterate_fn=lambda *a, **k: {"est": (v,)},
+                                max_iter=cfg.max_iter_backward, check_conv_fn=self.check_conv_fn,
+                                anderson_acceleration_config=aa)
+            return solver({"est": (v,)}, None)[0]["est"][0]
+
+        x.register_hook(solve_adjoint)
+        return x
+
     def forward(self, y, physics, init=None, x_gt=None, compute_metrics=False, **kwargs):
-        """no_grad unless unfolding (optimizers.py:826-881)"""
-        with (torch.no_grad() if not self.unfold else nullcontext()):
+        """no_grad unless unfolding; DEQ differentiates only through the equilibrium (optimizers.py:826-881)"""
+        with (torch.no_grad() if (not self.unfold or self.DEQ) else nullcontext()):
             X, metrics = self.fixed_point(y, physics, init=init, x_gt=x_gt, compute_metrics=compute_metrics, **kwargs)
-        x = self.get_output(X)
+        x = self._deq_output(X, y, physics, **kwargs) if self.DEQ else self.get_output(X)
         return (x, metrics) if compute_metrics else x
 
 

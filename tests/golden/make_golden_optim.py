@@ -70,3 +70,26 @@ for name, kw in cases.items():
     out[name] = x.numpy()
     print(name, x[0, :3].numpy())
 np.savez_compressed(os.path.join(OUT, "optim_loop_options.npz"), **out)
+
+# ---------------------------------------------------------------- DEQ (implicit differentiation, optimizers.py:741-824)
+from deepinv.optim.optimizers import DEQConfig  # noqa: E402
+
+deq_cases = {
+    "deq_default": DEQConfig(),
+    "deq_jacobian_free": DEQConfig(jacobian_free=True),
+    "deq_anderson_backward": DEQConfig(anderson_acceleration_backward=True, history_size_backward=3, max_iter_backward=30),
+}
+deq = {}
+for name, cfg in deq_cases.items():
+    yq = y.clone().requires_grad_()
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=L1(), lambda_reg=0.2, stepsize=step, max_iter=40,
+                           early_stop=False, unfold=True, trainable_params=["stepsize", "lambda_reg"], DEQ=cfg)
+    x = model(yq, phys)
+    (x ** 2).sum().backward()
+    params = dict(model.named_parameters())
+    deq[name + "_x"] = x.detach().numpy()
+    deq[name + "_gy"] = yq.grad.numpy()
+    for k, p in params.items():
+        deq[name + "_g_" + k.replace(".", "_")] = p.grad.numpy()
+    print(name, x.detach()[0, :2].numpy(), yq.grad[0, :2].numpy(), {k: float(p.grad) for k, p in params.items()})
+np.savez_compressed(os.path.join(OUT, "optim_deq.npz"), M=M.numpy(), y=y.numpy(), step=np.float64(step), **deq)

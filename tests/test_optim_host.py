@@ -192,3 +192,59 @@ def test_anderson_gradient_flows_through_current_iterate():
     assert y.grad is not None and torch.isfinite(y.grad).all() and y.grad.abs().sum() > 0
     step = [p for p in model.parameters()][0]
     assert step.grad is not None and torch.isfinite(step.grad).all()
+
+
+def test_deq_gradients_match_reference_golden():
+    """DEQ=... (implicit differentiation: hook solving g = J^T g + v, Jacobian-free mode, Anderson-accelerated
+    backward solve; optimizers.py:741-824) against gradients produced by the real reference."""
+    import os
+
+    import numpy as np
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "optim_deq.npz"))
+    M, step = torch.from_numpy(gold["M"]), float(gold["step"])
+    phys = MatPhysics(M)
+
+    class L1(dinv.optim.Prior):
+        def __init__(self):
+            super().__init__()
+            self.explicit_prior = True
+
+        def fn(self, x, *a, **k):
+            return x.abs().sum(dim=-1)
+
+        def prox(self, x, *a, gamma=1.0, **k):
+            return torch.sign(x) * torch.clamp(x.abs() - gamma, min=0)
+
+    C = dinv.optim.DEQConfig
+    cases = {"deq_default": C(), "deq_jacobian_free": C(jacobian_free=True),
+             "deq_anderson_backward": C(anderson_acceleration_backward=True, history_size_backward=3, max_iter_backward=30)}
+    for name, cfg in cases.items():
+        y = torch.from_numpy(gold["y"]).clone().requires_grad_()
+        model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=L1(), lambda_reg=0.2, stepsize=step, max_iter=40,
+                               early_stop=False, unfold=True, trainable_params=["stepsize", "lambda_reg"], DEQ=cfg)
+        x = model(y, phys)
+        (x ** 2).sum().backward()
+        assert torch.allclose(x.detach(), torch.from_numpy(gold[name + "_x"]), rtol=1e-9, atol=1e-11), name
+        assert torch.allclose(y.grad, torch.from_numpy(gold[name + "_gy"]), rtol=1e-6, atol=1e-8), name
+        for k, p in model.named_parameters():
+            ref = torch.from_numpy(gold[name + "_g_" + k.replace(".", "_")])
+            assert torch.allclose(p.grad, ref, rtol=1e-5, atol=1e-6), (name, k, float(p.grad), float(ref))
+
+
+def test_deq_builder_trains_through_the_equilibrium():
+    """DEQ_builder: no graph through the loop, gradients of the trainable step size from the adjoint fixed point"""
+    torch.manual_seed(1)
+    M = torch.randn(7, 5) / 3
+    phys = MatPhysics(M)
+    y = torch.randn(4, 7)
+    model = dinv.unfolded.DEQ_builder("GD", params_algo={"lambda": 1.0, "stepsize": 0.3}, data_fidelity=dinv.optim.L2(),
+                                      max_iter=200, trainable_params=["stepsize"], max_iter_backward=100)
+    x = model(y, phys)
+    xs = torch.linalg.lstsq(M, y.T).solution.T          # GD on least squares converges to the pseudo-inverse solution
+    assert torch.allclose(x, xs, atol=1e-3)
+    x.pow(2).sum().backward()
+    g = model.params_algo["stepsize"][0].grad
+    assert g is not None and torch.isfinite(g)
+    # at the exact equilibrium the solution does not depend on the step size: the implicit gradient vanishes
+    assert abs(float(g)) < 1e-2
