@@ -87,32 +87,79 @@ def _adjoint_raw(y, maps, mask, coil_dim):
     return x
 
 
+def _as_complex(t):   # [B,2,...] real pairs -> complex [B,...]
+    return torch.complex(t[:, 0], t[:, 1])
+
+
+def _per_coil_adjoint(y, mask, coil_dim):
+    """u_n = F^H(mask * y_n) for every coil, without the coil combination: the coils ride along the batch axis of the
+    single-coil kernel.  y [B,2,N,vol] (or [B,2,vol]) -> complex [B,N,vol]."""
+    if not coil_dim:
+        return _as_complex(_adjoint_raw(y, None, mask, False))[:, None]
+    B, _, N = y.shape[:3]
+    vol = tuple(y.shape[3:])
+    yb = y.permute(0, 2, 1, *range(3, y.ndim)).reshape(B * N, 2, *vol)
+    mb = mask
+    if mask is not None and mask.shape[0] == B and B > 1:
+        mb = mask.repeat_interleave(N, dim=0)
+    return _as_complex(_adjoint_raw(yb, None, mb, False)).reshape(B, N, *vol)
+
+
+def _reduce_like(g, ref):
+    """sum a per-sample gradient over the batch when the parameter is shared by the batch (leading size 1)"""
+    return g.sum(0, keepdim=True) if ref.shape[0] == 1 and g.shape[0] != 1 else g
+
+
+def _mask_grad(prod, mask, coil_dim):   # prod = upstream * unmasked k-space, [B,2,N,vol] or [B,2,vol]
+    if coil_dim:
+        prod = prod.sum(2)
+    return _reduce_like(prod, mask).to(mask.dtype)
+
+
 class _MriForward(torch.autograd.Function):
-    """y = M F S x ; backward is the adjoint kernel (same trick as ApplyRadon, radon.py:493-531)."""
+    """y = M F S x ; backward is the adjoint kernel (same trick as ApplyRadon, radon.py:493-531).  Gradients with
+    respect to `coil_maps` and `mask` (the reference gets them from autograd, e.g. for learned sampling patterns)
+    are assembled from the same kernels: dL/dM = sum g * F(S x),  dL/dS_n = F^H(M g_n) * conj(x)."""
 
     @staticmethod
     def forward(ctx, x, maps, mask, coil_dim):
-        ctx.save_for_backward(maps, mask)
+        ctx.save_for_backward(x, maps, mask)
         ctx.coil_dim = coil_dim
         return _forward_raw(x, maps, mask, coil_dim)
 
     @staticmethod
     def backward(ctx, g):
-        maps, mask = ctx.saved_tensors
-        return _MriAdjoint.apply(g, maps, mask, ctx.coil_dim), None, None, None
+        x, maps, mask = ctx.saved_tensors
+        gx = _MriAdjoint.apply(g, maps, mask, ctx.coil_dim) if ctx.needs_input_grad[0] else None
+        gmaps = gmask = None
+        if maps is not None and ctx.needs_input_grad[1]:
+            u = _per_coil_adjoint(g, mask, ctx.coil_dim)
+            gmaps = _reduce_like(u * _as_complex(x).conj()[:, None], maps).to(maps.dtype)
+        if mask is not None and ctx.needs_input_grad[2]:
+            gmask = _mask_grad(g * _forward_raw(x, maps, None, ctx.coil_dim), mask, ctx.coil_dim)
+        return gx, gmaps, gmask, None
 
 
 class _MriAdjoint(torch.autograd.Function):
+    """x = sum_n conj(S_n) F^H(M y_n); dL/dM = sum F(S g) * y,  dL/dS_n = conj(g) * F^H(M y_n)."""
+
     @staticmethod
     def forward(ctx, y, maps, mask, coil_dim):
-        ctx.save_for_backward(maps, mask)
+        ctx.save_for_backward(y, maps, mask)
         ctx.coil_dim = coil_dim
         return _adjoint_raw(y, maps, mask, coil_dim)
 
     @staticmethod
     def backward(ctx, g):
-        maps, mask = ctx.saved_tensors
-        return _MriForward.apply(g, maps, mask, ctx.coil_dim), None, None, None
+        y, maps, mask = ctx.saved_tensors
+        gy = _MriForward.apply(g, maps, mask, ctx.coil_dim) if ctx.needs_input_grad[0] else None
+        gmaps = gmask = None
+        if maps is not None and ctx.needs_input_grad[1]:
+            u = _per_coil_adjoint(y, mask, ctx.coil_dim)
+            gmaps = _reduce_like(_as_complex(g).conj()[:, None] * u, maps).to(maps.dtype)
+        if mask is not None and ctx.needs_input_grad[2]:
+            gmask = _mask_grad(_forward_raw(g, maps, None, ctx.coil_dim) * y, mask, ctx.coil_dim)
+        return gy, gmaps, gmask, None
 
 
 def mri_forward(x, coil_maps=None, mask=None, coil_dim=True):

@@ -103,3 +103,35 @@ def test_cpu_tensor_fails_loudly():
     phys = dinv.physics.MRI(img_size=(2, 8, 8))
     with pytest.raises(RuntimeError):
         phys.A(torch.randn(1, 2, 8, 8))
+
+
+@pytest.mark.parametrize("mb,sb", [(1, 1), (3, 3), (1, 3)])
+def test_parameter_gradients_match_autograd_oracle(dev, mb, sb):
+    """dL/d(coil_maps), dL/d(mask), dL/dx of A and A_adjoint against autograd through the CPU oracle (the reference
+    gets these from autograd; needed e.g. for learned sampling patterns).  Shared (batch 1) and per-sample params."""
+    from deepinv_amd.hip.mri import mri_adjoint, mri_forward
+    from oracle import physics_cpu as OP
+
+    g = torch.Generator().manual_seed(5)
+    B, N, H, W = 3, 4, 16, 12
+    x = torch.randn(B, 2, H, W, generator=g)
+    maps = torch.randn(sb, N, H, W, dtype=torch.complex64, generator=g) / 2
+    mask = torch.rand(mb, 2, H, W, generator=g)
+    wy = torch.randn(B, 2, N, H, W, generator=g)
+    wx = torch.randn(B, 2, H, W, generator=g)
+    yin = torch.randn(B, 2, N, H, W, generator=g)
+
+    def grads(fwd, adj, to):
+        xs, ms, ks, ys = (t.clone().to(to).requires_grad_() for t in (x, maps, mask, yin))
+        l1 = (fwd(xs, ms, ks) * wy.to(to)).sum()
+        g1 = torch.autograd.grad(l1, (xs, ms, ks))
+        l2 = (adj(ys, ms, ks) * wx.to(to)).sum()
+        g2 = torch.autograd.grad(l2, (ys, ms, ks))
+        return [t.cpu() for t in (*g1, *g2)]
+
+    ref = grads(lambda a, b, c: OP.multicoil_A(a, b, c), lambda a, b, c: OP.multicoil_AT(a, b, c), "cpu")
+    got = grads(lambda a, b, c: mri_forward(a, b, c), lambda a, b, c: mri_adjoint(a, b, c), dev)
+    for name, r, o in zip(("A/x", "A/maps", "A/mask", "AT/y", "AT/maps", "AT/mask"), ref, got):
+        assert o.shape == r.shape, name
+        real = lambda t: torch.view_as_real(t.resolve_conj()) if t.is_complex() else t
+        assert rel_err(real(o), real(r)) < 1e-4, name
