@@ -68,6 +68,8 @@ def _cached_adjoint(physics, y):
     """A^T y is the same tensor in every iteration of a reconstruction (the reference recomputes it each time,
     data_fidelity.py:335-338).  Reuse it while y and every parameter / buffer of the operator are untouched
     (storage address + in-place version counter): identical value, one adjoint less per iteration."""
+    if not isinstance(y, torch.Tensor) or not isinstance(physics, torch.nn.Module):
+        return physics.A_adjoint(y)
     key = (y.data_ptr(), y._version, tuple(y.shape), tuple(y.stride()), y.device,
            tuple((t.data_ptr(), t._version) for t in list(physics.buffers()) + list(physics.parameters())))
     hit = _ATY_CACHE.get(id(physics))
