@@ -36,6 +36,38 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float comp(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
+// epilogue shared by the three conv kernels: D[i][j], j = lane&31 (pixel), i = (reg&3) + 8*(reg>>2) + 4*h (cout),
+// i.e. register quad g = reg>>2 holds couts 8g+4h .. 8g+4h+3 = one float4 of channel block g.
+template <int MREP, bool RELU, int NRES>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[MREP][2], int n, int64_t opix, bool in, int cb0,
+                                           int cblocks_valid, int64_t cs, int lhi, float* __restrict__ y,
+                                           const float* __restrict__ res1, const float* __restrict__ res2) {
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        float4 r1[4], r2[4];
+        if (NRES >= 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (cb0 + 4 * m + g < cblocks_valid) r1[g] = ld4(res1 + ((int64_t)(cb0 + 4 * m + g) * cs + opix) * 8 + 4 * lhi);
+        }
+        if (NRES >= 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (cb0 + 4 * m + g < cblocks_valid) r2[g] = ld4(res2 + ((int64_t)(cb0 + 4 * m + g) * cs + opix) * 8 + 4 * lhi);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (cb0 + 4 * m + g >= cblocks_valid) continue;
+            float4 v = make_float4(acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
+            if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (NRES >= 1) v = add4(v, r1[g]);
+            if (NRES >= 2) v = add4(v, r2[g]);
+            if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            st4(y + ((int64_t)(cb0 + 4 * m + g) * cs + opix) * 8 + 4 * lhi, v);
+        }
+    }
+}
+
 inline int check_geom(const dinv_act_geom* g) {
     DINV_REQUIRE(g != nullptr, "null geometry");
     DINV_REQUIRE(g->batch >= 1 && g->height >= 1 && g->width >= 1, "bad geometry %dx%dx%d", g->batch, g->height, g->width);

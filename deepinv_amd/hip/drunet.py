@@ -30,6 +30,7 @@ def _l():
         l.dinv_act_unpack.argtypes = [G, vp, i32, vp, vp]
         l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
         l.dinv_conv3x3_tail.argtypes = [G, vp, vp, vp, i32, i32, vp, vp]
+        l.dinv_conv3x3_bf16x3.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
@@ -67,6 +68,21 @@ def pack_tail_weight(w: torch.Tensor) -> torch.Tensor:
     if cout > 4 or cin % 8:
         raise ValueError(f"tail packing needs cout <= 4 and cin % 8 == 0, got {cout},{cin}")
     return w.detach().float().reshape(cout, cin // 8, 8, 9).permute(1, 3, 0, 2).contiguous()
+
+
+def pack_bf16x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> exact 3-way bf16 split, packed [Cout/64][Cin/8][plane 3][tap 9][co 64][8] (bf16)"""
+    cout, cin = w.shape[:2]
+    if cin % 8 or cout % 64:
+        raise ValueError(f"bf16x3 packing needs cin % 8 == 0 and cout % 64 == 0, got {cin},{cout}")
+    w = w.detach().float()
+    p1 = w.bfloat16()
+    r = w - p1.float()
+    p2 = r.bfloat16()
+    p3 = (r - p2.float()).bfloat16()
+    planes = torch.stack((p1, p2, p3))                                   # [3, Cout, Cin, 3, 3]
+    planes = planes.reshape(3, cout // 64, 64, cin // 8, 8, 9)           # pl, ct, co, cb, ci, tap
+    return planes.permute(1, 3, 0, 5, 2, 4).contiguous()                # ct, cb, pl, tap, co, ci
 
 
 def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
@@ -165,6 +181,19 @@ def _conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=
 def conv3x3_tail(g, x, wtail, cin, cout, y, x2=None):
     """last layer on the vector ALU: y[:cout] = conv3x3(x (+x2)); wtail from pack_tail_weight"""
     check(_l().dinv_conv3x3_tail(ctypes.byref(g), ptr(x), ptr(x2), ptr(wtail), cin, cout, ptr(y), stream_ptr(y.device)))
+
+
+def conv3x3_bf16x3(g, x, wsplit, cin, cout, y, res1=None, relu=False, planes=3):
+    """EXPERIMENTAL: y = [relu](conv3x3(x)) (+res1) on the bf16 matrix cores, fp32-accurate 3-way split"""
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_l().dinv_conv3x3_bf16x3(ctypes.byref(g), ptr(x), ptr(wsplit), cin, cout, ptr(y), ptr(res1), int(relu),
+                                   int(planes), stream_ptr(y.device)))
+    if _prof is not None:
+        e1.record()
+        fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
+        _prof.append((e0, e1, "conv3x3_bf16x3_kernel", fl, (6.0 if planes == 3 else 3.0) * fl * 10 / 9))
 
 
 def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):

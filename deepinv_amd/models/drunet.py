@@ -30,6 +30,13 @@ def _use_winograd(g, pk) -> bool:
     return os.environ.get("DINV_WINOGRAD", "1") != "0"
 
 
+def _bf16_split_mode() -> int:
+    """EXPERIMENTAL opt-in: DINV_CONV_BF16X3=3 (six products, fp32-class accuracy) or =2 (three products, ~5e-6 per
+    layer) runs the ResBlock convolutions on the bf16 matrix cores instead of the fp32 Winograd kernel."""
+    v = os.environ.get("DINV_CONV_BF16X3", "")
+    return int(v) if v in ("2", "3") else 0
+
+
 def _conv_nd(dim):
     return {2: nn.Conv2d, 3: nn.Conv3d}[dim]
 
@@ -181,7 +188,8 @@ class DRUNet(Denoiser):
             p64 = K.pack_conv3x3_weight(w)
             p32 = K.pack_conv3x3_weight(w, mt=32) if p64[0].shape[3] == 64 else p64
             wino = K.pack_winograd_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0 and w.shape[1] >= 32) else None
-            return (p64, p32, wino)
+            split = K.pack_bf16x3_weight(w) if (_bf16_split_mode() and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0) else None
+            return (p64, p32, wino, split)
 
         e["head"] = c3(self.m_head)
         e["tail"] = c3(self.m_tail)
@@ -230,6 +238,9 @@ class DRUNet(Denoiser):
 
     def _conv_res(self, g, pk, x, y, relu=False, res1=None):
         """one ResBlock convolution: Winograd F(2x2,3x3) kernel when selected, else the direct MFMA kernel"""
+        if len(pk) > 3 and pk[3] is not None and _bf16_split_mode():
+            K.conv3x3_bf16x3(g, x, pk[3], pk[0][1], pk[0][2], y, res1=res1, relu=relu, planes=_bf16_split_mode())
+            return
         if pk[2] is not None and _use_winograd(g, pk):
             K.conv3x3_winograd(g, x, pk[2], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
             return

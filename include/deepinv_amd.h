@@ -146,6 +146,12 @@ int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const float* x2, c
  * relu and res1 are mutually exclusive (ResBlock conv1 / conv2, drunet.py:403-434). */
 int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w_wino, int32_t cin, int32_t cout,
                           float* y, const float* res1, int32_t relu, dinv_stream_t stream);
+/* EXPERIMENTAL (opt-in, DINV_CONV_BF16X3=1 in the Python layer): same operator as dinv_conv3x3_winograd on the BF16
+ * matrix cores: operands split exactly into bf16 parts, leading products, fp32 accumulate.  planes = 3: three parts,
+ * six products, fp32-level accuracy (~3e-7 per layer); planes = 2: two parts, three products (~5e-6 per layer).
+ * w_split: [cout/64][cin/8][plane 3][tap 9][co 64][8] bf16; cin % 8 == 0, cout % 64 == 0. */
+int dinv_conv3x3_bf16x3(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin, int32_t cout,
+                        float* y, const float* res1, int32_t relu, int32_t planes, dinv_stream_t stream);
 /* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin/8][cout][8] */
 int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                       const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
