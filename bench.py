@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 WINO_PMC_TRAFFIC = 1.4675e9   # bytes per conv3x3_wino_kernel launch, B=32 320x320 (see roofline below)
+MFMA_BF16_PEAK = 2500e12     # FLOP/s dense bf16 matrix (v_mfma_f32_32x32x16_bf16), MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12   # FLOP/s dense fp32 matrix (v_mfma_f32_32x32x2_f32)
 
 
@@ -143,13 +144,17 @@ def main():
         # dominant kernel = the one with the largest share of the timed region
         kname, kp = max(conv_prof.items(), key=lambda kv: kv[1]["ms"]) if conv_prof else ("none", None)
         achieved = kp["mfma_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
+        bf16 = "bf16" in kname   # opt-in bf16-split convolution: priced against the bf16 matrix peak
+        peak = MFMA_BF16_PEAK if bf16 else MFMA_F32_PEAK
         all_ms = sum(v["ms"] for v in conv_prof.values())
         all_direct = sum(v["direct_flops"] for v in conv_prof.values())
         res = {
             "metric": "PnP-PGD slices/sec (50 iters), 2D MRI 8-coil 320x320, 4x radial mask, DRUNet",
             "value": round(slices_per_s, 4), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (bf16 x%s exact operand split, f32 accumulate)" % os.environ["DINV_CONV_BF16X3"]
+                     if os.environ.get("DINV_CONV_BF16X3") in ("2", "3") else "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: 2D MRI 8-coil 320x320, 4x radial mask (80 spokes), PnP-PGD 50 it + "
                                    "DRUNet(2->2, random init), global batch %d" % args.batch,
                        "global_batch": args.batch, "per_gpu_batch": B_local, "iters": args.iters,
@@ -157,14 +162,15 @@ def main():
             # achieved = flops EXECUTED on the MFMA pipe by the dominant kernel / its HIP-event time; for the
             # Winograd F(2x2,3x3) kernel that is 16/36 of the direct-convolution count, which is reported
             # separately as the effective rate of all 3x3 convs (it may exceed the fp32 MFMA peak).
-            "roofline": {"bound": "mfma", "kernel": kname + " (DRUNet 3x3 conv, v_mfma_f32_32x32x2_f32)",
-                         "achieved": round(achieved / 1e12, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK, 4),
+            "roofline": {"bound": "mfma", "kernel": kname + (" (DRUNet 3x3 conv, v_mfma_f32_32x32x16_bf16, split operands)" if bf16
+                                                              else " (DRUNet 3x3 conv, v_mfma_f32_32x32x2_f32)"),
+                         "achieved": round(achieved / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4),
                          # HBM bytes per launch from separate PMC passes (profiles/pmc/r01_drunet_{rdreq,wrreq}.csv:
                          # TCC_EA0_RDREQ x 64 B x 2 (gfx950 wide-load correction) + TCC_EA0_WRREQ x 64 B, averaged
                          # over the 56 Winograd launches of one DRUNet call at this configuration); algorithmic
                          # bytes are ~1.1e9 (activations in + out + residual, weights): the kernel is MFMA-bound
-                         "traffic": WINO_PMC_TRAFFIC if (B_local == 32 and H == 320 and W == 320) else None,
+                         "traffic": WINO_PMC_TRAFFIC if (B_local == 32 and H == 320 and W == 320 and not bf16) else None,
                          "launches": kp["launches"] if kp else 0,
                          "avg_launch_ms": round(kp["ms"] / max(kp["launches"], 1), 4) if kp else 0.0,
                          "share_of_step": round(kp["ms"] * 1e-3 / elapsed, 4) if kp else 0.0,
