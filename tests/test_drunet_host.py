@@ -49,3 +49,37 @@ def test_tail_weight_pack():
         assert pk[ci // 8, ky * 3 + kx, co, ci % 8] == w[co, ci, ky, kx]
     with pytest.raises(ValueError):
         pack_tail_weight(torch.zeros(5, 16, 3, 3))
+
+
+def test_bf16_split_weight_pack_is_exact_and_laid_out():
+    """pack_bf16x3_weight: w = p1 + p2 + p3 with bf16 parts (error below 2^-24 |w|: the split loses nothing an fp32
+    product would keep), packed [Cout/64][Cin/8][plane 3][tap 9][co 64][8]; and the six leading products reproduce
+    an fp32 dot product to fp32 accuracy while the three-product form is ~2^-17 (the numbers behind drunet_bf16.hip)."""
+    from deepinv_amd.hip.drunet import pack_bf16x3_weight
+
+    g = torch.Generator().manual_seed(3)
+    cout, cin = 128, 24
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    pk = pack_bf16x3_weight(w)
+    assert pk.shape == (cout // 64, cin // 8, 3, 9, 64, 8) and pk.dtype == torch.bfloat16
+    rec = pk.float().sum(2)                                           # [ct, cb, tap, co, ci]
+    ref = w.reshape(cout // 64, 64, cin // 8, 8, 9).permute(0, 2, 4, 1, 3)
+    assert float((rec - ref).abs().max()) <= 2.0 ** -23 * float(ref.abs().max())
+    assert pk[1, 2, 0, 5, 7, 3] == w[64 + 7, 16 + 3, 1, 2].bfloat16()  # tap 5 = (ky 1, kx 2)
+
+    def split(x, n):
+        parts, r = [], x.clone()
+        for _ in range(n):
+            p = r.bfloat16().float()
+            parts.append(p)
+            r = r - p
+        return parts
+
+    a, b = torch.randn(64, 576, generator=g), torch.randn(576, 64, generator=g) / 24
+    exact = a.double() @ b.double()
+    rel = lambda o: float((o.double() - exact).norm() / exact.norm())
+    a3, b3 = split(a, 3), split(b, 3)
+    six = sum(a3[i] @ b3[j] for i, j in ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)))
+    a2, b2 = split(a, 2), split(b, 2)
+    three = a2[1] @ b2[0] + a2[0] @ b2[1] + a2[0] @ b2[0]
+    assert rel(six) < 5e-7 and rel(three) < 2e-5 and rel(a2[0] @ b2[0]) > 1e-3
