@@ -1,4 +1,4 @@
-"""``BaseOptim`` and the PGD / HQS / FISTA / GD front-ends
+"""``BaseOptim`` and the PGD / HQS front-ends
 (reference deepinv/optim/optimizers.py:94-881, 884-1058, 1459-1734)."""
 from __future__ import annotations
 
@@ -20,26 +20,6 @@ from .prior import ZeroPrior
 
 
 @dataclass
-class DEQConfig:
-    """Deep-equilibrium (implicit differentiation) options (optimizers.py:44-61)."""
-    jacobian_free: bool = False
-    anderson_acceleration_backward: bool = False
-    history_size_backward: int = 5
-    beta_backward: float = 1.0
-    eps_backward: float = 1e-4
-    max_iter_backward: int = 50
-
-
-@dataclass
-class AndersonAccelerationConfig:
-    """Anderson acceleration of the fixed-point iterations (optimizers.py:64-77)."""
-    history_size: int = 10
-    beta: float = 0.9
-    eps: float = 0.1
-    full_backprop: bool = False
-
-
-@dataclass
 class BacktrackingConfig:
     gamma: float = 0.1
     eta: float = 0.9
@@ -57,17 +37,9 @@ class BaseOptim(Reconstructor):
     def __init__(self, iterator, params_algo=MappingProxyType({"lambda": 1.0, "stepsize": 1.0}), data_fidelity=None,
                  prior=None, max_iter=100, crit_conv="residual", thres_conv=1e-5, early_stop=False, has_cost=False,
                  backtracking=None, custom_metrics=None, custom_init=None, get_output=lambda X: X["est"][0],
-                 unfold=False, trainable_params=None, DEQ=None, anderson_acceleration=False, verbose=False,
+                 unfold=False, trainable_params=None, verbose=False,
                  show_progress_bar=False, **kwargs):
         super().__init__()
-        if isinstance(DEQ, bool) or DEQ is None:   # optimizers.py:321-326
-            self.DEQ, self.DEQ_config = bool(DEQ), (DEQConfig() if DEQ else None)
-        else:
-            self.DEQ, self.DEQ_config = True, DEQ
-        if isinstance(anderson_acceleration, bool) or anderson_acceleration is None:   # optimizers.py:327-332
-            self.anderson_acceleration_config = AndersonAccelerationConfig() if anderson_acceleration else None
-        else:
-            self.anderson_acceleration_config = anderson_acceleration
         self.early_stop, self.crit_conv, self.verbose = early_stop, crit_conv, verbose
         self.show_progress_bar, self.max_iter = show_progress_bar, max_iter
         if isinstance(backtracking, bool):
@@ -122,8 +94,7 @@ class BaseOptim(Reconstructor):
             backtracking_check_fn=self.backtracking_check_fn, check_conv_fn=self.check_conv_fn,
             init_metrics_fn=self.init_metrics_fn, init_iterate_fn=self.init_iterate_fn,
             update_metrics_fn=self.update_metrics_fn, max_iter=max_iter, early_stop=early_stop,
-            backtracking_config=self.backtracking_config,
-            anderson_acceleration_config=self.anderson_acceleration_config, verbose=verbose,
+            backtracking_config=self.backtracking_config, verbose=verbose,
             show_progress_bar=show_progress_bar)
 
     # ---- per-iteration lookups (optimizers.py:464-500)
@@ -152,7 +123,13 @@ class BaseOptim(Reconstructor):
             else:
                 raise ValueError(f"Custom initial iterate must be a torch.Tensor, a tuple, or a dict. Got {type(init)}.")
         else:
-            X = {"est": (physics.A_adjoint(y), physics.A_adjoint(y))}
+            # the reference evaluates A^T y twice here and once more per PGD iteration; one evaluation serves the
+            # whole call (handed to the data-fidelity step through the FixedPoint call context)
+            aty = physics.A_adjoint(y)
+            ctx = getattr(self.fixed_point, "call_ctx", None)
+            if ctx is not None and not torch.is_grad_enabled():
+                ctx.put(physics, y, aty)
+            X = {"est": (aty, aty.clone())}
         X["cost"] = (cost_fn(X["est"][0], self.update_data_fidelity_fn(0), self.update_prior_fn(0),
                              self.update_params_fn(0), y, physics) if self.has_cost and cost_fn is not None else None)
         return X
@@ -212,50 +189,11 @@ class BaseOptim(Reconstructor):
             return True
         return False
 
-    def _deq_output(self, X, y, physics, **kwargs):
-        """Implicit differentiation at the equilibrium (optimizers.py:741-824): the loop ran without a graph; one
-        more tracked application of the iteration map T gives x* = T(x*) with d x*/d theta from T alone
-        (Jacobian-free mode), or - default - a gradient hook on x* that replaces the incoming gradient v by the
-        solution g of  g = J_T(x*)^T g + v  found by fixed-point iterations (optionally Anderson accelerated)."""
-        last = self.max_iter - 1
-        cur_df = self.update_data_fidelity_fn(last) if self.update_data_fidelity_fn else None
-        cur_prior = self.update_prior_fn(last) if self.update_prior_fn else None
-        cur_params = self.update_params_fn(last) if self.update_params_fn else None
-        T = self.fixed_point.iterator
-        x = T(X, cur_df, cur_prior, cur_params, y, physics, **kwargs)["est"][0]
-        cfg = self.DEQ_config
-        if cfg.jacobian_free or not x.requires_grad:
-            return x
-        x0 = x.clone().detach().requires_grad_()
-        f0 = T({"est": (x0,)}, cur_df, cur_prior, cur_params, y, physics, **kwargs)["est"][0]
-
-        class _AdjointMap(nn.Module):   # g -> J^T g + v, in the iterate-dictionary protocol of FixedPoint
-            cost_fn = None
-            has_cost = False
-
-            def __init__(self, v):
-                super().__init__()
-                self.v = v
-
-            def forward(self, G, *args, **kw):
-                return {"est": (torch.autograd.grad(f0, x0, G["est"][0], retain_graph=True)[0] + self.v,)}
-
-        def solve_adjoint(v):
-            aa = (AndersonAccelerationConfig(cfg.history_size_backward, cfg.beta_backward, cfg.eps_backward)
-                  if cfg.anderson_acceleration_backward else None)
-            solver = FixedPoint(_AdjointMap(v), init_iterate_fn=lambda *a, **k: {"est": (v,)},
-                                max_iter=cfg.max_iter_backward, check_conv_fn=self.check_conv_fn,
-                                anderson_acceleration_config=aa)
-            return solver({"est": (v,)}, None)[0]["est"][0]
-
-        x.register_hook(solve_adjoint)
-        return x
-
     def forward(self, y, physics, init=None, x_gt=None, compute_metrics=False, **kwargs):
-        """no_grad unless unfolding; DEQ differentiates only through the equilibrium (optimizers.py:826-881)"""
-        with (torch.no_grad() if (not self.unfold or self.DEQ) else nullcontext()):
+        """no_grad unless unfolding (optimizers.py:826-881)"""
+        with (torch.no_grad() if not self.unfold else nullcontext()):
             X, metrics = self.fixed_point(y, physics, init=init, x_gt=x_gt, compute_metrics=compute_metrics, **kwargs)
-        x = self._deq_output(X, y, physics, **kwargs) if self.DEQ else self.get_output(X)
+        x = self.get_output(X)
         return (x, metrics) if compute_metrics else x
 
 
@@ -286,7 +224,7 @@ def optim_builder(iteration, max_iter=100, params_algo=MappingProxyType({"lambda
                      params_algo=dict(params_algo), max_iter=max_iter, **kwargs).eval()
 
 
-def _front_end(iteration_cls, extra=()):
+def _front_end(iteration_cls):
     class _Algo(BaseOptim):
         def __init__(self, data_fidelity=None, prior=None, lambda_reg=1.0, stepsize=1.0, g_param=None,
                      sigma_denoiser=None, max_iter=100, crit_conv="residual", thres_conv=1e-5, early_stop=False,
@@ -296,8 +234,6 @@ def _front_end(iteration_cls, extra=()):
                 g_param = sigma_denoiser
             if params_algo is None:
                 params_algo = {"lambda": lambda_reg, "stepsize": stepsize, "g_param": g_param}
-                for k in extra:
-                    params_algo[k] = kwargs.pop(k, 3)
             super().__init__(iteration_cls(g_first=g_first, cost_fn=cost_fn), data_fidelity=data_fidelity, prior=prior,
                              params_algo=params_algo, max_iter=max_iter, crit_conv=crit_conv, thres_conv=thres_conv,
                              early_stop=early_stop, backtracking=backtracking, custom_metrics=custom_metrics,
@@ -309,7 +245,3 @@ PGD = _front_end(_its.PGDIteration)    # optimizers.py:1596-1734
 PGD.__name__ = PGD.__qualname__ = "PGD"
 HQS = _front_end(_its.HQSIteration)    # optimizers.py:1459-1593
 HQS.__name__ = HQS.__qualname__ = "HQS"
-FISTA = _front_end(_its.FISTAIteration, extra=("a",))
-FISTA.__name__ = FISTA.__qualname__ = "FISTA"
-GD = _front_end(_its.GDIteration)
-GD.__name__ = GD.__qualname__ = "GD"

@@ -1,1 +1,1 @@
-from .unfolded import BaseUnfold, unfolded_builder, DEQ_builder
+from .unfolded import BaseUnfold, unfolded_builder

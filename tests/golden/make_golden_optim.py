@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """Golden vectors for loop options of `BaseOptim` / `FixedPoint` from the REAL reference (deepinv v0.4.1 at
-/root/reference through oracle/ref_shim.py): Anderson acceleration (fixed_point.py:116-260) and backtracking
-(optimizers.py:162-175 region).  Plain matrix physics in float64, so the vectors pin the loop logic itself.
+/root/reference through oracle/ref_shim.py): plain PGD and backtracking (optimizers.py:655-701).  Plain matrix physics in float64, so the vectors pin the loop logic itself.
 
     python tests/golden/make_golden_optim.py
 """
@@ -50,14 +49,10 @@ step = 0.9 / float(torch.linalg.matrix_norm(M, 2) ** 2)
 phys = MatPhysics(M)
 out = {"M": M.numpy(), "y": y.numpy(), "step": np.float64(step)}
 
-from deepinv.optim.optimizers import AndersonAccelerationConfig, BacktrackingConfig  # noqa: E402
+from deepinv.optim.optimizers import BacktrackingConfig  # noqa: E402
 
 cases = {
     "pgd_plain": dict(),
-    "pgd_anderson_default": dict(anderson_acceleration=True),
-    "pgd_anderson_h3": dict(anderson_acceleration=AndersonAccelerationConfig(history_size=3, beta=0.8, eps=1e-4)),
-    "pgd_anderson_full": dict(anderson_acceleration=AndersonAccelerationConfig(history_size=4, beta=1.0, eps=1e-3,
-                                                                              full_backprop=True)),
     "pgd_backtracking": dict(backtracking=BacktrackingConfig(gamma=0.1, eta=0.5, max_iter=20), stepsize_scale=8.0),
 }
 for name, kw in cases.items():
@@ -70,26 +65,3 @@ for name, kw in cases.items():
     out[name] = x.numpy()
     print(name, x[0, :3].numpy())
 np.savez_compressed(os.path.join(OUT, "optim_loop_options.npz"), **out)
-
-# ---------------------------------------------------------------- DEQ (implicit differentiation, optimizers.py:741-824)
-from deepinv.optim.optimizers import DEQConfig  # noqa: E402
-
-deq_cases = {
-    "deq_default": DEQConfig(),
-    "deq_jacobian_free": DEQConfig(jacobian_free=True),
-    "deq_anderson_backward": DEQConfig(anderson_acceleration_backward=True, history_size_backward=3, max_iter_backward=30),
-}
-deq = {}
-for name, cfg in deq_cases.items():
-    yq = y.clone().requires_grad_()
-    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=L1(), lambda_reg=0.2, stepsize=step, max_iter=40,
-                           early_stop=False, unfold=True, trainable_params=["stepsize", "lambda_reg"], DEQ=cfg)
-    x = model(yq, phys)
-    (x ** 2).sum().backward()
-    params = dict(model.named_parameters())
-    deq[name + "_x"] = x.detach().numpy()
-    deq[name + "_gy"] = yq.grad.numpy()
-    for k, p in params.items():
-        deq[name + "_g_" + k.replace(".", "_")] = p.grad.numpy()
-    print(name, x.detach()[0, :2].numpy(), yq.grad[0, :2].numpy(), {k: float(p.grad) for k, p in params.items()})
-np.savez_compressed(os.path.join(OUT, "optim_deq.npz"), M=M.numpy(), y=y.numpy(), step=np.float64(step), **deq)

@@ -136,3 +136,35 @@ def test_diffpir_superresolution(dev, monkeypatch):
                       + cpu.sqrt_1m_alphas_cumprod[t_im1] * 0.1 ** 0.5 * fake_randn_like(xx))
         ref = xx / 2 + 0.5
     assert rel_err(out, ref) < 1e-3
+
+
+def test_back_to_back_reconstructions_use_their_own_adjoint(dev):
+    """Round-1 regression (stale A^T y): `model(y1, p); del y1; model(y2, p)` where the caching allocator hands y2
+    the freed block of y1 (same address, same shape, version counter 0 - the kernels write through raw pointers).
+    Both reconstructions must match the oracle (reference: A^T y recomputed every call, data_fidelity.py:335-338)."""
+    import deepinv_amd as dinv
+
+    H = W = 32
+    g = torch.Generator().manual_seed(4)
+    maps = torch.randn(1, 4, H, W, dtype=torch.complex64, generator=g) / 2
+    mask = dinv.utils.radial_mask(H, W, 12)
+    sd = OD.init_state_dict(2, 2, seed=1)
+    den = dinv.models.DRUNet(2, 2, pretrained=None).to(dev).eval()
+    den.load_state_dict(sd)
+    phys = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, H, W), device=dev)
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=1.0, g_param=0.05, max_iter=3)
+    A = lambda v: O.multicoil_A(v, maps, mask)
+    AT = lambda v: O.multicoil_AT(v, maps, mask)
+    xs = [torch.rand(2, 2, H, W, generator=g) for _ in range(4)]
+    ptrs, outs = [], []
+    for x in xs:
+        xd = x.to(dev)
+        y = phys.A(xd)             # fresh tensor from the caching allocator
+        ptrs.append(y.data_ptr())
+        outs.append(model(y, phys).cpu())
+        del y, xd
+    assert len(set(ptrs)) < len(ptrs), "the allocator never reused the measurement's block: scenario not exercised"
+    with torch.no_grad():
+        for x, out in zip(xs, outs):
+            ref = OO.pnp_pgd(A(x), A, AT, lambda u, s: OD.drunet(sd, u, s), max_iter=3)
+            assert rel_err(out, ref) < 1e-4
