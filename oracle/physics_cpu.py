@@ -296,7 +296,7 @@ def downsampling_prox_l2(z, y, gamma, filter, factor, img_size):
     """closed form for circular padding (blur.py:331-363)"""
     Fh = filter_fft(filter, img_size, real_fft=False)
     Fhc, Fh2 = torch.conj(Fh), torch.conj(Fh) * Fh
-    z_hat = downsampling_AT(y, filter, factor, img_size) + z / gamma
+    z_hat = downsampling_AT(y, filter, factor, img_size) + 1 / gamma * z
     Fz = torch.fft.fft2(z_hat)
 
     def splits(a, sf):
