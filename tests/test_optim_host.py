@@ -223,3 +223,67 @@ def test_adjoint_of_y_evaluated_once_per_call():
     with torch.inference_mode():          # tensors without version counters must work too
         dinv.optim.PGD(data_fidelity=dinv.optim.L2(), stepsize=0.01, max_iter=7)(torch.randn(2, 5), phys)
     assert calls["adj"] == 1 + 7
+
+
+def _gold(name):
+    import os
+
+    import numpy as np
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    return {k: torch.from_numpy(d[k]) for k in d.files}
+
+
+def test_unfolded_builder_host_logic_matches_reference_golden():
+    """The host side of unfolded_builder("PGD") (parameter wrapping, graph through the loop) against loss + gradients
+    produced by the REAL reference (tests/golden/make_golden_r2.py); physics = the CPU oracle operators."""
+    from oracle import physics_cpu as O
+
+    d = _gold("unfolded_pgd")
+    maps = torch.view_as_complex(d["maps"].contiguous())
+
+    class PhysCPU(dinv.physics.LinearPhysics):
+        def A(self, v, **k):
+            return O.multicoil_A(v, maps, d["mask"], True)
+
+        def A_adjoint(self, v, **k):
+            return O.multicoil_AT(v, maps, d["mask"], True)
+
+    class Den(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv3d(2, 2, 3, padding=1)
+            with torch.no_grad():
+                self.c.weight.copy_(d["wden"])
+                self.c.bias.copy_(d["bden"])
+
+        def forward(self, u, s):
+            return u - s * self.c(u)
+
+    model = dinv.unfolded.unfolded_builder("PGD", data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(Den()),
+                                           params_algo={"stepsize": 0.8, "g_param": 0.05, "lambda": 1.0}, max_iter=3,
+                                           trainable_params=["stepsize", "g_param"])
+    rec = model(d["y"], PhysCPU())
+    loss = (rec - d["x"]).pow(2).mean()
+    loss.backward()
+    assert torch.allclose(rec, d["rec"], rtol=1e-5, atol=1e-6)
+    assert abs(float(loss) - float(d["loss"])) / float(d["loss"]) < 1e-5
+    for n, p in model.named_parameters():
+        ref = d["grad_" + n.replace(".", "_")]
+        assert float((p.grad - ref).norm() / ref.norm()) < 1e-4, n
+
+
+def test_diffpir_schedule_matches_reference_golden():
+    """DiffPIR.get_alpha_beta / get_noise_schedule (diffusion.py:323-375): host-side schedule of the product against the
+    REAL reference's, three settings (this is pure host logic: no kernels involved)."""
+    for name, kw in (("diffpir", dict(sigma=0.05, max_iter=6, lambda_=7.0)), ("diffpir_schedule_a", None),
+                     ("diffpir_schedule_b", None)):
+        d = _gold(name)
+        if kw is None:
+            kw = dict(sigma=float(d["sigma"]), max_iter=int(d["max_iter"]), lambda_=float(d["lambda_"]))
+        s = dinv.sampling.DiffPIR(None, None, zeta=0.1, device="cpu", **kw)
+        rhos, sigmas, seq = s.get_noise_schedule(sigma=torch.tensor(kw["sigma"]))   # as forward() does (:441-443)
+        assert torch.equal(seq, d["seq"])
+        assert torch.allclose(sigmas, d["sigmas"], rtol=1e-6) and torch.allclose(rhos, d["rhos"], rtol=1e-6)
+        if "reduced" in d:
+            assert torch.allclose(s.reduced_alpha_cumprod, d["reduced"], rtol=1e-7)
