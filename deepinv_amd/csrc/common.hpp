@@ -8,6 +8,13 @@
 
 #include "../../include/deepinv_amd.h"
 
+// dynamic LDS of a kernel as a typed pointer (the host emulation used by the CPU tests supplies its own definition)
+#ifndef DINV_DYN_LDS
+#define DINV_DYN_LDS(T, name)                                                   \
+    extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[];  \
+    T* name = reinterpret_cast<T*>(name##_raw)
+#endif
+
 namespace dinv {
 
 // ---------------------------------------------------------------- error handling

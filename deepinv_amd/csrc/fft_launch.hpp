@@ -56,7 +56,7 @@ struct C2CIo {
 template <class Io, bool INV>
 __global__ __launch_bounds__(256) void fft_rows_kernel(Io io, int64_t nlines, int lpb, dinv_fft_plan plan,
                                                        const void* table, int centered, float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DINV_DYN_LDS(unsigned char, smem);
     const int N = plan.n;
     const int LS = (N % 2 == 0) ? N + 1 : N;
     const int tid = threadIdx.x;
@@ -92,7 +92,7 @@ template <class Io, bool INV>
 __global__ __launch_bounds__(256) void fft_cols_kernel(Io io, int64_t Q, int tq, int64_t qtiles,
                                                        dinv_fft_plan plan, const void* table, int centered,
                                                        float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DINV_DYN_LDS(unsigned char, smem);
     const int N = plan.n;
     const int LS = (N % 2 == 0) ? N + 1 : N;
     const int tid = threadIdx.x;

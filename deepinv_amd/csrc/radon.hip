@@ -69,7 +69,7 @@ template <int NB>
 __global__ __launch_bounds__(256) void radon_fwd_kernel(RadonGeom g, const float* __restrict__ xp,
                                                         const float* __restrict__ xn, const float2* __restrict__ cs,
                                                         float* __restrict__ sino) {
-    extern __shared__ float xn_s[];
+    DINV_DYN_LDS(float, xn_s);
     for (int i = threadIdx.x; i < g.G; i += 256) xn_s[i] = xn[i];
     __syncthreads();
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -132,7 +132,7 @@ template <int NB>
 __global__ __launch_bounds__(256) void radon_adj_kernel(RadonGeom g, const float* __restrict__ sp,
                                                         const float* __restrict__ xn, const float2* __restrict__ cs,
                                                         float* __restrict__ x) {
-    extern __shared__ float smem[];
+    DINV_DYN_LDS(float, smem);
     float* xn_s = smem;                                         // G
     float2* cs_s = reinterpret_cast<float2*>(smem + ((g.G + 1) / 2) * 2);  // A
     for (int i = threadIdx.x; i < g.G; i += 256) xn_s[i] = xn[i];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void radon_adj_kernel(RadonGeom g, const float
 __global__ __launch_bounds__(256) void iradon_kernel(RadonGeom g, const float* __restrict__ sino,
                                                      const float* __restrict__ xn, const float2* __restrict__ cs,
                                                      const float* __restrict__ ixtab, float* __restrict__ out) {
-    extern __shared__ float smem[];
+    DINV_DYN_LDS(float, smem);
     float2* cs_s = reinterpret_cast<float2*>(smem);
     float* ix_s = smem + 2 * g.A;
     for (int i = threadIdx.x; i < g.A; i += 256) { cs_s[i] = cs[i]; ix_s[i] = ixtab[i]; }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void iradon_kernel(RadonGeom g, const float* _
 constexpr int RJ = 8;  // outputs per thread
 __global__ __launch_bounds__(256) void ramp_kernel(int n_img, int N, int A, const float* __restrict__ y,
                                                    float* __restrict__ out) {
-    extern __shared__ float h_s[];  // h[d], d = 0..N-1
+    DINV_DYN_LDS(float, h_s);  // h[d], d = 0..N-1
     for (int d = threadIdx.x; d < N; d += 256) {
         float v = 0.f;
         if (d == 0) v = 0.5f;

@@ -143,4 +143,19 @@ def fft_plan(n: int, device) -> tuple[FftPlan, torch.Tensor]:
     check(l.dinv_fft_plan_init(int(n), ctypes.byref(plan), ctypes.c_void_p(host.data_ptr())))
     table = host.to(device)
     _plan_cache[key] = (plan, table)
+    _plan_host[int(n)] = host
     return plan, table
+
+
+_plan_host: dict = {}
+
+
+def fft_plan_host_table(n: int) -> torch.Tensor:
+    """the host copy of the table dinv_fft_plan_init wrote for length n (twiddles + digit-reversal positions)"""
+    if int(n) not in _plan_host:
+        l = lib()
+        plan = FftPlan()
+        host = torch.empty(l.dinv_fft_table_bytes(int(n)), dtype=torch.uint8)
+        check(l.dinv_fft_plan_init(int(n), ctypes.byref(plan), ctypes.c_void_p(host.data_ptr())))
+        _plan_host[int(n)] = host
+    return _plan_host[int(n)]

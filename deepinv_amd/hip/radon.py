@@ -1,11 +1,16 @@
-"""ctypes + autograd wrappers for the Radon kernels (csrc/radon.hip)."""
+"""ctypes + autograd wrappers for the Radon kernels (csrc/radon_tiled.hip, csrc/radon.hip).
+
+Default path: the LDS-tiled forward / adjoint kernels and the FFT ramp filter; the operator norm of a normalised
+``Tomography`` is handed to the kernels as a DEVICE scalar (no host read-back per call).  ``DINV_RADON_TILED=0``
+selects the round-1 gather kernels (kept for detector counts above the tiled kernels' limit and as a cross-check)."""
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
-from . import check, f32c, lib, ptr, require_hip, stream_ptr
+from . import FftPlan, check, f32c, fft_plan, fft_plan_host_table, lib, ptr, require_hip, stream_ptr
 
 
 class RadonDesc(ctypes.Structure):
@@ -14,6 +19,14 @@ class RadonDesc(ctypes.Structure):
                 ("scale", ctypes.c_float), ("reserved", ctypes.c_int32)]
 
 
+class RadonPlan(ctypes.Structure):
+    _fields_ = [("grid", ctypes.c_int32), ("n_angles", ctypes.c_int32), ("kw", ctypes.c_int32), ("band_h", ctypes.c_int32),
+                ("win_w", ctypes.c_int32), ("n_jblocks", ctypes.c_int32), ("n_bands", ctypes.c_int32),
+                ("n_chunks_plain", ctypes.c_int32), ("n_chunks_swap", ctypes.c_int32), ("fits", ctypes.c_int32),
+                ("blob_words", ctypes.c_int32), ("widest_window", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+
+
+TILED_MAX_GRID = 4096   # MAXG in csrc/radon_tiled.hip
 _declared = False
 
 
@@ -22,19 +35,35 @@ def _l():
     l = lib()
     if not _declared:
         vp, i32, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_size_t
-        D = ctypes.POINTER(RadonDesc)
+        D, P, F = ctypes.POINTER(RadonDesc), ctypes.POINTER(RadonPlan), ctypes.POINTER(FftPlan)
         l.dinv_radon_workspace_bytes.restype = sz
         l.dinv_radon_workspace_bytes.argtypes = [D, i32]
         l.dinv_radon_forward.argtypes = [D, vp, vp, vp, vp, vp, sz, vp]
         l.dinv_radon_adjoint.argtypes = [D, vp, vp, vp, vp, vp, sz, vp]
         l.dinv_radon_ramp.argtypes = [i32, i32, i32, vp, vp, vp]
         l.dinv_radon_backproject.argtypes = [D, vp, vp, vp, vp, vp, vp]
+        l.dinv_radon_plan_bytes.restype = sz
+        l.dinv_radon_plan_bytes.argtypes = [D]
+        l.dinv_radon_plan_init.argtypes = [D, vp, P, vp]
+        l.dinv_radon_tiled_workspace_bytes.restype = sz
+        l.dinv_radon_tiled_workspace_bytes.argtypes = [D, i32]
+        l.dinv_radon_forward_tiled.argtypes = [D, P, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        l.dinv_radon_adjoint_tiled.argtypes = [D, vp, vp, vp, vp, vp, vp, sz, vp]
+        l.dinv_radon_ramp_padded_size.restype = i32
+        l.dinv_radon_ramp_padded_size.argtypes = [i32]
+        l.dinv_radon_ramp_filter_init.argtypes = [i32, vp, vp]
+        l.dinv_radon_ramp_fft.argtypes = [i32, i32, i32, i32, F, vp, vp, vp, vp, vp]
         _declared = True
     return l
 
 
+def _use_tiled(grid: int) -> bool:
+    return grid <= TILED_MAX_GRID and os.environ.get("DINV_RADON_TILED", "1") != "0"
+
+
 class RadonGeometry:
-    """Host-side tables built exactly like the reference builds its grids (radon.py:70-71, 242-250, 334-341)."""
+    """Host-side tables built exactly like the reference builds its grids (radon.py:70-71, 242-250, 334-341), plus the
+    window plan of the tiled forward kernel (angle chunks, per-band LDS windows; ``dinv_radon_plan_init``)."""
 
     def __init__(self, angles_deg: torch.Tensor, width: int, circle: bool, device):
         sqrt2 = (2 * torch.ones(1)).sqrt()
@@ -49,37 +78,67 @@ class RadonGeometry:
         a = angles_deg.detach().to("cpu", torch.float32)
         theta = a * 4 * torch.ones(1).atan() / 180           # deg2rad (radon.py:70-71)
         self.A = int(a.numel())
-        self.cs = torch.stack([theta.cos(), theta.sin()], dim=1).contiguous().to(device)
+        cs_host = torch.stack([theta.cos(), theta.sin()], dim=1).contiguous()
+        self.cs = cs_host.to(device)
         self.xn = torch.linspace(-1, 1, self.G).to(device)   # affine_grid base grid, align_corners=True
         # IRadon grid x-coordinate of angle column a (radon.py:474-489) -> unnormalised like grid_sample does
         X = torch.arange(self.A, dtype=torch.float32) * 2.0 / (self.A - 1) - 1.0 if self.A > 1 else torch.zeros(1)
         self.ixtab = (((X + 1.0) / 2) * (self.A - 1)).contiguous().to(device)
         self.device = torch.device(device)
+        self.plan = self.plan_dev = None
+        if self.device.type == "cuda" and self.G <= TILED_MAX_GRID:
+            d = self.desc(1, 1.0)
+            blob = torch.zeros(_l().dinv_radon_plan_bytes(ctypes.byref(d)) // 4, dtype=torch.int32)
+            self.plan = RadonPlan()
+            check(_l().dinv_radon_plan_init(ctypes.byref(d), ptr(cs_host), ctypes.byref(self.plan), ptr(blob)))
+            self.plan_dev = blob[: self.plan.blob_words].to(device)
 
     def desc(self, n_img: int, scale: float) -> RadonDesc:
         return RadonDesc(n_img, self.W, self.G, self.pad_before, self.A, int(self.circle), float(scale), 0)
 
 
-def _fwd(x, geo: RadonGeometry, scale):
+def _norm_ptr(norm, dev):
+    if norm is None:
+        return ptr(None)
+    if norm.device != dev or norm.dtype != torch.float32:
+        raise RuntimeError("the operator norm must be a float32 scalar on the operator's device")
+    return ptr(norm)
+
+
+def _fwd(x, geo: RadonGeometry, norm, scale=1.0):
+    """x [B,C,W,W] -> [B,C,G,A] / norm * scale"""
     dev = require_hip(x, geo.xn)
     x = f32c(x)
     B, C, H, W = x.shape
-    d = geo.desc(B * C, scale)
     sino = torch.empty((B, C, geo.G, geo.A), device=dev, dtype=torch.float32)
+    if _use_tiled(geo.G) and geo.plan is not None:
+        d = geo.desc(B * C, scale)
+        ws = torch.empty(_l().dinv_radon_tiled_workspace_bytes(ctypes.byref(d), 0), device=dev, dtype=torch.uint8)
+        check(_l().dinv_radon_forward_tiled(ctypes.byref(d), ctypes.byref(geo.plan), ptr(geo.plan_dev), ptr(x), ptr(geo.xn),
+                                            ptr(geo.cs), _norm_ptr(norm, dev), ptr(sino), ptr(ws), ws.numel(),
+                                            stream_ptr(dev)))
+        return sino
+    d = geo.desc(B * C, scale if norm is None else scale / float(norm))   # gather kernels: host scalar
     ws = torch.empty(_l().dinv_radon_workspace_bytes(ctypes.byref(d), 0), device=dev, dtype=torch.uint8)
     check(_l().dinv_radon_forward(ctypes.byref(d), ptr(x), ptr(geo.xn), ptr(geo.cs), ptr(sino), ptr(ws), ws.numel(),
                                   stream_ptr(dev)))
     return sino
 
 
-def _adj(y, geo: RadonGeometry, scale):
+def _adj(y, geo: RadonGeometry, norm, scale=1.0):
     dev = require_hip(y, geo.xn)
     y = f32c(y)
     B, C, G, A = y.shape
     if G != geo.G or A != geo.A:
         raise ValueError(f"sinogram of shape {tuple(y.shape)} does not match the operator ({geo.G} detectors, {geo.A} angles)")
-    d = geo.desc(B * C, scale)
     x = torch.empty((B, C, geo.W, geo.W), device=dev, dtype=torch.float32)
+    if _use_tiled(geo.G):
+        d = geo.desc(B * C, scale)
+        ws = torch.empty(_l().dinv_radon_tiled_workspace_bytes(ctypes.byref(d), 1), device=dev, dtype=torch.uint8)
+        check(_l().dinv_radon_adjoint_tiled(ctypes.byref(d), ptr(y), ptr(geo.xn), ptr(geo.cs), _norm_ptr(norm, dev), ptr(x),
+                                            ptr(ws), ws.numel(), stream_ptr(dev)))
+        return x
+    d = geo.desc(B * C, scale if norm is None else scale / float(norm))
     ws = torch.empty(_l().dinv_radon_workspace_bytes(ctypes.byref(d), 1), device=dev, dtype=torch.uint8)
     check(_l().dinv_radon_adjoint(ctypes.byref(d), ptr(y), ptr(geo.xn), ptr(geo.cs), ptr(x), ptr(ws), ws.numel(),
                                   stream_ptr(dev)))
@@ -88,24 +147,24 @@ def _adj(y, geo: RadonGeometry, scale):
 
 class _RadonFwd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, geo, scale):
-        ctx.geo, ctx.scale = geo, scale
-        return _fwd(x, geo, scale)
+    def forward(ctx, x, geo, norm):
+        ctx.geo, ctx.norm = geo, norm
+        return _fwd(x, geo, norm)
 
     @staticmethod
     def backward(ctx, g):
-        return _RadonAdj.apply(g, ctx.geo, ctx.scale), None, None
+        return _RadonAdj.apply(g, ctx.geo, ctx.norm), None, None
 
 
 class _RadonAdj(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, geo, scale):
-        ctx.geo, ctx.scale = geo, scale
-        return _adj(y, geo, scale)
+    def forward(ctx, y, geo, norm):
+        ctx.geo, ctx.norm = geo, norm
+        return _adj(y, geo, norm)
 
     @staticmethod
     def backward(ctx, g):
-        return _RadonFwd.apply(g, ctx.geo, ctx.scale), None, None
+        return _RadonFwd.apply(g, ctx.geo, ctx.norm), None, None
 
 
 def iradon_backproject(y, geo: RadonGeometry, scale=1.0):
@@ -132,7 +191,7 @@ class _ApplyRadon(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, geo, scale, adjoint):
         ctx.geo, ctx.scale, ctx.adjoint = geo, scale, adjoint
-        return iradon_backproject(x, geo, scale) if adjoint else _fwd(x, geo, scale)
+        return iradon_backproject(x, geo, scale) if adjoint else _fwd(x, geo, None, scale)
 
     @staticmethod
     def backward(ctx, g):
@@ -143,12 +202,34 @@ def apply_radon(x, geo, scale, adjoint):
     return _ApplyRadon.apply(x, geo, float(scale), bool(adjoint))
 
 
-def radon_forward(x, geo, scale=1.0):
-    return _RadonFwd.apply(x, geo, float(scale))
+def radon_forward(x, geo, norm=None):
+    """Radon transform divided by the device scalar `norm` (None: unnormalised)"""
+    return _RadonFwd.apply(x, geo, norm)
 
 
-def radon_adjoint(y, geo, scale=1.0):
-    return _RadonAdj.apply(y, geo, float(scale))
+def radon_adjoint(y, geo, norm=None):
+    return _RadonAdj.apply(y, geo, norm)
+
+
+# --------------------------------------------------------------------------- ramp filter
+_ramp_cache: dict = {}
+
+
+def _ramp_tables(n_det: int, device):
+    """(P, fft plan, device fft table, device filter) of the reference's zero-padded rFFT ramp filter (radon.py:79-162)"""
+    device = torch.device(device)
+    key = (int(n_det), device.index if device.index is not None else torch.cuda.current_device())
+    hit = _ramp_cache.get(key)
+    if hit is None:
+        P = int(_l().dinv_radon_ramp_padded_size(int(n_det)))
+        plan, table = fft_plan(P, device)
+        filt = torch.empty(P, dtype=torch.float32)
+        check(_l().dinv_radon_ramp_filter_init(P, ptr(fft_plan_host_table(P)), ptr(filt)))
+        hit = _ramp_cache[key] = (P, plan, table, filt.to(device))
+    return hit
+
+
+RAMP_FFT_MAX_P = 8192   # one complex column of P points + the twiddles must fit the 160 KiB LDS
 
 
 class _Ramp(torch.autograd.Function):
@@ -161,11 +242,19 @@ class _Ramp(torch.autograd.Function):
         B, C, N, A = y.shape
         out = torch.empty_like(y)
         n = B * C
+        P = int(_l().dinv_radon_ramp_padded_size(int(N)))
+        use_fft = P <= RAMP_FFT_MAX_P and os.environ.get("DINV_RAMP_FFT", "1") != "0"
+        if use_fft:
+            P, plan, table, filt = _ramp_tables(N, dev)
         step = 65535
         for s in range(0, n, step):
             e = min(n, s + step)
             yy, oo = y.view(n, N, A)[s:e], out.view(n, N, A)[s:e]
-            check(_l().dinv_radon_ramp(e - s, N, A, ptr(yy), ptr(oo), stream_ptr(dev)))
+            if use_fft:
+                check(_l().dinv_radon_ramp_fft(e - s, N, A, P, ctypes.byref(plan), ptr(table), ptr(filt), ptr(yy), ptr(oo),
+                                               stream_ptr(dev)))
+            else:
+                check(_l().dinv_radon_ramp(e - s, N, A, ptr(yy), ptr(oo), stream_ptr(dev)))
         return out
 
     @staticmethod

@@ -2,8 +2,8 @@
 
 Differences from the reference, all internal: no precomputed sampling grids (3 GB at 512/720 angles),
 the exact adjoint is a deterministic gather kernel instead of an autograd replay
-(``adjoint_via_backprop=True`` keeps its meaning: *exact* adjoint), and the ramp filter is a direct
-convolution.  Fan-beam geometry is out of scope.
+(``adjoint_via_backprop=True`` keeps its meaning: *exact* adjoint), the ramp filter is the reference's zero-padded
+rFFT product done in one LDS-resident kernel, and the operator norm of ``normalize=True`` stays on the device.  Fan-beam geometry is out of scope.
 """
 from __future__ import annotations
 
@@ -55,7 +55,7 @@ class Tomography(LinearPhysics):
         self.dtype = dtype
         self.parallel_computation = parallel_computation  # kept for API compatibility; no effect here
         self.filter = RampFilter(dtype=dtype)
-        self._geo = None
+        self._geo = self._geo_key = None
         if normalize is None:
             warn("The default value of `normalize` is not specified and will be automatically set to `True`. "
                  "Set `normalize` explicitly to `True` or `False` to avoid this warning.")
@@ -72,28 +72,52 @@ class Tomography(LinearPhysics):
             self.normalize = True
         self.to(device)
 
-    # ---- geometry tables live on the device of the data; rebuilt if the module moved
+    # ---- geometry tables live on the device of the data; rebuilt if the module moved or the angles changed
     def _geometry(self, device):
-        if self._geo is None or self._geo.device != torch.device(device) or self._geo.A != self.angles.numel():
-            self._geo = hr.RadonGeometry(self.angles, self.img_width, self.circle, device)
+        a = self.angles
+        ver = None if a.is_inference() else a._version
+        key = (torch.device(device), a.data_ptr(), ver, a.numel())
+        if self._geo is None or self._geo_key != key:
+            self._geo = hr.RadonGeometry(a, self.img_width, self.circle, device)
+            self._geo_key = key
         return self._geo
 
-    def _scale(self):
-        return 1.0 / float(self.operator_norm) if self.normalize else 1.0
+    def update_parameters(self, **kwargs):
+        """new angles (same count or not) rebuild the geometry tables (forward.py:249-276 semantics for buffers)"""
+        super().update_parameters(**kwargs)
+        self._geo = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._geo = None
+
+    def _norm(self):
+        """the operator norm as a DEVICE scalar handed to the kernels (no host read-back per call)"""
+        return self.operator_norm.reshape(1) if self.normalize else None
+
+    def _scale_host(self):
+        """1/||A|| as a host float for the ApplyRadon branch only; read back once per value of the buffer"""
+        if not self.normalize:
+            return 1.0
+        n = self.operator_norm
+        key = (n.data_ptr(), None if n.is_inference() else n._version)
+        if getattr(self, "_scale_key", None) != key:
+            self._scale_key, self._scale_val = key, 1.0 / float(n)
+        return self._scale_val
 
     def A(self, x, **kwargs):
         if not x.shape[-2:] == (self.img_width, self.img_width):
             raise ValueError(f"Input image size {x.shape[-2:]} does not match the operator image size "
                              f"{(self.img_width, self.img_width)}.")
         if self.adjoint_via_backprop:
-            return hr.radon_forward(x, self._geometry(x.device), self._scale())
-        return hr.apply_radon(x, self._geometry(x.device), self._scale(), False)   # ApplyRadon (radon.py:493-531)
+            return hr.radon_forward(x, self._geometry(x.device), self._norm())
+        return hr.apply_radon(x, self._geometry(x.device), self._scale_host(), False)   # ApplyRadon (radon.py:493-531)
 
     def A_adjoint(self, y, **kwargs):
         if self.adjoint_via_backprop:
-            return hr.radon_adjoint(y, self._geometry(y.device), self._scale())
+            return hr.radon_adjoint(y, self._geometry(y.device), self._norm())
         # ApplyRadon(adjoint=True) = iradon(y, filtering=False) / pi * 2A = plain interpolated sum; / operator_norm
-        return hr.apply_radon(y, self._geometry(y.device), self._scale(), True)
+        return hr.apply_radon(y, self._geometry(y.device), self._scale_host(), True)
 
     def fbp(self, y, **kwargs):
         """filtered back-projection (tomography.py:258-293)"""

@@ -194,6 +194,38 @@ int dinv_radon_backproject(const dinv_radon_desc* d, const float* sino, const fl
 int dinv_radon_ramp(int32_t n_img, int32_t n_det, int32_t n_angles, const float* sino, float* out,
                     dinv_stream_t stream);
 
+/* ---- LDS-tiled kernels (csrc/radon_tiled.hip): same operators, same arithmetic, operands staged in LDS.
+ * The plan is host-built once per (angles, grid): angle chunks by marching class/direction and the window
+ * column range of every (chunk, 64-ray block, 16-row band).  `fits` == 0 (irregular angle lists whose chunks
+ * span more than the LDS window) means: call dinv_radon_forward instead. */
+typedef struct {
+    int32_t grid, n_angles, kw, band_h, win_w, n_jblocks, n_bands;
+    int32_t n_chunks_plain, n_chunks_swap;
+    int32_t fits;
+    int32_t blob_words;      /* size of the device blob in 32-bit words (= dinv_radon_plan_bytes / 4) */
+    int32_t widest_window;   /* diagnostic: the largest window width any (chunk, block, band) needs */
+    int32_t reserved[4];
+} dinv_radon_plan;
+size_t dinv_radon_plan_bytes(const dinv_radon_desc* d);
+/* cs_host:[A][2] fp32 (cos,sin) as uploaded to the device; host_blob: dinv_radon_plan_bytes(d) bytes, to be
+ * copied to the device unchanged */
+int dinv_radon_plan_init(const dinv_radon_desc* d, const float* cs_host, dinv_radon_plan* plan, void* host_blob);
+size_t dinv_radon_tiled_workspace_bytes(const dinv_radon_desc* d, int32_t adjoint);
+/* norm_dev: optional device scalar; when non-NULL the result is DIVIDED by it (tomography.py:253-254: the
+ * operator norm stays on the device, no host read-back per call); d->scale still multiplies. */
+int dinv_radon_forward_tiled(const dinv_radon_desc* d, const dinv_radon_plan* plan, const void* plan_dev,
+                             const float* x, const float* xn, const float* cs, const float* norm_dev,
+                             float* sino, void* ws, size_t ws_bytes, dinv_stream_t stream);
+int dinv_radon_adjoint_tiled(const dinv_radon_desc* d, const float* sino, const float* xn, const float* cs,
+                             const float* norm_dev, float* x, void* ws, size_t ws_bytes, dinv_stream_t stream);
+/* FFT ramp filter exactly as the reference pads it (radon.py:79-162): P = dinv_radon_ramp_padded_size(n_det),
+ * plan/table = dinv_fft_plan_init(P), filter = dinv_radon_ramp_filter_init(P, host table) uploaded. */
+int32_t dinv_radon_ramp_padded_size(int32_t n_det);
+int dinv_radon_ramp_filter_init(int32_t P, const void* fft_host_table, float* host_filter_out);
+int dinv_radon_ramp_fft(int32_t n_img, int32_t n_det, int32_t n_angles, int32_t P, const dinv_fft_plan* plan,
+                        const void* fft_table_dev, const float* filter_dev, const float* sino, float* out,
+                        dinv_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* Blur / Downsampling: padded true convolution, its exact transpose, and the  */
 /* real<->half-complex 2-D FFT used by BlurFFT                                 */
