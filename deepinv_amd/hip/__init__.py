@@ -68,6 +68,43 @@ def _declare(lib):
     # optional symbol groups are declared by the modules that own them (radon, conv, drunet)
 
 
+_tls = threading.local()
+
+
+class _DeviceGuardedLib:
+    """The ctypes library with every call issued on the device of the operands last checked by `require_hip`.
+    A kernel launch goes to the CURRENT HIP device whatever stream it is given, so operands on cuda:1 while cuda:0 is
+    current would fail (or use cuda:0's configuration caches); PyTorch ops guard against that, and so do these."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+        object.__setattr__(self, "_wrapped", {})
+
+    def __getattr__(self, name):
+        w = self._wrapped.get(name)
+        if w is None:
+            fn = getattr(self._cdll, name)
+
+            class _Fn:
+                __slots__ = ()
+
+                def __call__(_, *args):
+                    dev = getattr(_tls, "dev", None)
+                    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+                        with torch.cuda.device(dev):
+                            return fn(*args)
+                    return fn(*args)
+
+                def __setattr__(_, k, v):       # argtypes / restype declarations go to the real function
+                    setattr(fn, k, v)
+
+                def __getattr__(_, k):
+                    return getattr(fn, k)
+
+            w = self._wrapped[name] = _Fn()
+        return w
+
+
 def lib():
     """Load (once) and return the C-ABI library; fail loudly if it has not been built."""
     global _lib
@@ -79,7 +116,7 @@ def lib():
                         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(or `make -C deepinv_amd/csrc`). deepinv_amd has no CPU fallback."
                     )
-                l = ctypes.CDLL(LIB_PATH)
+                l = _DeviceGuardedLib(ctypes.CDLL(LIB_PATH))
                 _declare(l)
                 _lib = l
     return _lib
@@ -107,6 +144,7 @@ def require_hip(*tensors: torch.Tensor):
         elif t.device != dev:
             raise HipExtensionError(f"operands on different devices: {dev} vs {t.device}")
     lib()
+    _tls.dev = dev
     return dev
 
 

@@ -108,11 +108,21 @@ class _ConvT(torch.autograd.Function):
         return _Conv.apply(g, filt, padding, stride), None, None, None, None, None
 
 
+def _no_filter_grad(filt):
+    """the reference gets d/d(filter) from autograd through F.conv2d; these kernels differentiate w.r.t. the image
+    only, so a filter that asks for a gradient fails loudly instead of silently receiving None"""
+    if torch.is_grad_enabled() and isinstance(filt, torch.Tensor) and filt.requires_grad:
+        raise NotImplementedError("gradients w.r.t. the blur filter are not implemented on the HIP path "
+                                  "(blind / learned kernels): detach the filter or differentiate w.r.t. the image")
+
+
 def conv2d_strided(x, filt, padding="valid", stride=1):
+    _no_filter_grad(filt)
     return _Conv.apply(x, filt, padding, int(stride))
 
 
 def conv2d_strided_transpose(y, filt, padding, stride, H, W):
+    _no_filter_grad(filt)
     return _ConvT.apply(y, filt, padding, int(stride), int(H), int(W))
 
 
