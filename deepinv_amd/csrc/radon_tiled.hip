@@ -51,6 +51,7 @@ struct TiledGeom {
     int32_t PW, PH;                 // packed image pitch / rows (one zero ring + band overhang)
     int32_t njb, nbands;
     int32_t WW;                     // LDS window pitch in columns (forward only; from the plan)
+    uint32_t row_magic;             // ceil(2^32 / (WW * planes)): chunk index -> window row by multiply-high
     float scale;
 };
 
@@ -106,8 +107,8 @@ __global__ void radon_pack_image2(TiledGeom g, const float* __restrict__ x, floa
 template <int V> using vf = float __attribute__((ext_vector_type(V)));
 
 // block = 64 * kw threads (kw = angles per chunk, plan->kw); LDS: xn[G] ; win[PLANES][BH+1][WW][V]
-template <int NB, bool SWAP>
-__global__ __launch_bounds__(512) void radon_fwd_tiled_kernel(TiledGeom g, const float* __restrict__ xp,
+template <int NB, bool SWAP, int MAXPF>
+__global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kernel(TiledGeom g, const float* __restrict__ xp,
                                                               const float* __restrict__ xn,
                                                               const float2* __restrict__ cs,
                                                               const int32_t* __restrict__ chunk_angles,
@@ -158,24 +159,59 @@ __global__ __launch_bounds__(512) void radon_fwd_tiled_kernel(TiledGeom g, const
     const int32_t* wt = wtab + ((int64_t)ch * g.njb + jb) * g.nbands;
     const float* img = xp + (int64_t)grp * g.PH * g.PW * NB;
     const int plane_stride = (BH + 1) * WW * V;
+    // Window staging is software pipelined: the 16-byte chunks of band b+1 are loaded into registers BEFORE the rays
+    // march through band b (all loads in flight together, their latency hidden behind the march) and written to LDS
+    // after the barrier that ends band b.  A window row is staged at the full pitch WW (constant chunk -> (row, col)
+    // map: one multiply-high per chunk); columns beyond the band's own width are never read by a valid sample.
+    // MAXPF = chunks per thread held in registers (9 covers 8-wave workgroups, 18 the 4-wave ones)
+    const unsigned rowlen = (unsigned)(WW * PLANES);   // chunks per window row
+    const unsigned total = (unsigned)(BH + 1) * rowlen;
+    const unsigned magic = g.row_magic;              // ceil(2^32 / rowlen)
+    VF pre[MAXPF];
+    // chunk -> (row, column chunk) is the same in every band: global and LDS offsets are computed once; per band only
+    // the (uniform) base address of the window changes
+    int goff[MAXPF], loff[MAXPF];
+#pragma unroll
+    for (int k = 0; k < MAXPF; ++k) {
+        const unsigned q = tid + k * nthr;
+        const unsigned r = __umulhi(q, magic), cq = q - r * rowlen;
+        const unsigned col = cq / PLANES, pl = cq - col * PLANES;
+        goff[k] = (int)(r * (unsigned)(g.PW * NB) + cq * V);
+        loff[k] = (int)(pl * plane_stride + (r * WW + col) * V);
+    }
+    auto band_base = [&](int band) -> const float* {
+        const int wx0 = (wt[band] & 0xffff) - 8;
+        return img + ((int64_t)band * BH * g.PW + (wx0 + 1)) * NB;
+    };
+    auto issue = [&](int band) {
+        const float* base = band_base(band);
+#pragma unroll
+        for (int k = 0; k < MAXPF; ++k)
+            if (tid + k * nthr < total) pre[k] = *reinterpret_cast<const VF*>(base + goff[k]);
+    };
+    auto commit = [&](int band) {
+#pragma unroll
+        for (int k = 0; k < MAXPF; ++k)
+            if (tid + k * nthr < total) *reinterpret_cast<VF*>(win + loff[k]) = pre[k];
+        const float* base = band_base(band);
+        for (unsigned q = tid + MAXPF * nthr; q < total; q += nthr) {   // few-wave workgroups: the rest, synchronously
+            const unsigned r = __umulhi(q, magic), cq = q - r * rowlen;
+            const unsigned col = cq / PLANES, pl = cq - col * PLANES;
+            *reinterpret_cast<VF*>(win + pl * plane_stride + (r * WW + col) * V) =
+                *reinterpret_cast<const VF*>(base + r * (unsigned)(g.PW * NB) + cq * V);
+        }
+    };
+    issue(0);
     for (int band = 0; band < g.nbands; ++band) {
-        const int wi = wt[band];
-        const int wx0 = (wi & 0xffff) - 8, ww = wi >> 16;   // first window column (grid coordinate), width
+        const int wx0 = (wt[band] & 0xffff) - 8;   // first window column (grid coordinate)
+#ifdef DINV_EMU
+        const int ww = wt[band] >> 16;
+#endif
         const int vb = -1 + band * BH;
         __syncthreads();   // every ray is done with the previous window
-        {   // stage rows vb .. vb+BH, columns wx0 .. wx0+ww-1: 16-byte chunks, lanes along the contiguous (col, image) axis
-            const int nchunk = ww * PLANES;
-            const float* src = img + ((int64_t)(vb + 1) * g.PW + (wx0 + 1)) * NB;
-            for (int r = wv; r <= BH; r += kw) {
-                const float* srow = src + (int64_t)r * g.PW * NB;
-                float* drow = win + r * WW * V;
-                for (int q = lane; q < nchunk; q += 64) {
-                    const int col = q / PLANES, pl = q - col * PLANES;
-                    *reinterpret_cast<VF*>(drow + pl * plane_stride + col * V) = *reinterpret_cast<const VF*>(srow + q * V);
-                }
-            }
-        }
+        commit(band);
         __syncthreads();
+        if (band + 1 < g.nbands) issue(band + 1);
         if (active) {
             const bool last = band == g.nbands - 1;
             while ((unsigned)i < (unsigned)g.G) {
@@ -254,6 +290,7 @@ __global__ __launch_bounds__(256) void radon_adj_tiled_kernel(TiledGeom g, const
                                                               const float2* __restrict__ cs,
                                                               const float* __restrict__ norm, float* __restrict__ x) {
     constexpr int V = Vec<NB>::V, PLANES = Vec<NB>::PLANES;
+    using VF = vf<V>;
     DINV_DYN_LDS(float, lds);
     float* xn_s = lds;
     float* seg = lds + ((g.G + 3) & ~3);                   // [KA][PLANES][JW][V]
@@ -296,24 +333,26 @@ __global__ __launch_bounds__(256) void radon_adj_tiled_kernel(TiledGeom g, const
             jlo_s[tid] = jlo;
         }
         __syncthreads();
-        {   // stage seg[ai][pl][q][V] <- sp[grp][a0+ai][JPAD + jlo + q][pl*V ..]
-            constexpr int CH = KA * JW * PLANES;
-            for (int f = tid; f < CH; f += 256) {
+        {   // stage seg[ai][pl][q][V] <- sp[grp][a0+ai][JPAD + jlo + q][pl*V ..]; a thread's loads are all issued
+            // before the first LDS write (KA * JW * PLANES chunks / 256 threads = 4 per thread for 8 images)
+            constexpr int CH = KA * JW * PLANES, PER = (CH + 255) / 256;
+            VF v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int f = tid + k * 256;
                 const int ai = f / (JW * PLANES), r = f - ai * (JW * PLANES);
                 const int q = r / PLANES, pl = r - q * PLANES;
                 const int a = a0 + ai;
-                float v[V];
-                if (a < g.A) {
-                    const float* s0 = sp + (((int64_t)grp * g.A + a) * GJ + (JPAD + jlo_s[ai] + q)) * NB + pl * V;
+                v[k] = VF(0.f);
+                if (f < CH && a < g.A)
+                    v[k] = *reinterpret_cast<const VF*>(sp + (((int64_t)grp * g.A + a) * GJ + (JPAD + jlo_s[ai] + q)) * NB + pl * V);
+            }
 #pragma unroll
-                    for (int e = 0; e < V; ++e) v[e] = s0[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < V; ++e) v[e] = 0.f;
-                }
-                float* d = seg + (((int64_t)ai * PLANES + pl) * JW + q) * V;
-#pragma unroll
-                for (int e = 0; e < V; ++e) d[e] = v[e];
+            for (int k = 0; k < PER; ++k) {
+                const int f = tid + k * 256;
+                const int ai = f / (JW * PLANES), r = f - ai * (JW * PLANES);
+                const int q = r / PLANES, pl = r - q * PLANES;
+                if (f < CH) *reinterpret_cast<VF*>(seg + (((int64_t)ai * PLANES + pl) * JW + q) * V) = v[k];
             }
         }
         __syncthreads();
@@ -354,7 +393,7 @@ __global__ __launch_bounds__(256) void radon_adj_tiled_kernel(TiledGeom g, const
                     q = q < 0 ? 0 : (q > JW - 1 ? JW - 1 : q);   // out-of-segment candidates have wsum == 0
 #pragma unroll
                     for (int pl = 0; pl < PLANES; ++pl) {
-                        const float* v = seg + (((int64_t)ai * PLANES + pl) * JW + q) * V;
+                        const VF v = *reinterpret_cast<const VF*>(seg + ((ai * PLANES + pl) * JW + q) * V);
 #pragma unroll
                         for (int e = 0; e < V; ++e) acc[pl * V + e] = fmaf(wsum, v[e], acc[pl * V + e]);
                     }
@@ -423,16 +462,32 @@ __global__ __launch_bounds__(256) void ramp_fft_kernel(int n_img, int N, int A, 
     const int ncol = (A + 1) / 2;                // complex columns (the last one is half empty when A is odd)
     const float* src = y + (int64_t)n * N * A;
     float* dst = out + (int64_t)n * N * A;
-    // load: element (m, cc) = (y[m][2c], y[m][2c+1]); rows N..P-1 are the zero padding
-    for (int e = tid; e < P * CT; e += 256) {
-        const int m = e / CT, cc = e - m * CT;
-        const int a0 = 2 * (c0 + cc);
-        float2 v = make_float2(0.f, 0.f);
-        if (m < N && c0 + cc < ncol) {
-            v.x = src[(int64_t)m * A + a0];
-            if (a0 + 1 < A) v.y = src[(int64_t)m * A + a0 + 1];
+    // load: element (m, cc) = (y[m][2c], y[m][2c+1]); rows N..P-1 are the zero padding.  Eight independent loads per
+    // thread are in flight before the first LDS write.
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < N * CT; e0 += 256 * U) {
+        float2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256;
+            const int m = e / CT, cc = e - m * CT;
+            const int a0 = 2 * (c0 + cc);
+            v[u] = make_float2(0.f, 0.f);
+            if (e < N * CT && c0 + cc < ncol) {
+                v[u].x = src[(int64_t)m * A + a0];
+                if (a0 + 1 < A) v[u].y = src[(int64_t)m * A + a0 + 1];
+            }
         }
-        buf[cc * LS + m] = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256;
+            const int m = e / CT, cc = e - m * CT;
+            if (e < N * CT) buf[cc * LS + m] = v[u];
+        }
+    }
+    for (int e = N * CT + tid; e < P * CT; e += 256) {
+        const int m = e / CT, cc = e - m * CT;
+        buf[cc * LS + m] = make_float2(0.f, 0.f);
     }
     // forward transform, decimation in frequency: stages outermost first, natural order in, digit-reversed out
     {
@@ -487,6 +542,7 @@ int make_geom(const dinv_radon_desc* d, TiledGeom* g, int* NBsel) {
     g->PH = g->nbands * BH + 1;
     g->PW = d->grid + 2;
     g->WW = 0;
+    g->row_magic = 0;
     return 0;
 }
 
@@ -650,6 +706,20 @@ extern "C" size_t dinv_radon_tiled_workspace_bytes(const dinv_radon_desc* d, int
     return (2 * (size_t)g.groups * g.PH * g.PW * NB + kSlackFloats) * sizeof(float);
 }
 
+#define DINV_FWD_LAUNCH(PF)                                                                                              \
+    do {                                                                                                                 \
+        if (int e = set_dyn_lds(radon_fwd_tiled_kernel<NB, false, PF>, lds)) return e;                                  \
+        if (int e = set_dyn_lds(radon_fwd_tiled_kernel<NB, true, PF>, lds)) return e;                                   \
+        if (plan->n_chunks_plain > 0)                                                                                    \
+            hipLaunchKernelGGL((radon_fwd_tiled_kernel<NB, false, PF>), dim3(g.njb, plan->n_chunks_plain, g.groups),    \
+                               dim3(64 * kw), lds, s, g, (const float*)xp, xn, cs2, blob + L.off_angles,                \
+                               blob + L.off_dir, blob + L.off_wtab, norm_dev, sino, 0);                                  \
+        if (plan->n_chunks_swap > 0)                                                                                     \
+            hipLaunchKernelGGL((radon_fwd_tiled_kernel<NB, true, PF>), dim3(g.njb, plan->n_chunks_swap, g.groups),      \
+                               dim3(64 * kw), lds, s, g, (const float*)xpt, xn, cs2, blob + L.off_angles,               \
+                               blob + L.off_dir, blob + L.off_wtab, norm_dev, sino, plan->n_chunks_plain);               \
+    } while (0)
+
 extern "C" int dinv_radon_forward_tiled(const dinv_radon_desc* d, const dinv_radon_plan* plan, const void* plan_dev,
                                         const float* x, const float* xn, const float* cs, const float* norm_dev,
                                         float* sino, void* ws, size_t ws_bytes, dinv_stream_t stream) {
@@ -670,6 +740,10 @@ extern "C" int dinv_radon_forward_tiled(const dinv_radon_desc* d, const dinv_rad
     const int64_t npk = (int64_t)g.groups * g.PH * g.PW;
     const unsigned pk_blocks = (unsigned)std::min<int64_t>(ceil_div(npk, 256), 65535);
     g.WW = plan->win_w;
+    {
+        const uint64_t rowlen = (uint64_t)g.WW * (NBsel >= 8 ? 2 : 1);
+        g.row_magic = (uint32_t)((((uint64_t)1 << 32) + rowlen - 1) / rowlen);
+    }
     DINV_REQUIRE(g.groups <= 65535 && plan->n_chunks_plain <= 65535 && plan->n_chunks_swap <= 65535, "grid too large");
     DINV_NB_DISPATCH(NBsel, {
         float* xp = reinterpret_cast<float*>(ws);
@@ -677,17 +751,8 @@ extern "C" int dinv_radon_forward_tiled(const dinv_radon_desc* d, const dinv_rad
         const size_t lds = ((size_t)((g.G + 3) & ~3) + (size_t)(BH + 1) * g.WW * NB) * sizeof(float);
         DINV_REQUIRE(lds <= kMaxLdsBytes && (size_t)g.WW * NB <= kSlackFloats,
                      "window of %d columns x %d images does not fit the LDS: use dinv_radon_forward", g.WW, NB);
-        if (int e = set_dyn_lds(radon_fwd_tiled_kernel<NB, false>, lds)) return e;
-        if (int e = set_dyn_lds(radon_fwd_tiled_kernel<NB, true>, lds)) return e;
         hipLaunchKernelGGL(radon_pack_image2<NB>, dim3(pk_blocks), dim3(256), 0, s, g, x, xp, xpt);
-        if (plan->n_chunks_plain > 0)
-            hipLaunchKernelGGL((radon_fwd_tiled_kernel<NB, false>), dim3(g.njb, plan->n_chunks_plain, g.groups),
-                               dim3(64 * kw), lds, s, g, (const float*)xp, xn, cs2, blob + L.off_angles, blob + L.off_dir,
-                               blob + L.off_wtab, norm_dev, sino, 0);
-        if (plan->n_chunks_swap > 0)
-            hipLaunchKernelGGL((radon_fwd_tiled_kernel<NB, true>), dim3(g.njb, plan->n_chunks_swap, g.groups),
-                               dim3(64 * kw), lds, s, g, (const float*)xpt, xn, cs2, blob + L.off_angles, blob + L.off_dir,
-                               blob + L.off_wtab, norm_dev, sino, plan->n_chunks_plain);
+        if (kw == 8) DINV_FWD_LAUNCH(9); else DINV_FWD_LAUNCH(18);
     });
     DINV_CHECK_LAUNCH();
     return 0;

@@ -111,7 +111,9 @@ def _fwd(x, geo: RadonGeometry, norm, scale=1.0):
     x = f32c(x)
     B, C, H, W = x.shape
     sino = torch.empty((B, C, geo.G, geo.A), device=dev, dtype=torch.float32)
-    if _use_tiled(geo.G) and geo.plan is not None:
+    # few angles per workgroup (coarse or irregular angle lists) leave the LDS-tiled forward kernel under-occupied:
+    # below 4 the gather kernel is the faster one (measured at 512^2: 60 angles, kw = 2); DINV_RADON_TILED=2 forces
+    if _use_tiled(geo.G) and geo.plan is not None and (geo.plan.kw >= 4 or os.environ.get("DINV_RADON_TILED") == "2"):
         d = geo.desc(B * C, scale)
         ws = torch.empty(_l().dinv_radon_tiled_workspace_bytes(ctypes.byref(d), 0), device=dev, dtype=torch.uint8)
         check(_l().dinv_radon_forward_tiled(ctypes.byref(d), ctypes.byref(geo.plan), ptr(geo.plan_dev), ptr(x), ptr(geo.xn),
