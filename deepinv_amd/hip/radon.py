@@ -120,11 +120,11 @@ def _fwd(x, geo: RadonGeometry, norm, scale=1.0):
                                             ptr(geo.cs), _norm_ptr(norm, dev), ptr(sino), ptr(ws), ws.numel(),
                                             stream_ptr(dev)))
         return sino
-    d = geo.desc(B * C, scale if norm is None else scale / float(norm))   # gather kernels: host scalar
+    d = geo.desc(B * C, scale)
     ws = torch.empty(_l().dinv_radon_workspace_bytes(ctypes.byref(d), 0), device=dev, dtype=torch.uint8)
     check(_l().dinv_radon_forward(ctypes.byref(d), ptr(x), ptr(geo.xn), ptr(geo.cs), ptr(sino), ptr(ws), ws.numel(),
                                   stream_ptr(dev)))
-    return sino
+    return sino if norm is None else sino.div_(norm)   # the gather kernels take a host scalar only: divide on the device
 
 
 def _adj(y, geo: RadonGeometry, norm, scale=1.0):
@@ -140,11 +140,11 @@ def _adj(y, geo: RadonGeometry, norm, scale=1.0):
         check(_l().dinv_radon_adjoint_tiled(ctypes.byref(d), ptr(y), ptr(geo.xn), ptr(geo.cs), _norm_ptr(norm, dev), ptr(x),
                                             ptr(ws), ws.numel(), stream_ptr(dev)))
         return x
-    d = geo.desc(B * C, scale if norm is None else scale / float(norm))
+    d = geo.desc(B * C, scale)
     ws = torch.empty(_l().dinv_radon_workspace_bytes(ctypes.byref(d), 1), device=dev, dtype=torch.uint8)
     check(_l().dinv_radon_adjoint(ctypes.byref(d), ptr(y), ptr(geo.xn), ptr(geo.cs), ptr(x), ptr(ws), ws.numel(),
                                   stream_ptr(dev)))
-    return x
+    return x if norm is None else x.div_(norm)
 
 
 class _RadonFwd(torch.autograd.Function):
