@@ -392,7 +392,7 @@ extern "C" int dinv_act_geom_init(int32_t batch, int32_t height, int32_t width, 
     g->plane = (int64_t)g->hp * g->wp;
     g->np = g->plane * batch;
     g->sl = g->wp + 4;
-    g->cs = g->sl + ceil_div(g->np, NT) * NT + g->wp + 4;
+    g->cs = g->sl + ceil_div(g->np, 2 * NT) * 2 * NT + g->wp + 4;   // whole 512-pixel tiles (drunet_bf16s.hip)
     g->cs = (g->cs + 3) / 4 * 4;
     return 0;
 }

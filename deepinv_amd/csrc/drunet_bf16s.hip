@@ -1,0 +1,245 @@
+// DRUNet ResBlock 3x3 convolution on the BF16 matrix cores with a two-part exact operand split (gfx950).
+//
+// Operator: y = [relu](conv3x3(x)) (+ res1), stride 1, zero padding 1, no bias (deepinv/models/drunet.py:403-434),
+// on the padded channel-blocked activation layout of drunet.hip.
+//
+// Arithmetic: every fp32 operand is written as x = xh + xl with bf16 parts (xh = bf16(x), xl = bf16(x - xh), both
+// round-to-nearest-even; x - xh is exact), and a product a*b is evaluated as ah*bl + al*bh + ah*bh with fp32
+// accumulation in v_mfma_f32_32x32x16_bf16: the dropped al*bl term and the rounding of the low parts are ~2^-17
+// relative per operand, 2-4e-6 per layer against an fp64 convolution and 1.7e-6 on the DRUNet output with O(1)-gain
+// ResBlock weights (tests/test_drunet_gpu.py, tests/test_golden_gpu.py).  The bf16 matrix pipe is 16x the fp32 one and
+// co-issues with the vector ALU, so three products leave a 5.3x higher ceiling than the fp32 MFMA path.
+//
+// Structure (what differs from the first bf16 kernel, drunet_bf16.hip):
+//   * K = 16 per MFMA = 2 channel blocks of 8 x ONE tap (lane half h supplies channel block 2s + h): no padding tap,
+//     9 MFMAs per tile and 16 channels instead of 10;
+//   * workgroup = 8 waves = 512 consecutive padded pixels x 64 couts, each wave a 64 x 64 tile (2 x 2 accumulators);
+//   * the K loop runs over sub-steps (16 channels, one kernel row dy): a sub-step needs one 514-pixel row segment of
+//     the input (split into hi / lo bf16 planes while it is staged) and 3 taps x 16 channels x 64 couts of pre-split
+//     weights = 45 KB of LDS; two such stages alternate: the global loads of sub-step t+2 (into registers) and the
+//     split + LDS write of sub-step t+1 run underneath the 36 MFMAs per wave of sub-step t; ONE barrier per sub-step.
+//     Odd waves stage before their MFMAs, even waves after them, so that on a SIMD one wave's vector work overlaps
+//     the other wave's matrix work.
+#include "drunet_common.hpp"
+
+using namespace dinv;
+using namespace dinv_drunet;
+
+namespace {
+
+constexpr int TP = 512;                 // pixels per workgroup
+constexpr int SEGX = TP + 2;            // staged row segment (one halo pixel on each side)
+constexpr int XUNITS = 2 * 2 * SEGX;    // 16-byte units of a stage's activations: [plane][cblk][SEGX]
+constexpr int WUNITS = 2 * 3 * 2 * 64;  // ... of its weights: [plane][dx][cblk][co 64]
+constexpr int STAGE = XUNITS + WUNITS;  // 2824 units = 45,184 bytes
+constexpr int NSTAGE = 2;
+constexpr int XCH = 2 * SEGX;           // 32-byte fp32 chunks (8 channels of one pixel) per sub-step: 1028
+constexpr int XPER = (XCH + 511) / 512; // per thread: 3 (the third only for 4 threads)
+constexpr int WPER = (WUNITS + 511) / 512;  // 2 (the second for 256 threads)
+
+struct SArgs {
+    Geom g;
+    const float* x;
+    const uint4* w;    // [cout/64][cin/16][dy 3][plane 2][dx 3][cblk 2][co 64] x (8 bf16)
+    float* y;
+    const float* res1;
+    int32_t cin, cblocks_valid;
+    int32_t ntiles, ytiles, tiles_per_xcd;
+};
+
+__device__ __forceinline__ unsigned f2bf(float f) {   // round to nearest even, as v_cvt_pk_bf16_f32
+#ifdef DINV_EMU
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+#else
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
+}
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+
+// 8 fp32 -> 8 bf16 high parts + 8 bf16 low parts (each 16 bytes)
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = f2bf(v[e]);
+        l[e] = f2bf(v[e] - bf2f(h[e]));
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+#ifdef DINV_EMU
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16& c) {
+    emu_bf16x8 av, bv;
+    std::memcpy(&av, &a, 16);
+    std::memcpy(&bv, &b, 16);
+    return emu_mfma_f32_32x32x16_bf16(av, bv, c);
+}
+#else
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+#endif
+
+template <bool RELU, int NRES>
+__global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
+    DINV_DYN_LDS(uint4, lds);   // [NSTAGE][STAGE]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // XCD-aware order: consecutive pixel tiles (which share their halo rows) and the cout tiles of one pixel tile stay
+    // on one XCD (observed placement: block b runs on XCD b % 8; speed only)
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int ty = jx % a.ytiles, tl = jx / a.ytiles;
+    const int tile = xcd * a.tiles_per_xcd + tl;
+    if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;
+    const int64_t p0 = (int64_t)tile * TP;
+    const int nsub = 3 * (a.cin / 16);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // ---- this thread's staging slots (the same in every sub-step)
+    int xg[XPER], xl[XPER];   // global offset (floats) inside the sub-step's source rows, LDS unit inside the stage
+    bool xok[XPER];
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+        const int q = tid + k * 512;
+        xok[k] = q < XCH;
+        const int qq = xok[k] ? q : 0;
+        const int cb = qq / SEGX, i = qq - cb * SEGX;
+        xg[k] = (int)(((int64_t)cb * a.g.cs + i) * 8);   // cs * 8 < 2^31 is checked by the launcher
+        xl[k] = cb * SEGX + i;                           // + plane * 2 * SEGX
+    }
+    const uint4* wsrc0 = a.w + (int64_t)ty * nsub * WUNITS;
+    const float* xsrc0 = a.x + (a.g.sl + p0 - 1) * 8;
+
+    float4 xr[XPER][2];
+    uint4 wr[WPER];
+    auto issue = [&](int t) {   // global loads of sub-step t into registers
+        const int s = t / 3, dyi = t - 3 * s;
+        const float* xs = xsrc0 + ((int64_t)(2 * s) * a.g.cs + (int64_t)(dyi - 1) * a.g.wp) * 8;
+#pragma unroll
+        for (int k = 0; k < XPER; ++k)
+            if (xok[k]) {
+                xr[k][0] = ld4(xs + xg[k]);
+                xr[k][1] = ld4(xs + xg[k] + 4);
+            }
+        const uint4* ws = wsrc0 + (int64_t)t * WUNITS;
+#pragma unroll
+        for (int k = 0; k < WPER; ++k)
+            if (tid + k * 512 < WUNITS) wr[k] = ws[tid + k * 512];
+    };
+    auto commit = [&](int t) {   // split + write the registers of sub-step t into its ring slot
+        uint4* st = lds + (t % NSTAGE) * STAGE;
+#pragma unroll
+        for (int k = 0; k < XPER; ++k)
+            if (xok[k]) {
+                uint4 hi, lo;
+                split8(xr[k][0], xr[k][1], hi, lo);
+                st[xl[k]] = hi;
+                st[2 * SEGX + xl[k]] = lo;
+            }
+#pragma unroll
+        for (int k = 0; k < WPER; ++k)
+            if (tid + k * 512 < WUNITS) st[XUNITS + tid + k * 512] = wr[k];
+    };
+
+    // operand slots of this lane: A = weights (row = cout l31 of m-tile, k half = channel block lhi),
+    //                             B = pixels  (col = pixel l31 of n-tile, k half = channel block lhi)
+    const int aslot = lhi * 64 + l31;                       // + (plane*3 + dx)*128 + m*32
+    const int bslot = lhi * SEGX + wv * 64 + l31;           // + plane*2*SEGX + n*32 + dx
+
+    issue(0);
+    commit(0);
+    if (nsub > 1) issue(1);
+    __syncthreads();
+    for (int t = 0; t < nsub; ++t) {
+        // registers hold sub-step t+1 (loaded one iteration ago); its slot was last read in iteration t-1, before
+        // the barrier that ended that iteration
+        const bool early = (wv & 1) != 0;
+        if (early) {
+            if (t + 1 < nsub) commit(t + 1);
+            if (t + 2 < nsub) issue(t + 2);
+        }
+        const uint4* st = lds + (t % NSTAGE) * STAGE;
+        const uint4* xs = st;
+        const uint4* ws = st + XUNITS;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            uint4 A[2][2], B[2][2];   // [tile][plane]
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) A[m][pl] = ws[(pl * 3 + dx) * 128 + aslot + m * 32];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) B[n][pl] = xs[pl * 2 * SEGX + bslot + n * 32 + dx];
+            }
+            // smallest terms first: ah*bl, al*bh, ah*bh
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = mfma_bf16(A[m][0], B[n][1], acc[m][n]);
+                    acc[m][n] = mfma_bf16(A[m][1], B[n][0], acc[m][n]);
+                    acc[m][n] = mfma_bf16(A[m][0], B[n][0], acc[m][n]);
+                }
+        }
+        if (!early) {
+            if (t + 1 < nsub) commit(t + 1);
+            if (t + 2 < nsub) issue(t + 2);
+        }
+        __syncthreads();   // slot t is consumed; slot t+1 is complete
+    }
+    const int cb0 = ty * 8;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int64_t p = p0 + wv * 64 + n * 32 + l31;
+        if (p >= a.g.np) continue;
+        store_tile<2, RELU, NRES>(acc, n, a.g.sl + p, interior(a.g, p), cb0, a.cblocks_valid, a.g.cs, lhi, a.y, a.res1,
+                                  nullptr);
+    }
+}
+
+}  // namespace
+
+extern "C" int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin,
+                                  int32_t cout, float* y, const float* res1, int32_t relu, dinv_stream_t stream) {
+    if (int e = check_geom(g)) return e;
+    DINV_REQUIRE(x && w_split && y, "null tensor pointer");
+    DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0,
+                 "bf16-split conv needs cin %% 16 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
+    DINV_REQUIRE(!(relu && res1), "relu and residual are not combined in DRUNet");
+    DINV_REQUIRE(g->cs >= g->sl + ceil_div(g->np, TP) * TP + g->wp + HALO, "channel-block stride too small for 512-pixel tiles");
+    DINV_REQUIRE(g->cs * 16 < ((int64_t)1 << 31), "activation row too long for 32-bit staging offsets");
+    SArgs a{make_geom(*g), x, reinterpret_cast<const uint4*>(w_split), y, res1, cin, cout / 8, 0, 0, 0};
+    a.ntiles = (int32_t)ceil_div(g->np, TP);
+    a.ytiles = cout / 64;
+    a.tiles_per_xcd = (int32_t)ceil_div(a.ntiles, 8);
+    const dim3 grid((unsigned)(a.tiles_per_xcd * a.ytiles * 8)), block(512);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    constexpr size_t lds = (size_t)NSTAGE * STAGE * sizeof(uint4);
+    static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
+#define DINV_S_LAUNCH(R, N)                                                                                       \
+    do {                                                                                                          \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16s_kernel<R, N>),            \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        if (e_ != hipSuccess) return fail(100 + (int)e_, "hipFuncSetAttribute: %s", hipGetErrorString(e_));       \
+        hipLaunchKernelGGL((conv3x3_bf16s_kernel<R, N>), grid, block, lds, st, a);                                \
+    } while (0)
+    if (relu) DINV_S_LAUNCH(true, 0);
+    else if (res1) DINV_S_LAUNCH(false, 1);
+    else DINV_S_LAUNCH(false, 0);
+#undef DINV_S_LAUNCH
+    DINV_CHECK_LAUNCH();
+    return 0;
+}

@@ -128,7 +128,13 @@ __global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kern
     const int jb = blockIdx.x, ch = chunk_base + blockIdx.y, grp = blockIdx.z;
     const int a = chunk_angles[ch * kw + wv];
     const int dir = chunk_dir[ch];
-    const int j = jb * 64 + lane;
+    // ds_read_b128 is serviced in four fixed 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): give each group
+    // 16 ADJACENT rays, whose taps are adjacent window columns, so that a group spans as few bank rows as possible
+    const int l5 = lane & 31;
+    const bool g0 = l5 < 4 || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
+    const int ray = (lane & 32) + (g0 ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12))
+                                      : 16 + (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16)));
+    const int j = jb * 64 + ray;
     const bool active = a >= 0 && j < g.G;
     __syncthreads();
     float c = 0.f, s = 0.f, xj = 0.f;
@@ -213,43 +219,48 @@ __global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kern
         __syncthreads();
         if (band + 1 < g.nbands) issue(band + 1);
         if (active) {
-            const bool last = band == g.nbands - 1;
-            while ((unsigned)i < (unsigned)g.G) {
-                if (v0 >= vb + BH && !last) break;   // this sample belongs to a later band
+            // one basic block per sample: an out-of-image sample reads a clamped (valid) window address with zero
+            // weights instead of branching, and the position of the NEXT sample is evaluated between the tap reads and
+            // the multiply-adds of the current one, so the two LDS latencies of a step overlap
+            const int vend = band == g.nbands - 1 ? 0x7fffffff : vb + BH;
+            while ((unsigned)i < (unsigned)g.G && v0 < vend) {
                 const bool ok = u0 >= -1 && u0 <= g.G - 1 && v0 >= -1 && v0 <= g.G - 1;
-                if (ok) {
-                    int col = u0 - wx0;
+                int col = u0 - wx0, row = v0 - vb;
 #ifdef DINV_EMU
-                    if (col < 0 || col > ww - 2) ++dinv_emu_window_misses;   // host emulation only: the plan must cover
+                if (ok && (col < 0 || col > ww - 2)) ++dinv_emu_window_misses;   // host emulation only: the plan must cover
 #endif
-                    col = col < 0 ? 0 : (col > WW - 2 ? WW - 2 : col);   // never taken when the plan is right
-                    const int row = v0 - vb;
-                    const float w00 = (1.0f - tu) * (1.0f - tv), w01 = tu * (1.0f - tv);
-                    const float w10 = (1.0f - tu) * tv, w11 = tu * tv;
-                    const float* p = win + (row * WW + col) * V;
+                col = col < 0 ? 0 : (col > WW - 2 ? WW - 2 : col);   // valid samples are inside by construction
+                row = row < 0 ? 0 : (row > BH - 1 ? BH - 1 : row);
+                const float okf = ok ? 1.0f : 0.0f;
+                const float a0 = 1.0f - tu, b0 = (1.0f - tv) * okf, b1 = tv * okf;
+                const float w00 = a0 * b0, w01 = tu * b0, w10 = a0 * b1, w11 = tu * b1;
+                const float* p = win + (row * WW + col) * V;
+                VF t00[PLANES], t01[PLANES], t10[PLANES], t11[PLANES];
 #pragma unroll
-                    for (int pl = 0; pl < PLANES; ++pl) {
-                        const float* pp = p + pl * plane_stride;
-                        const VF t00 = *reinterpret_cast<const VF*>(pp), t01 = *reinterpret_cast<const VF*>(pp + V);
-                        const VF t10 = *reinterpret_cast<const VF*>(pp + WW * V);
-                        const VF t11 = *reinterpret_cast<const VF*>(pp + WW * V + V);
-#pragma unroll
-                        for (int e = 0; e < V; ++e) {
-                            float r = acc[pl][e];
-                            r = fmaf(w00, t00[e], r);
-                            r = fmaf(w01, t01[e], r);
-                            r = fmaf(w10, t10[e], r);
-                            r = fmaf(w11, t11[e], r);
-                            acc[pl][e] = r;
-                        }
-                    }
+                for (int pl = 0; pl < PLANES; ++pl) {
+                    const float* pp = p + pl * plane_stride;
+                    t00[pl] = *reinterpret_cast<const VF*>(pp);
+                    t01[pl] = *reinterpret_cast<const VF*>(pp + V);
+                    t10[pl] = *reinterpret_cast<const VF*>(pp + WW * V);
+                    t11[pl] = *reinterpret_cast<const VF*>(pp + WW * V + V);
                 }
                 i += dir;
-                if ((unsigned)i < (unsigned)g.G) {
-                    eval(xi_next);
+                eval(xi_next);
+                {
                     const int in = i + dir;
-                    xi_next = xn_s[(unsigned)in < (unsigned)g.G ? in : i];
+                    xi_next = xn_s[(unsigned)in < (unsigned)g.G ? in : (i < 0 ? 0 : (i > g.G - 1 ? g.G - 1 : i))];
                 }
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        float r = acc[pl][e];
+                        r = fmaf(w00, t00[pl][e], r);
+                        r = fmaf(w01, t01[pl][e], r);
+                        r = fmaf(w10, t10[pl][e], r);
+                        r = fmaf(w11, t11[pl][e], r);
+                        acc[pl][e] = r;
+                    }
             }
         }
     }

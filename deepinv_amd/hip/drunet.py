@@ -31,6 +31,7 @@ def _l():
         l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
         l.dinv_conv3x3_tail.argtypes = [G, vp, vp, vp, i32, i32, vp, vp]
         l.dinv_conv3x3_bf16x3.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
+        l.dinv_conv3x3_bf16s.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
@@ -83,6 +84,20 @@ def pack_bf16x3_weight(w: torch.Tensor) -> torch.Tensor:
     planes = torch.stack((p1, p2, p3))                                   # [3, Cout, Cin, 3, 3]
     planes = planes.reshape(3, cout // 64, 64, cin // 8, 8, 9)           # pl, ct, co, cb, ci, tap
     return planes.permute(1, 3, 0, 5, 2, 4).contiguous()                # ct, cb, pl, tap, co, ci
+
+
+def pack_bf16s_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> two-part bf16 split (hi = bf16(w), lo = bf16(w - hi)), packed for csrc/drunet_bf16s.hip:
+    [Cout/64][Cin/16][dy 3][plane 2][dx 3][cblk 2][co 64][ci 8] (bf16)"""
+    cout, cin = w.shape[:2]
+    if cin % 16 or cout % 64:
+        raise ValueError(f"bf16-split packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
+    w = w.detach().float()
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    planes = torch.stack((hi, lo))                                            # [2, Cout, Cin, 3, 3]
+    planes = planes.reshape(2, cout // 64, 64, cin // 16, 2, 8, 3, 3)         # pl, ct, co, s, cblk, ci, dy, dx
+    return planes.permute(1, 3, 6, 0, 7, 4, 2, 5).contiguous()               # ct, s, dy, pl, dx, cblk, co, ci
 
 
 def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
@@ -194,6 +209,20 @@ def conv3x3_bf16x3(g, x, wsplit, cin, cout, y, res1=None, relu=False, planes=3):
         e1.record()
         fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
         _prof.append((e0, e1, "conv3x3_bf16x3_kernel", fl, (6.0 if planes == 3 else 3.0) * fl * 10 / 9))
+
+
+def conv3x3_bf16s(g, x, wsplit, cin, cout, y, res1=None, relu=False):
+    """y = [relu](conv3x3(x)) (+res1) on the bf16 matrix cores, two-part exact operand split, three products
+    (csrc/drunet_bf16s.hip); wsplit from pack_bf16s_weight"""
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_l().dinv_conv3x3_bf16s(ctypes.byref(g), ptr(x), ptr(wsplit), cin, cout, ptr(y), ptr(res1), int(relu),
+                                  stream_ptr(y.device)))
+    if _prof is not None:
+        e1.record()
+        fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
+        _prof.append((e0, e1, "conv3x3_bf16s_kernel", fl, 3.0 * fl))
 
 
 def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):

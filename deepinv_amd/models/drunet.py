@@ -31,10 +31,23 @@ def _use_winograd(g, pk) -> bool:
 
 
 def _bf16_split_mode() -> int:
-    """EXPERIMENTAL opt-in: DINV_CONV_BF16X3=3 (six products, fp32-class accuracy) or =2 (three products, ~5e-6 per
-    layer) runs the ResBlock convolutions on the bf16 matrix cores instead of the fp32 Winograd kernel."""
+    """opt-in: DINV_CONV_BF16X3=3 (six products, fp32-class accuracy) or =2 (three products, ~5e-6 per layer) runs the
+    ResBlock convolutions on the first-generation bf16 kernel (csrc/drunet_bf16.hip)."""
     v = os.environ.get("DINV_CONV_BF16X3", "")
     return int(v) if v in ("2", "3") else 0
+
+
+DEFAULT_RESBLOCK_CONV = "wino"
+
+
+def _resblock_conv() -> str:
+    """which kernel runs the 56 ResBlock convolutions: 'bf16s' = two-part bf16 operand split on the bf16 matrix cores,
+    pipelined (csrc/drunet_bf16s.hip); 'wino' = fp32 Winograd F(2x2,3x3) on the fp32 matrix cores; 'direct' = fp32
+    implicit GEMM.  DINV_DRUNET_CONV overrides the default."""
+    v = os.environ.get("DINV_DRUNET_CONV", DEFAULT_RESBLOCK_CONV)
+    if v not in ("bf16s", "wino", "direct"):
+        raise ValueError(f"DINV_DRUNET_CONV must be bf16s, wino or direct, got {v}")
+    return v
 
 
 def _conv_nd(dim):
@@ -174,7 +187,9 @@ class DRUNet(Denoiser):
 
     # ------------------------------------------------------------------ MFMA inference engine
     def _weights_version(self):
-        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        # tensors created under torch.inference_mode() carry no version counter (reading it raises)
+        return (tuple(0 if p.is_inference() else p._version for p in self.parameters())
+                + tuple(p.data_ptr() for p in self.parameters()))
 
     def _prepare(self, device):
         ver = self._weights_version()
@@ -189,7 +204,8 @@ class DRUNet(Denoiser):
             p32 = K.pack_conv3x3_weight(w, mt=32) if p64[0].shape[3] == 64 else p64
             wino = K.pack_winograd_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0 and w.shape[1] >= 32) else None
             split = K.pack_bf16x3_weight(w) if (_bf16_split_mode() and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0) else None
-            return (p64, p32, wino, split)
+            bf16s = K.pack_bf16s_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0) else None
+            return (p64, p32, wino, split, bf16s)
 
         e["head"] = c3(self.m_head)
         e["tail"] = c3(self.m_tail)
@@ -241,7 +257,14 @@ class DRUNet(Denoiser):
         if len(pk) > 3 and pk[3] is not None and _bf16_split_mode():
             K.conv3x3_bf16x3(g, x, pk[3], pk[0][1], pk[0][2], y, res1=res1, relu=relu, planes=_bf16_split_mode())
             return
-        if pk[2] is not None and _use_winograd(g, pk):
+        mode = _resblock_conv()
+        if mode == "bf16s" and len(pk) > 4 and pk[4] is not None:
+            # 512-pixel x 64-cout workgroups: keep it only where they fill the chip (small per-GPU batches at the
+            # coarse U-Net levels fall through to the Winograd kernel)
+            if ((g.np + 511) // 512) * (pk[0][2] // 64) >= 256 or os.environ.get("DINV_DRUNET_CONV_FORCE"):
+                K.conv3x3_bf16s(g, x, pk[4], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
+                return
+        if pk[2] is not None and mode != "direct" and _use_winograd(g, pk):
             K.conv3x3_winograd(g, x, pk[2], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
             return
         (w, ci, co) = self._pick(g, pk)

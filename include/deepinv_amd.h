@@ -152,6 +152,11 @@ int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w
  * w_split: [cout/64][cin/8][plane 3][tap 9][co 64][8] bf16; cin % 8 == 0, cout % 64 == 0. */
 int dinv_conv3x3_bf16x3(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin, int32_t cout,
                         float* y, const float* res1, int32_t relu, int32_t planes, dinv_stream_t stream);
+/* Same operator on the BF16 matrix cores with a two-part exact operand split (x = xh + xl, three products
+ * ah*bl + al*bh + ah*bh, fp32 accumulate; 2-4e-6 per layer vs fp64), software-pipelined (csrc/drunet_bf16s.hip).
+ * w_split: [cout/64][cin/16][dy 3][plane 2][dx 3][cblk 2][co 64][8] bf16; cin % 16 == 0, cout % 64 == 0. */
+int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin, int32_t cout,
+                       float* y, const float* res1, int32_t relu, dinv_stream_t stream);
 /* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin/8][cout][8] */
 int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                       const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);

@@ -176,3 +176,53 @@ def test_drunet_bf16_split_matches_oracle(dev, monkeypatch, planes):
     with torch.no_grad():
         out = model(x.to(dev), 0.05)
     assert rel_err(out, OD.drunet(sd, x, 0.05)) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(2, 24, 40, 64, 64, "plain"), (1, 17, 33, 32, 128, "relu"),
+                                                 (2, 16, 16, 128, 64, "res"), (3, 5, 7, 16, 64, "plain"),
+                                                 (1, 160, 160, 128, 128, "relu"), (2, 20, 20, 512, 512, "res"),
+                                                 (70, 4, 6, 32, 128, "plain"), (1, 2, 330, 64, 64, "res")])
+def test_bf16s_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
+    """pipelined two-part bf16 split (csrc/drunet_bf16s.hip): three products, a few 1e-6 per layer against fp64;
+    512-pixel tiles incl. ragged last tile, many tiny images, a single long row"""
+    from deepinv_amd.hip import drunet as K
+
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)).to(dev)
+    r = torch.randn(B, cout, H, W, generator=g).to(dev)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+    geo = K.geom(B, H, W)
+
+    def to_act(t):
+        a = K.alloc(geo, t.shape[1], dev)
+        av = a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+        av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    xa, ra, ya = to_act(x), to_act(r), K.alloc(geo, cout, dev)
+    K.conv3x3_bf16s(geo, xa, K.pack_bf16s_weight(w), cin, cout, ya, res1=ra if mode == "res" else None, relu=mode == "relu")
+    av = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+    out = av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W)
+    assert rel_err(out, ref) < 2e-5
+    assert av[:, :, 0].abs().max() == 0 and av[:, :, H + 1:].abs().max() == 0
+    assert av[:, :, :, 0].abs().max() == 0 and av[:, :, :, W + 1:].abs().max() == 0
+
+
+def test_drunet_bf16s_matches_oracle(dev, monkeypatch):
+    import deepinv_amd as dinv
+
+    monkeypatch.setenv("DINV_DRUNET_CONV", "bf16s")
+    monkeypatch.setenv("DINV_DRUNET_CONV_FORCE", "1")
+    sd = OD.init_state_dict(2, 2, seed=1)
+    model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
+    model.load_state_dict(sd)
+    model.eval()
+    x = torch.rand(2, 2, 64, 96, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        out = model(x.to(dev), 0.05)
+    assert rel_err(out, OD.drunet(sd, x, 0.05)) < 1e-4

@@ -1,0 +1,78 @@
+"""The bf16-split DRUNet convolution kernel (deepinv_amd/csrc/drunet_bf16s.hip) executed on the HOST by the fiber
+emulation of tests/emu (MFMA emulated from the documented fragment layout) against an fp64 convolution."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import emu_lib as E
+
+
+class ActGeom(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32), ("hp", ctypes.c_int32),
+                ("wp", ctypes.c_int32), ("plane", ctypes.c_int64), ("np", ctypes.c_int64), ("sl", ctypes.c_int64),
+                ("cs", ctypes.c_int64)]
+
+
+def geom(B, H, W):
+    """dinv_act_geom_init (csrc/drunet.hip) restated"""
+    g = ActGeom()
+    g.batch, g.height, g.width = B, H, W
+    g.hp, g.wp = H + 2, (W + 2 + 3) // 4 * 4
+    g.plane = g.hp * g.wp
+    g.np = g.plane * B
+    g.sl = g.wp + 4
+    g.cs = g.sl + (g.np + 511) // 512 * 512 + g.wp + 4
+    g.cs = (g.cs + 3) // 4 * 4
+    return g
+
+
+def to_act(t, g):
+    B, C, H, W = t.shape
+    a = torch.zeros(C // 8, g.cs, 8)
+    av = a[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
+    av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+    return a
+
+
+def from_act(a, g, C):
+    B, H, W = g.batch, g.height, g.width
+    av = a[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
+    return av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, C, H, W)
+
+
+def pack(w):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_bf16s_weight   # pure torch host code
+    return pack_bf16s_weight(w)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 12, 20, 16, 64, "plain"), (2, 9, 14, 32, 64, "relu"),
+                                                 (1, 17, 33, 32, 128, "res"), (3, 16, 16, 64, 64, "plain")])
+def test_bf16_split_conv_matches_fp64(B, H, W, cin, cout, mode):
+    gen = torch.Generator().manual_seed(H * W + cin)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / (3.0 * cin ** 0.5)
+    r = torch.randn(B, cout, H, W, generator=gen)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+    g = geom(B, H, W)
+    xa, ra = to_act(x, g), to_act(r, g)
+    ya = torch.full((cout // 8, g.cs, 8), float("nan"))
+    wp = pack(w)
+    l = E.lib()
+    E.check(l.dinv_conv3x3_bf16s(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya),
+                                 E.p(ra) if mode == "res" else None, int(mode == "relu"), None))
+    out = from_act(ya, g, cout)
+    assert not torch.isnan(out).any()
+    err = float((out.double() - ref).norm() / ref.norm())
+    assert err < 2e-5, err          # two-part split: a few 1e-6 per layer
+    # the zero border of the padded layout stays zero (the next layer reads it as padding)
+    full = ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
+    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
+    assert float(full[:, :, H + 1].abs().max()) == 0 and float(full[:, :, :, W + 1:].abs().max()) == 0

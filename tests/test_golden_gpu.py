@@ -154,7 +154,7 @@ def test_tomography_normalised_golden(dev):
     assert rel_err(p.A_dagger(d["y"], fbp=True), d["fbp"]) < TOL
 
 
-@pytest.mark.parametrize("mode", ["", "2", "3"])
+@pytest.mark.parametrize("mode", ["", "2", "3", "bf16s"])
 def test_drunet_unit_gain_resblocks_golden(dev, mode, monkeypatch):
     """End-to-end DRUNet parity that is sensitive to the ResBlock kernels: orthogonal gain 1.0 on the 56 ResBlock convs
     (with the reference's 0.2 every branch is ~0.04x the identity path).  Default fp32 Winograd path and both
@@ -162,10 +162,13 @@ def test_drunet_unit_gain_resblocks_golden(dev, mode, monkeypatch):
     import deepinv_amd as dinv
     from oracle import drunet_cpu as OD
 
-    if mode:
+    monkeypatch.delenv("DINV_CONV_BF16X3", raising=False)
+    monkeypatch.setenv("DINV_DRUNET_CONV", "wino")
+    if mode == "bf16s":      # the pipelined two-part split kernel, forced also where its tiles would not fill the chip
+        monkeypatch.setenv("DINV_DRUNET_CONV", "bf16s")
+        monkeypatch.setenv("DINV_DRUNET_CONV_FORCE", "1")
+    elif mode:
         monkeypatch.setenv("DINV_CONV_BF16X3", mode)
-    else:
-        monkeypatch.delenv("DINV_CONV_BF16X3", raising=False)
     sd = OD.init_state_dict(2, 2, seed=321, res_gain=1.0)
     den = dinv.models.DRUNet(2, 2, pretrained=None).to(dev).eval()
     den.load_state_dict(sd)
