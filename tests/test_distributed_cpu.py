@@ -35,7 +35,8 @@ def _worker(rank, world, port, n_total, q):
     with dinv.distributed.BatchParallelContext(backend="gloo", device="cpu") as ctx:
         sl = ctx.slab(n_total)
         rec = dinv.distributed.reconstruct_batch_parallel(ctx, model, y_full, phys)
-        q.put((rank, sl.start, sl.stop, rec.clone()))
+        q.put((rank, sl.start, sl.stop, rec.clone().numpy()))   # by value: a tensor would travel as a shared-memory
+        # handle that can vanish when this process exits before the parent maps it
 
 
 @pytest.mark.parametrize("n_total", [8, 7])
@@ -69,5 +70,6 @@ def test_batch_parallel_equals_single_process(n_total):
     slabs = sorted((s, e) for _, s, e, _ in results)
     assert slabs[0][0] == 0 and slabs[-1][1] == n_total and slabs[0][1] == slabs[1][0]   # contiguous cover
     for _, _, _, rec in results:
+        rec = torch.from_numpy(rec)
         assert rec.shape == ref.shape
         assert torch.allclose(rec, ref, atol=1e-6)   # every rank holds the full gathered batch
