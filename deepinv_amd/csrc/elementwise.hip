@@ -74,10 +74,14 @@ __global__ __launch_bounds__(64) void dot_final_kernel(int nblk, const float* __
 // CG updates with per-sample scalars kept on the device (conjugate_gradient.py:55-66):
 //   mode 0:  alpha_b = num[b] / (den[b] + eps);  x += alpha_b p ;  r -= alpha_b Ap
 //   mode 1:  beta_b  = num[b] / (den[b] + eps);  p  = r + beta_b p
+// `done` (optional device flag): once the solve has converged the updates are skipped, so iterations issued after
+// convergence leave x, r, p exactly as the reference's `break` would (conjugate_gradient.py:61).
 __global__ __launch_bounds__(256) void cg_update_kernel(int mode, int64_t n, const float* __restrict__ num,
                                                         const float* __restrict__ den, float eps,
                                                         float* __restrict__ v0, float* __restrict__ v1,
-                                                        const float* __restrict__ w0, const float* __restrict__ w1) {
+                                                        const float* __restrict__ w0, const float* __restrict__ w1,
+                                                        const int32_t* __restrict__ done) {
+    if (done && done[0]) return;
     const int b = blockIdx.y;
     const float s = num[b] / (den[b] + eps);
     const int64_t base = (int64_t)b * n, n4 = n / 4;
@@ -101,6 +105,16 @@ __global__ __launch_bounds__(256) void cg_update_kernel(int mode, int64_t n, con
         if (mode == 0) { v0[o] = fmaf(s, w0[o], v0[o]); v1[o] = fmaf(-s, w1[o], v1[o]); }
         else v0[o] = fmaf(s, v0[o], w0[o]);
     }
+}
+
+// done |= all_b(res[b] < tol2[b])   (the reference's torch.all(res_new < tol), evaluated on the device)
+__global__ __launch_bounds__(64) void cg_check_kernel(int batch, const float* __restrict__ res,
+                                                      const float* __restrict__ tol2, int32_t* __restrict__ done) {
+    int ok = 1;
+    for (int b = threadIdx.x; b < batch; b += 64) ok &= (res[b] < tol2[b]) ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ok &= __shfl_xor(ok, m);
+    if (threadIdx.x == 0 && ok) done[0] = 1;
 }
 
 inline unsigned stream_blocks(int64_t n) { return (unsigned)std::min<int64_t>(std::max<int64_t>(ceil_div(n / 4 + 1, 256), 1), 2048); }
@@ -141,7 +155,28 @@ extern "C" int dinv_cg_update(int32_t mode, int32_t batch, int64_t n, const floa
     if (batch == 0 || n == 0) return 0;
     DINV_REQUIRE(batch <= 65535 && n % 4 == 0, "batch too large or n %% 4 != 0");
     hipLaunchKernelGGL(cg_update_kernel, dim3(stream_blocks(n), batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       mode, n, num, den, eps, v0, v1, w0, w1);
+                       mode, n, num, den, eps, v0, v1, w0, w1, (const int32_t*)nullptr);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_cg_update_masked(int32_t mode, int32_t batch, int64_t n, const float* num, const float* den, float eps,
+                                     float* v0, float* v1, const float* w0, const float* w1, const int32_t* done,
+                                     dinv_stream_t stream) {
+    DINV_REQUIRE((mode == 0 || mode == 1) && batch >= 0 && n >= 0 && num && den && v0 && w0 && done, "bad arguments");
+    DINV_REQUIRE(mode == 1 || (v1 && w1), "mode 0 needs r and Ap");
+    if (batch == 0 || n == 0) return 0;
+    DINV_REQUIRE(batch <= 65535 && n % 4 == 0, "batch too large or n %% 4 != 0");
+    hipLaunchKernelGGL(cg_update_kernel, dim3(stream_blocks(n), batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       mode, n, num, den, eps, v0, v1, w0, w1, done);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_cg_check(int32_t batch, const float* res, const float* tol2, int32_t* done, dinv_stream_t stream) {
+    DINV_REQUIRE(batch >= 0 && res && tol2 && done, "bad arguments");
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(cg_check_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), batch, res, tol2, done);
     DINV_CHECK_LAUNCH();
     return 0;
 }

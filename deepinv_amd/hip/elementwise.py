@@ -22,6 +22,8 @@ def _l():
         l.dinv_batched_dot_blocks.argtypes = [i64]
         l.dinv_batched_dot.argtypes = [i32, i64, vp, vp, vp, vp, vp]
         l.dinv_cg_update.argtypes = [i32, i32, i64, vp, vp, f32, vp, vp, vp, vp, vp]
+        l.dinv_cg_update_masked.argtypes = [i32, i32, i64, vp, vp, f32, vp, vp, vp, vp, vp, vp]
+        l.dinv_cg_check.argtypes = [i32, vp, vp, vp, vp]
         _declared = True
     return l
 
@@ -57,15 +59,28 @@ def batched_dot(x, y):
     return out
 
 
-def cg_update_xr(num, den, eps, x, r, p, Ap):
-    """x += s p ; r -= s Ap  with s_b = num_b / (den_b + eps), in place"""
+def cg_update_xr(num, den, eps, x, r, p, Ap, done=None):
+    """x += s p ; r -= s Ap  with s_b = num_b / (den_b + eps), in place (skipped once the device flag `done` is set)"""
     B = x.shape[0]
-    check(_l().dinv_cg_update(0, B, x.numel() // B, ptr(num), ptr(den), float(eps), ptr(x), ptr(r), ptr(p), ptr(Ap),
-                              stream_ptr(x.device)))
+    if done is None:
+        check(_l().dinv_cg_update(0, B, x.numel() // B, ptr(num), ptr(den), float(eps), ptr(x), ptr(r), ptr(p), ptr(Ap),
+                                  stream_ptr(x.device)))
+    else:
+        check(_l().dinv_cg_update_masked(0, B, x.numel() // B, ptr(num), ptr(den), float(eps), ptr(x), ptr(r), ptr(p),
+                                         ptr(Ap), ptr(done), stream_ptr(x.device)))
 
 
-def cg_update_p(num, den, eps, p, r):
-    """p = r + s p  with s_b = num_b / (den_b + eps), in place"""
+def cg_update_p(num, den, eps, p, r, done=None):
+    """p = r + s p  with s_b = num_b / (den_b + eps), in place (skipped once `done` is set)"""
     B = p.shape[0]
-    check(_l().dinv_cg_update(1, B, p.numel() // B, ptr(num), ptr(den), float(eps), ptr(p), None, ptr(r), None,
-                              stream_ptr(p.device)))
+    if done is None:
+        check(_l().dinv_cg_update(1, B, p.numel() // B, ptr(num), ptr(den), float(eps), ptr(p), None, ptr(r), None,
+                                  stream_ptr(p.device)))
+    else:
+        check(_l().dinv_cg_update_masked(1, B, p.numel() // B, ptr(num), ptr(den), float(eps), ptr(p), None, ptr(r), None,
+                                         ptr(done), stream_ptr(p.device)))
+
+
+def cg_check(res, tol2, done):
+    """done |= all(res < tol2), on the device (no host round trip)"""
+    check(_l().dinv_cg_check(res.shape[0], ptr(res), ptr(tol2), ptr(done), stream_ptr(res.device)))

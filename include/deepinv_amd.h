@@ -277,6 +277,13 @@ int dinv_batched_dot(int32_t batch, int64_t n, const float* x, const float* y, f
  *   mode 0: v0 (x) += s_b * w0 (p) ; v1 (r) -= s_b * w1 (Ap)        mode 1: v0 (p) = w0 (r) + s_b * v0 (p) */
 int dinv_cg_update(int32_t mode, int32_t batch, int64_t n, const float* num, const float* den, float eps,
                    float* v0, float* v1, const float* w0, const float* w1, dinv_stream_t stream);
+/* Device-side convergence (conjugate_gradient.py:61 `if torch.all(res < tol): break` without a host round trip per
+ * iteration): dinv_cg_check sets *done when every sample's residual is below its tolerance; the masked update is a
+ * no-op once *done is set, so iterations issued after convergence leave the iterate exactly as the break would. */
+int dinv_cg_update_masked(int32_t mode, int32_t batch, int64_t n, const float* num, const float* den, float eps,
+                          float* v0, float* v1, const float* w0, const float* w1, const int32_t* done,
+                          dinv_stream_t stream);
+int dinv_cg_check(int32_t batch, const float* res, const float* tol2, int32_t* done, dinv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,69 @@
+"""Loop-algebra kernels (deepinv_amd/csrc/elementwise.hip) on the host emulation: the CG driver of
+deepinv_amd/optim/linear.py with its device-side convergence flag against the oracle's CG
+(reference deepinv/optim/linear/conjugate_gradient.py:48-75)."""
+import ctypes
+
+import pytest
+import torch
+
+import emu_lib as E
+from oracle import optim_cpu as OO
+
+
+class EmuEw:
+    """deepinv_amd.hip.elementwise with the kernels running in the fiber emulation on CPU tensors"""
+
+    def __init__(self):
+        self.l = E.lib()
+        self.l.dinv_batched_dot_blocks.restype = ctypes.c_int32
+
+    def lincomb(self, a, x, b=0.0, y=None, c=0.0, z=None):
+        out = torch.empty_like(x)
+        E.check(self.l.dinv_lincomb(ctypes.c_int64(x.numel()), ctypes.c_float(a), E.p(x), ctypes.c_float(b), E.p(y),
+                                    ctypes.c_float(c), E.p(z), E.p(out), None))
+        return out
+
+    def batched_dot(self, x, y):
+        B, n = x.shape[0], x.numel() // x.shape[0]
+        out = torch.empty(B)
+        part = torch.empty(B * self.l.dinv_batched_dot_blocks(ctypes.c_int64(n)))
+        E.check(self.l.dinv_batched_dot(B, ctypes.c_int64(n), E.p(x), E.p(y), E.p(out), E.p(part), None))
+        return out
+
+    def cg_update_xr(self, num, den, eps, x, r, p, Ap, done=None):
+        B = x.shape[0]
+        E.check(self.l.dinv_cg_update_masked(0, B, ctypes.c_int64(x.numel() // B), E.p(num), E.p(den), ctypes.c_float(eps),
+                                             E.p(x), E.p(r), E.p(p), E.p(Ap), E.p(done), None))
+
+    def cg_update_p(self, num, den, eps, p, r, done=None):
+        B = p.shape[0]
+        E.check(self.l.dinv_cg_update_masked(1, B, ctypes.c_int64(p.numel() // B), E.p(num), E.p(den), ctypes.c_float(eps),
+                                             E.p(p), None, E.p(r), None, E.p(done), None))
+
+    def cg_check(self, res, tol2, done):
+        E.check(self.l.dinv_cg_check(res.shape[0], E.p(res), E.p(tol2), E.p(done), None))
+
+
+@pytest.mark.parametrize("check_every", [1, 4, 1000])
+def test_cg_with_device_side_convergence_matches_reference_cg(check_every, monkeypatch):
+    """however rarely the host looks at the flag (every iteration, every 4th, never before max_iter), the iterate is
+    the one the reference's `break` leaves: updates issued after convergence are no-ops"""
+    from deepinv_amd.optim import linear
+
+    monkeypatch.setattr(linear, "CG_CHECK_EVERY", check_every)
+    g = torch.Generator().manual_seed(0)
+    M = torch.randn(3, 24, 24, generator=g)
+    H = lambda v: torch.einsum("bij,bj->bi", M.transpose(1, 2) @ M + 0.5 * torch.eye(24), v.reshape(3, 24)).reshape(v.shape)
+    b = torch.randn(3, 2, 12, generator=g)
+    calls = {"n": 0}
+
+    def Hc(v):
+        calls["n"] += 1
+        return H(v)
+
+    x = linear._conjugate_gradient_hip(Hc, b, 60, 1e-5, 1e-8, None, False, ew=EmuEw())
+    ref = OO.conjugate_gradient(H, b, max_iter=60, tol=1e-5)
+    assert float((x - ref).norm() / ref.norm()) < 1e-5
+    if check_every == 1:
+        n1 = calls["n"]
+        assert n1 < 40      # really stopped early
