@@ -18,8 +18,8 @@
 //     the input (split into hi / lo bf16 planes while it is staged) and 3 taps x 16 channels x 64 couts of pre-split
 //     weights = 45 KB of LDS; two such stages alternate: the global loads of sub-step t+2 (into registers) and the
 //     split + LDS write of sub-step t+1 run underneath the 36 MFMAs per wave of sub-step t; ONE barrier per sub-step.
-//     Odd waves stage before their MFMAs, even waves after them, so that on a SIMD one wave's vector work overlaps
-//     the other wave's matrix work.
+//     Waves 4-7 stage before their MFMAs, waves 0-3 after them, so that on a SIMD (which holds waves w and w+4) one
+//     wave's vector work overlaps the other wave's matrix work.
 #include "drunet_common.hpp"
 
 using namespace dinv;
@@ -33,9 +33,6 @@ constexpr int XUNITS = 2 * 2 * SEGX;    // 16-byte units of a stage's activation
 constexpr int WUNITS = 2 * 3 * 2 * 64;  // ... of its weights: [plane][dx][cblk][co 64]
 constexpr int STAGE = XUNITS + WUNITS;  // 2824 units = 45,184 bytes
 constexpr int NSTAGE = 2;
-constexpr int XCH = 2 * SEGX;           // 32-byte fp32 chunks (8 channels of one pixel) per sub-step: 1028
-constexpr int XPER = (XCH + 511) / 512; // per thread: 3 (the third only for 4 threads)
-constexpr int WPER = (WUNITS + 511) / 512;  // 2 (the second for 256 threads)
 
 struct SArgs {
     Geom g;
@@ -86,6 +83,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, cons
 }
 #endif
 
+struct Staged {   // one sub-step's share of a thread, between its global loads and its LDS writes
+    float4 x0a, x0b, x1a, x1b, x2a, x2b;
+    uint4 w0, w1;
+};
+
 template <bool RELU, int NRES>
 __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
     DINV_DYN_LDS(uint4, lds);   // [NSTAGE][STAGE]
@@ -108,50 +110,40 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    // ---- this thread's staging slots (the same in every sub-step)
-    int xg[XPER], xl[XPER];   // global offset (floats) inside the sub-step's source rows, LDS unit inside the stage
-    bool xok[XPER];
-#pragma unroll
-    for (int k = 0; k < XPER; ++k) {
-        const int q = tid + k * 512;
-        xok[k] = q < XCH;
-        const int qq = xok[k] ? q : 0;
-        const int cb = qq / SEGX, i = qq - cb * SEGX;
-        xg[k] = (int)(((int64_t)cb * a.g.cs + i) * 8);   // cs * 8 < 2^31 is checked by the launcher
-        xl[k] = cb * SEGX + i;                           // + plane * 2 * SEGX
-    }
+    // ---- this thread's staging slots (the same in every sub-step).  Every thread moves two full chunks (its pixel
+    // tid of both channel blocks) and one weight unit; the 4 chunks of the two tail pixels and the remaining 256
+    // weight units are LOADED by every thread (clamped, redundant addresses) and only WRITTEN by the threads that own
+    // them, so the loads are straight-line code without divergent branches.
+    const int tq = tid & 3;                                  // tail chunk: channel block tq>>1, pixel 512 + (tq&1)
+    const int xg0 = tid * 8, xg1 = (int)(a.g.cs * 8) + tid * 8;                      // cs * 16 < 2^31 (launcher)
+    const int xg2 = (int)((int64_t)(tq >> 1) * a.g.cs * 8) + (TP + (tq & 1)) * 8;
+    const int xl0 = tid, xl1 = SEGX + tid, xl2 = (tq >> 1) * SEGX + TP + (tq & 1);    // + plane * 2 * SEGX
+    const int wu1 = 512 + (tid & 255);
     const uint4* wsrc0 = a.w + (int64_t)ty * nsub * WUNITS;
     const float* xsrc0 = a.x + (a.g.sl + p0 - 1) * 8;
 
-    float4 xr[XPER][2];
-    uint4 wr[WPER];
+    Staged rg;
     auto issue = [&](int t) {   // global loads of sub-step t into registers
         const int s = t / 3, dyi = t - 3 * s;
         const float* xs = xsrc0 + ((int64_t)(2 * s) * a.g.cs + (int64_t)(dyi - 1) * a.g.wp) * 8;
-#pragma unroll
-        for (int k = 0; k < XPER; ++k)
-            if (xok[k]) {
-                xr[k][0] = ld4(xs + xg[k]);
-                xr[k][1] = ld4(xs + xg[k] + 4);
-            }
+        rg.x0a = ld4(xs + xg0); rg.x0b = ld4(xs + xg0 + 4);
+        rg.x1a = ld4(xs + xg1); rg.x1b = ld4(xs + xg1 + 4);
+        rg.x2a = ld4(xs + xg2); rg.x2b = ld4(xs + xg2 + 4);
         const uint4* ws = wsrc0 + (int64_t)t * WUNITS;
-#pragma unroll
-        for (int k = 0; k < WPER; ++k)
-            if (tid + k * 512 < WUNITS) wr[k] = ws[tid + k * 512];
+        rg.w0 = ws[tid];
+        rg.w1 = ws[wu1];
     };
     auto commit = [&](int t) {   // split + write the registers of sub-step t into its ring slot
         uint4* st = lds + (t % NSTAGE) * STAGE;
-#pragma unroll
-        for (int k = 0; k < XPER; ++k)
-            if (xok[k]) {
-                uint4 hi, lo;
-                split8(xr[k][0], xr[k][1], hi, lo);
-                st[xl[k]] = hi;
-                st[2 * SEGX + xl[k]] = lo;
-            }
-#pragma unroll
-        for (int k = 0; k < WPER; ++k)
-            if (tid + k * 512 < WUNITS) st[XUNITS + tid + k * 512] = wr[k];
+        uint4 hi, lo;
+        split8(rg.x0a, rg.x0b, hi, lo);
+        st[xl0] = hi; st[2 * SEGX + xl0] = lo;
+        split8(rg.x1a, rg.x1b, hi, lo);
+        st[xl1] = hi; st[2 * SEGX + xl1] = lo;
+        split8(rg.x2a, rg.x2b, hi, lo);
+        if (tid < 4) { st[xl2] = hi; st[2 * SEGX + xl2] = lo; }
+        st[XUNITS + tid] = rg.w0;
+        if (tid < 256) st[XUNITS + wu1] = rg.w1;
     };
 
     // operand slots of this lane: A = weights (row = cout l31 of m-tile, k half = channel block lhi),
@@ -166,7 +158,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
     for (int t = 0; t < nsub; ++t) {
         // registers hold sub-step t+1 (loaded one iteration ago); its slot was last read in iteration t-1, before
         // the barrier that ended that iteration
-        const bool early = (wv & 1) != 0;
+        const bool early = (wv & 4) != 0;   // waves w and w+4 share a SIMD (dispatch order 0,2,1,3): one of each kind per SIMD
         if (early) {
             if (t + 1 < nsub) commit(t + 1);
             if (t + 2 < nsub) issue(t + 2);
@@ -174,31 +166,38 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
         const uint4* st = lds + (t % NSTAGE) * STAGE;
         const uint4* xs = st;
         const uint4* ws = st + XUNITS;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            uint4 A[2][2], B[2][2];   // [tile][plane]
+        // operands of tap dx+1 are read while the 12 MFMAs of tap dx run; the three products go product-major, so that
+        // consecutive MFMAs write different accumulators (a dependent 32x32 MFMA would wait for its predecessor)
+        uint4 A[2][2][2], B[2][2][2];   // [buffer][tile][plane]
+        auto rd = [&](int buf, int dx) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m) A[m][pl] = ws[(pl * 3 + dx) * 128 + aslot + m * 32];
+                for (int m = 0; m < 2; ++m) A[buf][m][pl] = ws[(pl * 3 + dx) * 128 + aslot + m * 32];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) B[n][pl] = xs[pl * 2 * SEGX + bslot + n * 32 + dx];
+                for (int n = 0; n < 2; ++n) B[buf][n][pl] = xs[pl * 2 * SEGX + bslot + n * 32 + dx];
             }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int cur = dx & 1;
+            if (dx < 2) rd(cur ^ 1, dx + 1);
             // smallest terms first: ah*bl, al*bh, ah*bh
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int e = 0; e < 3; ++e) {
+                const int pa = e == 1 ? 1 : 0, pb = e == 0 ? 1 : 0;
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    acc[m][n] = mfma_bf16(A[m][0], B[n][1], acc[m][n]);
-                    acc[m][n] = mfma_bf16(A[m][1], B[n][0], acc[m][n]);
-                    acc[m][n] = mfma_bf16(A[m][0], B[n][0], acc[m][n]);
-                }
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(A[cur][m][pa], B[cur][n][pb], acc[m][n]);
+            }
         }
         if (!early) {
             if (t + 1 < nsub) commit(t + 1);
             if (t + 2 < nsub) issue(t + 2);
         }
-        __syncthreads();   // slot t is consumed; slot t+1 is complete
+        lds_barrier();   // slot t is consumed; slot t+1 is complete (global loads of t+2 stay in flight)
     }
     const int cb0 = ty * 8;
 #pragma unroll

@@ -31,6 +31,16 @@ __device__ __forceinline__ bool interior(const Geom& g, int64_t p) {
     return r >= 1 && r <= g.h && c >= 1 && c <= g.w;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load and
+// store of the wave, which the software pipelines of the conv kernels want to keep in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef DINV_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
