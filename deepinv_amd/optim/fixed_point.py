@@ -46,6 +46,53 @@ class FixedPoint(nn.Module):
         if f_step is not None:
             f_step.call_ctx = ctx
 
+    # ------------------------------------------------------------------ HIP-graph replay of the loop
+    def _graph_ok(self, X, compute_metrics):
+        """one iteration can be captured once and replayed when nothing in it depends on the iteration index or on
+        host-side decisions: no autograd, no metrics, no early stop, no backtracking, constant parameters / prior /
+        data fidelity, device tensors.  Opt-in: DINV_LOOP_GRAPH=1 (or `self.use_graph = True`)."""
+        import os
+
+        import torch
+
+        if not (getattr(self, "use_graph", False) or os.environ.get("DINV_LOOP_GRAPH", "0") == "1"):
+            return False
+        if torch.is_grad_enabled() or compute_metrics or self.backtracking_config is not None or self.max_iter < 3:
+            return False
+        if self.early_stop and self.check_conv_fn is not None:
+            return False
+        if X is None or not all(isinstance(t, torch.Tensor) and t.is_cuda for t in X["est"]) or X.get("cost") is not None:
+            return False
+        first = [f(0) if f else None for f in (self.update_params_fn, self.update_data_fidelity_fn, self.update_prior_fn)]
+        for it in range(1, self.max_iter):
+            cur = [f(it) if f else None for f in (self.update_params_fn, self.update_data_fidelity_fn, self.update_prior_fn)]
+            if cur[0] != first[0] or cur[1] is not first[1] or cur[2] is not first[2]:
+                return False
+        return True
+
+    def _run_graph(self, X, *args, **kwargs):
+        """iteration 0 runs eagerly (it builds every plan / workspace), iteration 1 is captured into a HIP graph whose
+        inputs are static copies of the iterate, and the graph is replayed for the remaining iterations: one host call
+        per iteration instead of ~80 kernel launches (fixed_point.py:324-361 with the same arithmetic)."""
+        import torch
+
+        X = self.single_iteration(X, 0, *args, **kwargs)
+        static = [t.clone() for t in X["est"]]
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                Xo = self.single_iteration({"est": tuple(static), "cost": None}, 1, *args, **kwargs)
+                for s, o in zip(static, Xo["est"]):
+                    s.copy_(o)
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(1, self.max_iter):
+            graph.replay()
+        out = {"est": tuple(s.clone() for s in static), "cost": None}
+        del graph
+        return out
+
     def forward(self, *args, init=None, compute_metrics=False, x_gt=None, **kwargs):
         """fixed_point.py:262-361"""
         self._set_ctx(CallContext())
@@ -54,6 +101,8 @@ class FixedPoint(nn.Module):
             metrics = self.init_metrics_fn(X, x_gt=x_gt) if self.init_metrics_fn and compute_metrics else None
             self.backtracking_check = True
             failed = 0
+            if self._graph_ok(X, compute_metrics):
+                return self._run_graph(X, *args, **kwargs), metrics
             for it in range(self.max_iter):
                 X_prev = X
                 X = self.single_iteration(X, it, *args, **kwargs)
