@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
-WINO_PMC_TRAFFIC = 1.4675e9   # bytes per conv3x3_wino_kernel launch, B=32 320x320 (see roofline below)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # {kernel: {bytes_per_launch, commit, config}}
 MFMA_BF16_PEAK = 2500e12     # FLOP/s dense bf16 matrix (v_mfma_f32_32x32x16_bf16), MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12   # FLOP/s dense fp32 matrix (v_mfma_f32_32x32x2_f32)
 
@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--coils", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the operator rows of configs 3-5")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,44 +134,64 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3
+    def op_row(name, cfg, batch, fn, alg, n=20, **extra):
+        t = time_op(fn, n)
+        row = {"op": name, "config": cfg, "batch": batch, "ms": round(t * 1e3, 4), "alg_MB": round(alg / 1e6, 2),
+               "GBps": round(alg / t / 1e9, 1), "frac_hbm_peak": round(alg / t / HBM_PEAK, 4)}
+        for k, v in extra.items():      # *_per_s extras are work counts: divide by the measured time
+            row[k] = round(v / t, 1) if k.endswith("_per_s") else v
+        ops.append(row)
+
     alg = (B_local * 2 * H * W + B_local * 2 * args.coils * H * W) * 4 + args.coils * H * W * 8 + 2 * H * W * 4
-    for name, fn in (("MultiCoilMRI.A", lambda: physics.A(x_true)), ("MultiCoilMRI.A_adjoint", lambda: physics.A_adjoint(y))):
-        t = time_op(fn)
-        ops.append({"op": name, "batch": B_local, "ms": round(t * 1e3, 4), "alg_MB": round(alg / 1e6, 2),
-                    "GBps": round(alg / t / 1e9, 1), "frac_hbm_peak": round(alg / t / HBM_PEAK, 4)})
+    op_row("MultiCoilMRI.A", "cfg2", B_local, lambda: physics.A(x_true), alg)
+    op_row("MultiCoilMRI.A_adjoint", "cfg2", B_local, lambda: physics.A_adjoint(y), alg)
+    op_row("MultiCoilMRI.A_adjoint_A", "cfg2", B_local, lambda: physics.A_adjoint_A(x_true), 2 * B_local * 2 * H * W * 4
+           + args.coils * H * W * 8 + 2 * H * W * 4)
+    if world == 1 and not args.no_other_configs:
+        other_config_ops(dinv, device, op_row)
 
     if rank == 0:
         slices_per_s = args.batch * args.steps / elapsed
         # dominant kernel = the one with the largest share of the timed region
         kname, kp = max(conv_prof.items(), key=lambda kv: kv[1]["ms"]) if conv_prof else ("none", None)
         achieved = kp["mfma_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
-        bf16 = "bf16" in kname   # opt-in bf16-split convolution: priced against the bf16 matrix peak
+        bf16 = "bf16" in kname   # bf16-split convolution: priced against the bf16 matrix peak
         peak = MFMA_BF16_PEAK if bf16 else MFMA_F32_PEAK
         all_ms = sum(v["ms"] for v in conv_prof.values())
         all_direct = sum(v["direct_flops"] for v in conv_prof.values())
+        from deepinv_amd.models.drunet import _resblock_conv
+        conv_mode = ("bf16x" + os.environ["DINV_CONV_BF16X3"] if os.environ.get("DINV_CONV_BF16X3") in ("2", "3")
+                     else _resblock_conv())
+        dtype = {"bf16s": "f32 in/out; ResBlock convs = bf16 x2 exact operand split (3 products), f32 accumulate",
+                 "bf16x2": "f32 in/out; ResBlock convs = bf16 x2 exact operand split (3 products), f32 accumulate",
+                 "bf16x3": "f32 in/out; ResBlock convs = bf16 x3 exact operand split (6 products), f32 accumulate"}.get(conv_mode, "f32")
+        # HBM bytes per launch of the dominant kernel: measured by separate rocprofv3 --pmc passes (TCC_EA0_RDREQ x 64 B x 2
+        # [gfx950 wide-load correction] + TCC_EA0_WRREQ x 64 B, averaged over the launches of one DRUNet call) and
+        # recorded, with the commit and configuration they were taken at, in profiles/pmc_traffic.json
+        traffic = None
+        try:
+            rec = json.load(open(PMC_TRAFFIC_FILE)).get(kname)
+            if rec and rec.get("config") == {"batch": B_local, "height": H, "width": W}:
+                traffic = rec["bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         res = {
             "metric": "PnP-PGD slices/sec (50 iters), 2D MRI 8-coil 320x320, 4x radial mask, DRUNet",
             "value": round(slices_per_s, 4), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (bf16 x%s exact operand split, f32 accumulate)" % os.environ["DINV_CONV_BF16X3"]
-                     if os.environ.get("DINV_CONV_BF16X3") in ("2", "3") else "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: 2D MRI 8-coil 320x320, 4x radial mask (80 spokes), PnP-PGD 50 it + "
                                    "DRUNet(2->2, random init), global batch %d" % args.batch,
                        "global_batch": args.batch, "per_gpu_batch": B_local, "iters": args.iters,
-                       "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if world > 1 else "none"},
-            # achieved = flops EXECUTED on the MFMA pipe by the dominant kernel / its HIP-event time; for the
-            # Winograd F(2x2,3x3) kernel that is 16/36 of the direct-convolution count, which is reported
-            # separately as the effective rate of all 3x3 convs (it may exceed the fp32 MFMA peak).
+                       "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if world > 1 else "none",
+                       "resblock_conv": conv_mode, "loop_graph": os.environ.get("DINV_LOOP_GRAPH", "0") == "1"},
+            # achieved = flops EXECUTED on the matrix pipe by the dominant kernel / its HIP-event time: 3 products per
+            # multiply for the bf16 split kernel, 16/36 of the direct count for fp32 Winograd F(2x2,3x3); the effective
+            # direct-convolution rate of all 3x3 convs is reported next to it
             "roofline": {"bound": "mfma", "kernel": kname + (" (DRUNet 3x3 conv, v_mfma_f32_32x32x16_bf16, split operands)" if bf16
                                                               else " (DRUNet 3x3 conv, v_mfma_f32_32x32x2_f32)"),
                          "achieved": round(achieved / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4),
-                         # HBM bytes per launch from separate PMC passes (profiles/pmc/r01_drunet_{rdreq,wrreq}.csv:
-                         # TCC_EA0_RDREQ x 64 B x 2 (gfx950 wide-load correction) + TCC_EA0_WRREQ x 64 B, averaged
-                         # over the 56 Winograd launches of one DRUNet call at this configuration); algorithmic
-                         # bytes are ~1.1e9 (activations in + out + residual, weights): the kernel is MFMA-bound
-                         "traffic": WINO_PMC_TRAFFIC if (B_local == 32 and H == 320 and W == 320 and not bf16) else None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "launches": kp["launches"] if kp else 0,
                          "avg_launch_ms": round(kp["ms"] / max(kp["launches"], 1), 4) if kp else 0.0,
                          "share_of_step": round(kp["ms"] * 1e-3 / elapsed, 4) if kp else 0.0,
@@ -179,57 +200,101 @@ def main():
             "operators": ops,
         }
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
-            res["cpu_baseline"] = cpu_baseline(denoiser, maps, mask, H, W, args.coils, args.iters)
+            res["cpu_baseline"] = cpu_baseline(denoiser, maps, mask, H, W, args.coils, args.iters, y0=y[:1].cpu(),
+                                               x_gpu0=out[:1].cpu())
+            res["parity_rel_err_50it"] = res["cpu_baseline"].pop("parity_rel_err")
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(denoiser, maps, mask, H, W, coils, iters):
-    """The oracle ("port": same ATen CPU call sequence as the reference) timed on this box's host
-    cores on a bounded sample: 1 slice x `n_it` PGD iterations, scaled to `iters` iterations
-    (per-iteration cost is constant; per-slice CPU cost is batch independent)."""
+def other_config_ops(dinv, device, op_row):
+    """operator rows of BASELINE configs[2..4] at their per-GPU shard shapes (SURVEY 8d byte counts);
+    the Radon rows also carry bilinear samples/s (that operator is gather-rate bound, not HBM bound)"""
+    g = torch.Generator().manual_seed(0)
+    # cfg3: Tomography 512x512, 720 angles, 8 images per GPU
+    B, W, A = 8, 512, 720
+    phys = dinv.physics.Tomography(angles=A, img_width=W, circle=False, normalize=True, device=device)
+    x = torch.rand(B, 1, W, W, generator=g).to(device)
+    y = phys.A(x)
+    G = y.shape[2]
+    alg = B * (W * W + G * A) * 4
+    smp = float(B) * G * G * A
+    op_row("Tomography.A", "cfg3", B, lambda: phys.A(x), alg, n=5, Gsamples_per_s=smp / 1e9)
+    op_row("Tomography.A_adjoint", "cfg3", B, lambda: phys.A_adjoint(y), alg, n=5, Gsamples_per_s=smp / 1e9)
+    op_row("Tomography.fbp", "cfg3", B, lambda: phys.A_dagger(y, fbp=True), alg + 2 * B * G * A * 4, n=5)
+    del phys, x, y
+    # cfg4: 3-D MultiCoilMRI 12 coils 16x256x256, 2 volumes per GPU
+    B, coils, vol = 2, 12, (16, 256, 256)
+    nv = vol[0] * vol[1] * vol[2]
+    x = torch.rand(B, 2, *vol, generator=g).to(device)
+    maps = (torch.randn(1, coils, *vol, dtype=torch.complex64, generator=g) / coils ** 0.5).to(device)
+    mask = torch.zeros(*vol)
+    mask[..., ::4] = 1
+    mask[..., 118:138] = 1
+    phys = dinv.physics.MultiCoilMRI(mask=mask.to(device), coil_maps=maps, img_size=(2, *vol), three_d=True, device=device)
+    y = phys.A(x)
+    alg = B * 2 * nv * 4 + B * 2 * coils * nv * 4 + coils * nv * 8 + 2 * nv * 4
+    op_row("MultiCoilMRI3D.A", "cfg4", B, lambda: phys.A(x), alg)
+    op_row("MultiCoilMRI3D.A_adjoint", "cfg4", B, lambda: phys.A_adjoint(y), alg)
+    del phys, x, y, maps
+    # cfg5: Downsampling x4 (bicubic, circular) on 3x256x256, 16 images per GPU
+    B, img = 16, (3, 256, 256)
+    phys = dinv.physics.Downsampling(img_size=img, filter="bicubic", factor=4, padding="circular", device=device)
+    x = torch.rand(B, *img, generator=g).to(device)
+    y = phys.A(x)
+    z = torch.rand(B, *img, generator=g).to(device)
+    alg = B * 3 * (256 * 256 + 64 * 64) * 4
+    op_row("Downsampling.A", "cfg5", B, lambda: phys.A(x), alg)
+    op_row("Downsampling.A_adjoint", "cfg5", B, lambda: phys.A_adjoint(y), alg)
+    op_row("Downsampling.prox_l2", "cfg5", B, lambda: phys.prox_l2(z, y, 0.7), 2 * B * 3 * 256 * 256 * 4 + B * 3 * 64 * 64 * 4)
+
+
+def cpu_baseline(denoiser, maps, mask, H, W, coils, iters, y0=None, x_gpu0=None):
+    """The oracle ("port": same ATen CPU call sequence as the reference) timed on this box's host cores on a bounded
+    sample: the FULL `iters`-iteration PnP-PGD reconstruction of slice 0 of the GPU batch (per-slice CPU cost is batch
+    independent).  The CPU result is kept: its relative distance to the GPU reconstruction of the same measurement is
+    the headline-configuration parity figure (`parity_rel_err_50it`, north_star bound 1e-4)."""
     from oracle import drunet_cpu as OD
     from oracle import optim_cpu as OO
     from oracle import physics_cpu as OP
 
     cores = os.cpu_count() or 1
     sd = {k: v.detach().cpu() for k, v in denoiser.state_dict().items()}
-    g = torch.Generator().manual_seed(1000)
-    x = torch.rand(1, 2, H, W, generator=g)
     A = lambda v: OP.multicoil_A(v, maps, mask)
     AT = lambda v: OP.multicoil_AT(v, maps, mask)
-    y = A(x)
+    if y0 is None:
+        y0 = A(torch.rand(1, 2, H, W, generator=torch.Generator().manual_seed(1000)))
     den = lambda u, s: OD.drunet(sd, u, s)
+    calib = {}
     with torch.no_grad():
-        # give the CPU its best shot: oneDNN/MKL at batch 1 degrade badly when oversubscribed (256 threads
-        # on this box: 52 s / iteration), so calibrate the thread count on one denoiser call each
+        # give the CPU its best shot: oneDNN/MKL at batch 1 degrade badly when oversubscribed (256 threads on this
+        # box: 52 s / iteration), so calibrate the thread count on one denoiser call each
+        probe = torch.rand(1, 2, H, W, generator=torch.Generator().manual_seed(7))
         best = None
         for nt in [c for c in (8, 16, 32, 64, 128) if c <= cores] or [cores]:
             torch.set_num_threads(nt)
-            den(y.new_zeros(1, 2, H, W), 0.05)
+            den(probe.new_zeros(1, 2, H, W), 0.05)
             t0 = time.perf_counter()
-            den(x, 0.05)
+            den(probe, 0.05)
             dt = time.perf_counter() - t0
+            calib[str(nt)] = round(dt, 3)
             if best is None or dt < best[1]:
                 best = (nt, dt)
             if dt > 3 * best[1]:
                 break
         torch.set_num_threads(best[0])
-        OO.pnp_pgd(y, A, AT, den, max_iter=1)  # warm-up
-        n_it = 0
+        OO.pnp_pgd(y0, A, AT, den, max_iter=1)  # warm-up
         t0 = time.perf_counter()
-        xk = AT(y)
-        while True:
-            xk = OO.pnp_pgd(y, A, AT, den, max_iter=1, x0=xk)
-            n_it += 1
-            if time.perf_counter() - t0 > 12.0 or n_it >= iters:
-                break
+        xk = OO.pnp_pgd(y0, A, AT, den, max_iter=iters)
         dt = time.perf_counter() - t0
-    per_slice = dt / n_it * iters
-    return {"value": round(1.0 / per_slice, 5), "unit": "slices/s", "cores": torch.get_num_threads(), "host_cores": cores,
-            "kind": "port",
-            "sample": f"1 slice x {n_it} PGD iterations ({dt:.1f} s), scaled to {iters} iterations"}
+    err = None
+    if x_gpu0 is not None:
+        err = float((x_gpu0.double() - xk.double()).norm() / xk.double().norm())
+    return {"value": round(1.0 / dt, 5), "unit": "slices/s", "cores": torch.get_num_threads(), "host_cores": cores,
+            "kind": "port", "threads_calibration_s_per_denoiser_call": calib,
+            "sample": f"slice 0 of the batch, all {iters} PGD iterations ({dt:.1f} s)",
+            "parity_rel_err": None if err is None else float(f"{err:.3e}")}
 
 
 if __name__ == "__main__":

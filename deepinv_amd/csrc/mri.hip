@@ -644,16 +644,16 @@ inline int64_t volume(const dinv_mri_desc* d) {
     return v;
 }
 
-// Sub-batching of the static pipeline: the three passes of a chunk of slices run back to back over the SAME chunk of
-// the coil scratch t (chunk x coils x vol complex64), so t is produced and consumed while it is still resident in the
-// 256 MB Infinity Cache instead of making two extra HBM round trips per call.  0 = whole batch at once.
+// Sub-batching of the static pipeline (DINV_MRI_CHUNK = slices per chunk, 0 / unset = whole batch): the three passes of
+// a chunk run back to back over the SAME chunk of the coil scratch t, so that t is produced and consumed while it may
+// still sit in the 256 MB Infinity Cache.  MEASURED (r02, cfg2, B = 32: A / A^T in ms): whole batch 0.259 /
+// 0.279; chunks of 16: 0.267 / 0.283; of 8: 0.303 / 0.340; of 4: 0.412 / 0.441 - each pass already streams at
+// 4.1-4.8 TB/s, and smaller launches only add ramp-up/tail; 3-D cfg4 per volume: A 0.283 vs 0.303, A^T 0.392 vs 0.300.
+// Hence OFF by default; the knob stays for other shapes.
 int mri_chunk(const dinv_mri_desc* d) {
-    static const int forced = [] { const char* e = getenv("DINV_MRI_CHUNK"); return e ? atoi(e) : -1; }();
-    if (forced >= 0) return forced;
-    // default: chunks of at most ~64 MB of scratch
-    const int64_t per_slice = (int64_t)d->coils * volume(d) * (int64_t)sizeof(float2);
-    const int64_t c = (64ll << 20) / (per_slice > 0 ? per_slice : 1);
-    return (int)std::max<int64_t>(1, c);
+    static const int forced = [] { const char* e = getenv("DINV_MRI_CHUNK"); return e ? atoi(e) : 0; }();
+    (void)d;
+    return forced > 0 ? forced : 0;
 }
 
 }  // namespace
