@@ -20,6 +20,13 @@
 //     split + LDS write of sub-step t+1 run underneath the 36 MFMAs per wave of sub-step t; ONE barrier per sub-step.
 //     Waves 4-7 stage before their MFMAs, waves 0-3 after them, so that on a SIMD (which holds waves w and w+4) one
 //     wave's vector work overlaps the other wave's matrix work.
+//
+// Measured on MI355X (level 1: 128 channels, 160x160, B = 32; random data, so the matrix pipe runs at its power-limited
+// ~2.0 GHz): this kernel 0.73-0.85 ms = 1.0 PFLOP/s executed (the best plain-HIP bf16 GEMMs reach 1.25-1.34 PFLOP/s on
+// random operands, cdna_hip_programming.md 5); the same loop without staging 0.63 ms, staging without MFMAs 0.40 ms.
+// Variants that were built and measured slower: loads two sub-steps ahead in a second register set (0.89 ms), a
+// three-slot ring with the next sub-step's first operands read before the barrier and sched_barrier-pinned phases
+// (0.89 ms: pinning keeps the split's vector work out of the MFMA blocks of the same wave).
 #include "drunet_common.hpp"
 
 using namespace dinv;
@@ -122,10 +129,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
     const uint4* wsrc0 = a.w + (int64_t)ty * nsub * WUNITS;
     const float* xsrc0 = a.x + (a.g.sl + p0 - 1) * 8;
 
-    // Two register sets: the loads of a sub-step are issued TWO sub-steps before its LDS write (set s & 1 holds
-    // sub-step s), so a sub-step may be shorter than the memory latency without stalling on its successor's operands.
-    Staged r0, r1;
-    auto issue = [&](int t, Staged& rg) {   // global loads of sub-step t into registers
+    Staged rg;
+    auto issue = [&](int t) {   // global loads of sub-step t into registers
         const int s = t / 3, dyi = t - 3 * s;
         const float* xs = xsrc0 + ((int64_t)(2 * s) * a.g.cs + (int64_t)(dyi - 1) * a.g.wp) * 8;
         rg.x0a = ld4(xs + xg0); rg.x0b = ld4(xs + xg0 + 4);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
         rg.w0 = ws[tid];
         rg.w1 = ws[wu1];
     };
-    auto commit = [&](int t, const Staged& rg) {   // split + write the registers of sub-step t into its ring slot
+    auto commit = [&](int t) {   // split + write the registers of sub-step t into its ring slot
         uint4* st = lds + (t % NSTAGE) * STAGE;
         uint4 hi, lo;
         split8(rg.x0a, rg.x0b, hi, lo);
@@ -152,14 +157,18 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
     //                             B = pixels  (col = pixel l31 of n-tile, k half = channel block lhi)
     const int aslot = lhi * 64 + l31;                       // + (plane*3 + dx)*128 + m*32
     const int bslot = lhi * SEGX + wv * 64 + l31;           // + plane*2*SEGX + n*32 + dx
-    const bool early = (wv & 4) != 0;   // waves w and w+4 share a SIMD (dispatch order 0,2,1,3): one of each kind per SIMD
 
-    // one sub-step: MFMAs from slot t; `rg` holds sub-step t+1 (written to the other slot, which was last read before
-    // the previous barrier) and is refilled with the loads of sub-step t+3
-    auto step = [&](int t, Staged& rg) {
+    issue(0);
+    commit(0);
+    if (nsub > 1) issue(1);
+    __syncthreads();
+    for (int t = 0; t < nsub; ++t) {
+        // registers hold sub-step t+1 (loaded one iteration ago); its slot was last read in iteration t-1, before
+        // the barrier that ended that iteration
+        const bool early = (wv & 4) != 0;   // waves w and w+4 share a SIMD (dispatch order 0,2,1,3): one of each kind per SIMD
         if (early) {
-            if (t + 1 < nsub) commit(t + 1, rg);
-            if (t + 3 < nsub) issue(t + 3, rg);
+            if (t + 1 < nsub) commit(t + 1);
+            if (t + 2 < nsub) issue(t + 2);
         }
         const uint4* st = lds + (t % NSTAGE) * STAGE;
         const uint4* xs = st;
@@ -192,20 +201,10 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
             }
         }
         if (!early) {
-            if (t + 1 < nsub) commit(t + 1, rg);
-            if (t + 3 < nsub) issue(t + 3, rg);
+            if (t + 1 < nsub) commit(t + 1);
+            if (t + 2 < nsub) issue(t + 2);
         }
-        lds_barrier();   // slot t is consumed; slot t+1 is complete (global loads stay in flight)
-    };
-
-    issue(0, r1);
-    commit(0, r1);
-    if (nsub > 1) issue(1, r0);   // set (s & 1): odd sub-steps in r0, even ones in r1
-    if (nsub > 2) issue(2, r1);
-    __syncthreads();
-    for (int t = 0; t < nsub; t += 2) {
-        step(t, r0);                       // t even: t+1 odd -> r0
-        if (t + 1 < nsub) step(t + 1, r1);
+        lds_barrier();   // slot t is consumed; slot t+1 is complete (global loads of t+2 stay in flight)
     }
     const int cb0 = ty * 8;
 #pragma unroll

@@ -37,7 +37,7 @@ def _bf16_split_mode() -> int:
     return int(v) if v in ("2", "3") else 0
 
 
-DEFAULT_RESBLOCK_CONV = "wino"
+DEFAULT_RESBLOCK_CONV = "bf16s"
 
 
 def _resblock_conv() -> str:
@@ -261,7 +261,7 @@ class DRUNet(Denoiser):
         if mode == "bf16s" and len(pk) > 4 and pk[4] is not None:
             # 512-pixel x 64-cout workgroups: keep it only where they fill the chip (small per-GPU batches at the
             # coarse U-Net levels fall through to the Winograd kernel)
-            if ((g.np + 511) // 512) * (pk[0][2] // 64) >= 256 or os.environ.get("DINV_DRUNET_CONV_FORCE"):
+            if ((g.np + 511) // 512) * (pk[0][2] // 64) >= 192 or os.environ.get("DINV_DRUNET_CONV_FORCE"):
                 K.conv3x3_bf16s(g, x, pk[4], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
                 return
         if pk[2] is not None and mode != "direct" and _use_winograd(g, pk):

@@ -118,6 +118,7 @@ def test_drunet_winograd_matches_oracle(dev, monkeypatch):
     import deepinv_amd as dinv
 
     monkeypatch.setenv("DINV_WINOGRAD", "1")
+    monkeypatch.setenv("DINV_DRUNET_CONV", "wino")
     sd = OD.init_state_dict(2, 2, seed=1)
     model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
     model.load_state_dict(sd)
