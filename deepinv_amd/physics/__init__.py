@@ -5,3 +5,4 @@ from .mri import MRI, MultiCoilMRI, MRIMixin
 from .tomography import Tomography, RampFilter
 from .blur import Blur, BlurFFT, Downsampling
 from . import functional
+from . import generator

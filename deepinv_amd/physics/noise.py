@@ -1,7 +1,7 @@
 """Noise models applied by ``Physics.forward`` only (reference deepinv/physics/noise.py:11-330).
 
-Measurement synthesis happens once per problem, outside the iteration loop
-(forward.py:120), so this stays plain PyTorch on whatever device the measurements live on.
+Gaussian noise on a HIP device is one fused pass (csrc/random.hip: Philox4x32-10 + Box-Muller, y = x + sigma n); on
+other devices (and for the other models) it is the reference's torch expression.
 """
 from __future__ import annotations
 
@@ -55,6 +55,12 @@ class GaussianNoise(NoiseModel):
         if sigma is not None:
             self.sigma = self._as_sigma(sigma).to(self.sigma.device)
         s = self.sigma.to(x.device)
+        if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad) \
+                and (s.numel() == 1 or s.numel() == x.shape[0]):
+            from ..hip import random as hrand
+
+            self.rng_manual_seed(seed)
+            return hrand.gaussian_noise(x, s, self.rng)
         if s.ndim > 0 and s.numel() > 1:
             s = s.reshape(-1, *([1] * (x.ndim - 1)))
         return x + self.randn_like(x, seed=seed) * s

@@ -232,6 +232,24 @@ int dinv_radon_ramp_fft(int32_t n_img, int32_t n_det, int32_t n_angles, int32_t 
                         dinv_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
+/* Measurement synthesis on the device: additive Gaussian noise                */
+/* (deepinv/physics/noise.py:197-330) and Cartesian MRI acceleration masks     */
+/* (deepinv/physics/generator/mri.py:15-384).  Philox4x32-10: element i of a   */
+/* call uses counter offset + i/4 under key `seed`.                            */
+/* ------------------------------------------------------------------------- */
+/* y[i] = x[i] + sigma * N(0,1); sigma = sigma_dev[i / per_sample] when sigma_dev != NULL, else sigma_scalar;
+ * x may be NULL (pure noise). */
+int dinv_gaussian_noise(int64_t n, int64_t per_sample, const float* x, const float* sigma_dev, float sigma_scalar,
+                        uint64_t seed, uint64_t offset, float* y, dinv_stream_t stream);
+/* mask[batch, channels, times, height, width] of k-space columns.  mode 0: per (batch, time) row, n_lines columns
+ * without replacement with probabilities pdf_dev[width] (zero on the centre band [center_lo, center_hi), which is
+ * always sampled); mode 1: equispaced columns round(arange((t + offset_b) % accel, width - 1, accel)) with
+ * offset_b uniform in [0, n_offsets). */
+int dinv_mri_mask_lines(int32_t batch, int32_t channels, int32_t times, int32_t height, int32_t width, int32_t n_lines,
+                        int32_t center_lo, int32_t center_hi, int32_t mode, const float* pdf_dev, double accel,
+                        int32_t n_offsets, uint64_t seed, uint64_t offset, float* mask, dinv_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
 /* Blur / Downsampling: padded true convolution, its exact transpose, and the  */
 /* real<->half-complex 2-D FFT used by BlurFFT                                 */
 /* (deepinv/physics/functional/convolution.py:42-164, 689-758, 837-865;        */

@@ -2,14 +2,17 @@
 320x320): HBM bytes per launch of each conv kernel = TCC_EA0_RDREQ x 64 B x 2 (gfx950 counts a 128-B request of a wide
 coalesced read as one 64-B unit: MI355X_MICROARCH.md, HBM section) + TCC_EA0_WRREQ x 64 B, averaged over its launches.
 usage: python scripts/make_pmc_traffic.py <rdreq dir> <wrreq dir> <commit> > profiles/pmc_traffic.json"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, re, sys
 
 def collect(d, counter):
     tot, n = collections.Counter(), collections.Counter()
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"].startswith(counter):
-                k = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("<")[0].split("(")[0]
+                m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+                if not m:
+                    continue
+                k = m.group(1)
                 tot[k] += float(r["Counter_Value"]); n[k] += 1
     return tot, n
 
