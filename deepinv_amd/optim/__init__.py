@@ -6,5 +6,6 @@ from .optim_iterators import (OptimIterator, fStep, gStep, PGDIteration, HQSIter
 from .fixed_point import FixedPoint
 from .optimizers import BaseOptim, PGD, HQS, optim_builder, create_iterator, BacktrackingConfig
 from .linear import conjugate_gradient, least_squares, least_squares_implicit_backward, dot
+from .linear_solvers import lsqr, bicgstab, minres
 from .dpir import DPIR, get_DPIR_params
 from . import linear

@@ -109,7 +109,8 @@ def _conjugate_gradient_hip(A, b, max_iter, tol, eps, init, verbose, ew=None):
 
 def least_squares(A, AT, y, z=0.0, init=None, gamma=None, parallel_dim=0, AAT=None, ATA=None, solver="CG",
                   max_iter=100, tol=1e-6, **kwargs):
-    r""":math:`\min_x \frac{\gamma}{2}\|Ax-y\|^2 + \frac12\|x-z\|^2` (least_squares.py:15-197); CG only."""
+    r""":math:`\min_x \frac{\gamma}{2}\|Ax-y\|^2 + \frac12\|x-z\|^2` (least_squares.py:15-197); solvers CG, BiCGStab,
+    lsqr, minres."""
     if isinstance(parallel_dim, int):
         parallel_dim = [parallel_dim]
     if gamma is None:
@@ -130,23 +131,33 @@ def least_squares(A, AT, y, z=0.0, init=None, gamma=None, parallel_dim=0, AAT=No
         elif gamma.ndim != Aty.ndim:
             raise ValueError(f"gamma should either be 0D, 1D, or match same number of dimensions as ATy, but got "
                              f"ndims {gamma.ndim} and {Aty.ndim}")
-    if solver != "CG":
-        raise ValueError(f"Solver {solver} is not on the accelerated path (CG only).")
+    from .linear_solvers import bicgstab, lsqr, minres
+
+    if solver == "lsqr":     # rectangular solver on A itself (least_squares.py:122-134)
+        x, _ = lsqr(A, AT, y, x0=z, eta=1 / gamma if gamma_provided else None, max_iter=max_iter, tol=tol,
+                    parallel_dim=parallel_dim, **kwargs)
+        return x
+    if solver not in ("CG", "BiCGStab", "minres"):
+        raise ValueError(f"Solver {solver} not recognized. Choose between 'CG', 'lsqr', 'BiCGStab' and 'minres'.")
     complete = Aty.shape == y.shape
     overcomplete = Aty.numel() < y.numel()
-    if AAT is None:
-        AAT = lambda x: A(AT(x))
-    if ATA is None:
-        ATA = lambda x: AT(A(x))
-    if gamma_provided:
-        b = Aty + 1 / gamma * z
-        H = lambda x: ATA(x) + 1 / gamma * x
-        overcomplete = False
-    elif not overcomplete:
-        H, b = (lambda x: AAT(x)), y
+    if complete and solver in ("BiCGStab", "minres"):     # square system solved directly (least_squares.py:139-141)
+        H, b = (lambda x: A(x)), y
     else:
-        H, b = (lambda x: ATA(x)), Aty
-    x = conjugate_gradient(A=H, b=b, init=init, max_iter=max_iter, tol=tol, parallel_dim=parallel_dim, **kwargs)
+        if AAT is None:
+            AAT = lambda x: A(AT(x))
+        if ATA is None:
+            ATA = lambda x: AT(A(x))
+        if gamma_provided:
+            b = Aty + 1 / gamma * z
+            H = lambda x: ATA(x) + 1 / gamma * x
+            overcomplete = False
+        elif not overcomplete:
+            H, b = (lambda x: AAT(x)), y
+        else:
+            H, b = (lambda x: ATA(x)), Aty
+    run = {"CG": conjugate_gradient, "BiCGStab": bicgstab, "minres": minres}[solver]
+    x = run(A=H, b=b, init=init, max_iter=max_iter, tol=tol, parallel_dim=parallel_dim, **kwargs)
     if not gamma_provided and not overcomplete and not complete:
         x = AT(x)
     return x

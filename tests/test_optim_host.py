@@ -287,3 +287,19 @@ def test_diffpir_schedule_matches_reference_golden():
         assert torch.allclose(sigmas, d["sigmas"], rtol=1e-6) and torch.allclose(rhos, d["rhos"], rtol=1e-6)
         if "reduced" in d:
             assert torch.allclose(s.reduced_alpha_cumprod, d["reduced"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("solver", ["CG", "BiCGStab", "lsqr", "minres"])
+def test_least_squares_solvers_match_reference_golden(solver):
+    """least_squares(solver=...) (least_squares.py:15-197, lsqr.py, bicgstab.py, minres.py) against outputs of the REAL
+    reference on tall / wide / square batched matrix operators, with no, scalar and per-sample gamma."""
+    d = _gold("ls_solvers")
+    for tag in ("tall", "wide", "square"):
+        M, y, z = d[f"{tag}_M"], d[f"{tag}_y"], d[f"{tag}_z"]
+        A = lambda x: torch.einsum("bij,bj->bi", M, x)
+        AT = lambda v: torch.einsum("bij,bi->bj", M, v)
+        for gname, gamma in (("none", None), ("scalar", 0.7), ("batched", torch.tensor([0.3, 1.0, 2.5], dtype=torch.float64))):
+            x = dinv.optim.least_squares(A, AT, y, z=z if gamma is not None else 0.0, init=z if gamma is not None else None,
+                                         gamma=gamma, solver=solver, max_iter=200, tol=1e-10)
+            ref = d[f"{tag}_{solver}_{gname}"]
+            assert torch.allclose(x, ref, rtol=1e-7, atol=1e-9), (tag, solver, gname, float((x - ref).abs().max()))
