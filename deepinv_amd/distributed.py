@@ -82,3 +82,109 @@ def reconstruct_batch_parallel(ctx: BatchParallelContext, model, y_full: torch.T
     n = y_full.shape[0]
     x_local = model(ctx.scatter_batch(y_full), physics, **kwargs)
     return ctx.all_gather_batch(x_local, n)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Operator-parallel distribution: a stack of linear operators A = [A_1; ...; A_n] shared out over the ranks
+# (reference deepinv/distributed/distrib_framework.py:234-732, DistributedStackedLinearPhysics).  The natural instance
+# on the hot path is COIL-parallel MultiCoilMRI: rank r owns a slab of coils, `A` needs no communication at all (each
+# rank produces the k-space of its coils) and `A_adjoint` / `A_adjoint_A` end in ONE image-sized RCCL all-reduce
+# (sum_n conj(S_n) F^H M y_n is a sum over coils).  One huge volume can thus use all 8 GPUs of a node.
+# ----------------------------------------------------------------------------------------------------------------------
+from .physics.forward import LinearPhysics  # noqa: E402
+
+
+class DistributedStackedLinearPhysics(LinearPhysics):
+    """`num_operators` linear operators built by ``factory(index, device, factory_kwargs)``; rank r owns the indices
+    i with i % world_size == r (round robin, distrib_framework.py:194-203).
+
+    * ``A(x, gather=False)`` -> list of this rank's measurements (no communication); ``gather=True`` -> the full list,
+      in operator order, on every rank (one all-gather per operator group; needs equal measurement shapes);
+    * ``A_adjoint(y, reduce_op="sum")``: y = full list (length num_operators) or this rank's local list; local partial
+      sum, then one all-reduce; ``reduce_op=None`` returns the local contribution;
+    * ``A_adjoint_A(x)``: sum_i A_i^T A_i x with one all-reduce (what the PGD / CG loops call)."""
+
+    def __init__(self, ctx: BatchParallelContext, num_operators: int, factory, *, factory_kwargs=None, **kwargs):
+        super().__init__(**kwargs)
+        self.ctx, self.num_operators = ctx, int(num_operators)
+        self.local_indexes = [i for i in range(self.num_operators) if i % ctx.world_size == ctx.rank]
+        self.local_physics = torch.nn.ModuleList([factory(i, ctx.device, factory_kwargs) for i in self.local_indexes])
+        for p in self.local_physics:
+            if not isinstance(p, LinearPhysics):
+                raise ValueError("factory must return LinearPhysics instances.")
+
+    def _local(self, y):
+        """this rank's share of a measurement list (accepts the full list or the local one)"""
+        if len(y) == self.num_operators and self.num_operators != len(self.local_indexes):
+            return [y[i] for i in self.local_indexes]
+        if len(y) != len(self.local_indexes):
+            raise ValueError(f"expected {self.num_operators} (all) or {len(self.local_indexes)} (local) measurements, got {len(y)}")
+        return list(y)
+
+    def _reduce(self, t, reduce_op):
+        if reduce_op is None or self.ctx.world_size == 1:
+            return t
+        if reduce_op != "sum":
+            raise ValueError("reduce_op must be 'sum' or None")
+        t = t.contiguous()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def A(self, x, gather: bool = True, **kwargs):
+        local = [p.A(x, **kwargs) for p in self.local_physics]
+        if not gather or self.ctx.world_size == 1:
+            return local
+        out = [None] * self.num_operators
+        W = self.ctx.world_size
+        for k in range((self.num_operators + W - 1) // W):      # k-th operator of every rank
+            mine = local[k] if k < len(local) else None
+            if mine is None:     # ranks without a k-th operator contribute an empty slot of the common shape
+                ref = local[0] if local else None
+                if ref is None:
+                    raise RuntimeError("a rank without any operator cannot take part in a gathered A()")
+                mine = torch.zeros_like(ref)
+            bufs = [torch.empty_like(mine) for _ in range(W)]
+            dist.all_gather(bufs, mine.contiguous())
+            for r in range(W):
+                i = k * W + r
+                if i < self.num_operators:
+                    out[i] = bufs[r]
+        return out
+
+    def A_adjoint(self, y, reduce_op: str | None = "sum", **kwargs):
+        ys = self._local(y)
+        acc = None
+        for p, yi in zip(self.local_physics, ys):
+            t = p.A_adjoint(yi, **kwargs)
+            acc = t if acc is None else acc + t
+        if acc is None:
+            raise RuntimeError("this rank owns no operator: cannot shape its (zero) contribution")
+        return self._reduce(acc, reduce_op)
+
+    def A_adjoint_A(self, x, reduce_op: str | None = "sum", **kwargs):
+        acc = None
+        for p in self.local_physics:
+            t = p.A_adjoint_A(x, **kwargs)
+            acc = t if acc is None else acc + t
+        return self._reduce(acc, reduce_op)
+
+    def A_vjp(self, x, v, reduce_op: str | None = "sum", **kwargs):
+        return self.A_adjoint(v, reduce_op=reduce_op, **kwargs)
+
+
+def coil_parallel_mri(ctx: BatchParallelContext, mask, coil_maps, img_size, three_d: bool = False, **kwargs):
+    """MultiCoilMRI with its coils dealt out over the ranks (contiguous slabs, so every rank applies its fused
+    expand / FFT / combine kernels to a [1, N/P, ...] map tensor); see DistributedStackedLinearPhysics."""
+    from .physics.mri import MultiCoilMRI
+
+    n = coil_maps.shape[1]
+    q, r = divmod(n, ctx.world_size)
+    bounds = [0]
+    for k in range(ctx.world_size):
+        bounds.append(bounds[-1] + q + (1 if k < r else 0))
+
+    def factory(i, device, _):
+        return MultiCoilMRI(mask=mask, coil_maps=coil_maps[:, bounds[i]:bounds[i + 1]].contiguous(), img_size=img_size,
+                            three_d=three_d, device=device, **kwargs)
+
+    return DistributedStackedLinearPhysics(ctx, ctx.world_size, factory)

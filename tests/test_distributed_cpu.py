@@ -73,3 +73,74 @@ def test_batch_parallel_equals_single_process(n_total):
         rec = torch.from_numpy(rec)
         assert rec.shape == ref.shape
         assert torch.allclose(rec, ref, atol=1e-6)   # every rank holds the full gathered batch
+
+
+def _stack_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import deepinv_amd as dinv
+    from deepinv_amd.distributed import BatchParallelContext, DistributedStackedLinearPhysics
+
+    g = torch.Generator().manual_seed(0)
+    Ms = [torch.randn(5, 4, generator=g) for _ in range(5)]      # 5 operators over 2 ranks: ragged (3 + 2)
+
+    class Mat(dinv.physics.LinearPhysics):
+        def __init__(self, M):
+            super().__init__()
+            self.M = M
+
+        def A(self, x, **k):
+            return x @ self.M.T
+
+        def A_adjoint(self, y, **k):
+            return y @ self.M
+
+    x = torch.randn(3, 4, generator=g)
+    with BatchParallelContext(backend="gloo", device="cpu") as ctx:
+        phys = DistributedStackedLinearPhysics(ctx, 5, lambda i, dev, kw: Mat(Ms[i]))
+        y_local = phys.A(x, gather=False)
+        y_all = phys.A(x, gather=True)
+        aty = phys.A_adjoint(y_all)                 # full list in, all-reduced image out
+        aty2 = phys.A_adjoint(y_local)              # local list in: same result
+        ata = phys.A_adjoint_A(x)
+        part = phys.A_adjoint(y_local, reduce_op=None)
+        # a PGD loop on the distributed operator: L2.grad = A^T A x - A^T y, both all-reduced
+        ident = dinv.optim.PnP(denoiser=lambda x, sigma=None, **k: x)      # implicit prior: no cost on the list y
+        model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=ident, stepsize=0.01, max_iter=10)
+        rec = model(y_local, phys)
+        q.put((rank, [t.numpy() for t in y_all], aty.numpy(), aty2.numpy(), ata.numpy(), part.numpy(), rec.numpy(),
+               phys.local_indexes))
+
+
+def test_operator_parallel_stack_matches_single_process():
+    """DistributedStackedLinearPhysics on 2 gloo ranks (ragged 3 + 2 operators) == the stacked operator in one process:
+    gathered A, all-reduced A^T / A^T A, and a PGD reconstruction through them (distrib_framework.py:387-560)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stack_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(0)
+    Ms = [torch.randn(5, 4, generator=g) for _ in range(5)]
+    x = torch.randn(3, 4, generator=g)
+    ys = [x @ M.T for M in Ms]
+    aty = sum(y @ M for y, M in zip(ys, Ms))
+    rec = aty.clone()
+    for _ in range(10):
+        rec = rec - 0.01 * (sum((rec @ M.T) @ M for M in Ms) - aty)
+    assert results[0][7] == [0, 2, 4] and results[1][7] == [1, 3]
+    parts = []
+    for rank, y_all, a1, a2, ata, part, r, _ in results:
+        for yi, ref in zip(y_all, ys):
+            assert torch.allclose(torch.from_numpy(yi), ref, atol=1e-6)
+        assert torch.allclose(torch.from_numpy(a1), aty, atol=1e-5) and torch.allclose(torch.from_numpy(a2), aty, atol=1e-5)
+        assert torch.allclose(torch.from_numpy(ata), aty, atol=1e-5)
+        assert torch.allclose(torch.from_numpy(r), rec, atol=1e-5)
+        parts.append(torch.from_numpy(part))
+    assert torch.allclose(parts[0] + parts[1], aty, atol=1e-5) and not torch.allclose(parts[0], aty, atol=1e-3)

@@ -135,3 +135,29 @@ def test_parameter_gradients_match_autograd_oracle(dev, mb, sb):
         assert o.shape == r.shape, name
         real = lambda t: torch.view_as_real(t.resolve_conj()) if t.is_complex() else t
         assert rel_err(real(o), real(r)) < 1e-4, name
+
+
+@pytest.mark.parametrize("img,three_d,coils", [((32, 48), False, 5), ((8, 16, 32), True, 4)])
+def test_coil_parallel_partition_sums_to_full_operator(dev, img, three_d, coils):
+    """coil_parallel_mri on two emulated ranks of ONE device (no process group: reduce_op=None and the partial images
+    added by hand) == the full MultiCoilMRI: the coil slabs tile the coil axis and A^T / A^T A are sums over coils."""
+    import deepinv_amd as dinv
+    from deepinv_amd.distributed import BatchParallelContext, coil_parallel_mri
+
+    g = _g(9)
+    x = torch.randn(2, 2, *img, generator=g).to(dev)
+    maps = (torch.randn(1, coils, *img, dtype=torch.complex64, generator=g) / coils ** 0.5).to(dev)
+    mask = (torch.rand(1, 1, *img, generator=g) > 0.5).float().to(dev)
+    full = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, *img), three_d=three_d, device=dev)
+    y_full = full.A(x)
+    ranks = []
+    for r in range(2):
+        ctx = BatchParallelContext(device=dev)
+        ctx.world_size, ctx.rank = 2, r
+        ranks.append(coil_parallel_mri(ctx, mask, maps, (2, *img), three_d=three_d))
+    ys = [p.A(x, gather=False)[0] for p in ranks]
+    assert rel_err(torch.cat(ys, dim=2), y_full) < 1e-6                      # coil slabs, in order
+    aty = sum(p.A_adjoint(y, reduce_op=None) for p, y in zip(ranks, [[y] for y in ys]))
+    assert rel_err(aty, full.A_adjoint(y_full)) < 1e-5
+    ata = sum(p.A_adjoint_A(x, reduce_op=None) for p in ranks)
+    assert rel_err(ata, full.A_adjoint_A(x)) < 1e-5
