@@ -125,10 +125,30 @@ struct TileFft {
         if (ROW) { line = w / K; i = w - line * K; } else { i = w / L; line = w - i * L; }
     }
 
-    template <class LoadF, class EmitF>
+    // LDS_IN: the inputs themselves live in `buf` (natural order, whatever addressing `load` uses): every thread first
+    // pulls ALL its stage-1 inputs into registers, then the workgroup synchronises, and only then are the stage-1
+    // outputs written over the same LDS tile (two transforms back to back on one tile, see mri_cols_normal_kernel).
+    template <bool LDS_IN = false, class LoadF, class EmitF>
     static __device__ __forceinline__ void run(float2* buf, const float2* __restrict__ tw, int lines, int c,
                                                float scale, int tid, LoadF load, EmitF emit) {
         constexpr int R1 = P::R1, R2 = P::R2, M1 = P::M1, M2 = P::M2;
+        float2 vin[LDS_IN ? NS1 : 1][R1];
+        if constexpr (LDS_IN) {
+#pragma unroll
+            for (int slot = 0; slot < NS1; ++slot) {
+                const int w = tid + 256 * slot;
+                int line, u;
+                split(w, P::K1, line, u);
+                if (w >= L * P::K1 || line >= lines) continue;
+#pragma unroll
+                for (int j = 0; j < R1; ++j) {
+                    int n = u + M1 * j + c;
+                    if (n >= N) n -= N;
+                    vin[slot][j] = load(slot, j, line, n);
+                }
+            }
+            __syncthreads();
+        }
         // ---------------- stage 1 : global -> registers -> LDS  (or straight to the output when single-stage)
 #pragma unroll
         for (int slot = 0; slot < NS1; ++slot) {
@@ -139,9 +159,13 @@ struct TileFft {
             float2 v[R1];
 #pragma unroll
             for (int j = 0; j < R1; ++j) {
-                int n = u + M1 * j + c;
-                if (n >= N) n -= N;
-                v[j] = load(slot, j, line, n);
+                if constexpr (LDS_IN) {
+                    v[j] = vin[slot][j];
+                } else {
+                    int n = u + M1 * j + c;
+                    if (n >= N) n -= N;
+                    v[j] = load(slot, j, line, n);
+                }
             }
             Bfly<R1, INV>::run(v);
             if constexpr (P::STAGES == 1) {
@@ -203,7 +227,7 @@ struct TileFft {
 
     // ---- ROW-mode variant with 4 adjacent elements per thread on the global side: every global access is a
     // 16-byte-per-lane vector access (the guide's "vectorize ALWAYS" rule; 4-byte-per-lane streams top out near
-    // 2.7 TB/s on this chip, 16-byte ones reach >5 TB/s).  loadv(line, n0, out[4]) / emitv(line, k0, q, v[4]).
+    // 2.7 TB/s on this chip, 16-byte ones reach >5 TB/s).  loadv(line, n0, out[4]) / emitv(slot, line, k0, q, v[4]).
     template <class LoadV, class EmitV>
     static __device__ __forceinline__ void run_v4(float2* buf, const float2* __restrict__ tw, int lines, int c,
                                                   float scale, int tid, LoadV loadv, EmitV emitv) {
@@ -279,7 +303,7 @@ struct TileFft {
             for (int q = 0; q < RL; ++q) {
                 int k0 = i0 + R1 * Q2N * q + c;
                 if (k0 >= N) k0 -= N;
-                emitv(line, k0, q, o[q]);
+                emitv(slot, line, k0, q, o[q]);
             }
         }
     }
@@ -324,7 +348,7 @@ __global__ __launch_bounds__(256) void fft_rows_static_v4_kernel(Io io, int64_t 
         __syncthreads();
         TF::run_v4(buf, tw, lines, c, scale, tid,
                    [&](int line, int n0, float2 (&out)[4]) { io.load4(ctxs[line], n0, out); },
-                   [&](int line, int k0, int, const float2 (&v)[4]) { io.store4(ctxs[line], k0, v); });
+                   [&](int, int line, int k0, int, const float2 (&v)[4]) { io.store4(ctxs[line], k0, v); });
     }
 }
 

@@ -613,6 +613,145 @@ int launch_cols_combine_inv(const float2* t, const float2* maps, float* x, int64
     return 0;
 }
 
+// ---- normal operator, middle pass: t <- F^H_axis( M^2 . F_axis t ) along the first volume axis, in place, ONE round trip
+// of t: forward transform of an N x L column tile (outputs kept in registers), masked write back into the same LDS
+// tile in natural order, inverse transform out of the tile (TileFft::run<LDS_IN>), store.  y = M F S x is never formed.
+// The mask multiplies each real channel twice, exactly as A followed by A_adjoint does (mri.py:271, :300).
+template <class P, int L>
+__global__ __launch_bounds__(256) void mri_cols_normal_kernel(float2* __restrict__ t, const float* __restrict__ mask,
+                                                              int ncoil, int mask_batch, int64_t Q, int64_t qtiles,
+                                                              int64_t ntiles, const void* table, float scale) {
+    using TF = TileFft<P, false, false, L>;
+    using TI = TileFft<P, true, false, L>;
+    constexpr int N = P::N;
+    __shared__ __attribute__((aligned(16))) float2 buf[(size_t)N * L];
+    const float2* tw = reinterpret_cast<const float2*>(table);
+    const int tid = threadIdx.x;
+    const int c = N / 2;
+    const int line = tid % L;
+    const int64_t vol = (int64_t)N * Q;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p = tile / qtiles;
+        const int64_t q0 = (tile - p * qtiles) * L;
+        const int cols = (int)min((int64_t)L, Q - q0);
+        const int64_t q = q0 + (line < cols ? line : 0);
+        float2* tp = t + p * vol + q;
+        const float* mre = mask ? mask + ((mask_batch > 1 ? p / ncoil : 0) * 2) * vol + q : nullptr;
+        __syncthreads();   // previous tile's inverse transform has left the LDS tile
+        float2 out[TF::NSL][TF::RL];
+        TF::run(buf, tw, cols, c, scale, tid,
+                [&](int, int, int, int n) { return tp[(int64_t)n * Q]; },
+                [&](int slot, int, int k, int qq, float2 v) {
+                    if (mre) {
+                        const float m0 = mre[(int64_t)k * Q], m1 = mre[vol + (int64_t)k * Q];
+                        v.x = m0 * (m0 * v.x);
+                        v.y = m1 * (m1 * v.y);
+                    }
+                    out[slot][qq] = v;
+                });
+        __syncthreads();   // every last-stage read of the tile is done: overwrite it with k-space in natural order
+        {
+            constexpr int Q2N = (P::STAGES == 3) ? P::R2 : 1;
+#pragma unroll
+            for (int slot = 0; slot < TF::NSL; ++slot) {
+                const int w = tid + 256 * slot;
+                const int i = w / L;                 // cols mode: item -> (i, line) with the line fastest
+                if (w >= L * TF::KL || line >= cols) continue;
+#pragma unroll
+                for (int qq = 0; qq < TF::RL; ++qq) {
+                    int k;
+                    if constexpr (P::STAGES == 1) k = qq + c;
+                    else k = (i % P::R1) + P::R1 * (i / P::R1) + P::R1 * Q2N * qq + c;
+                    if (k >= N) k -= N;
+                    buf[k * L + line] = out[slot][qq];
+                }
+            }
+        }
+        __syncthreads();
+        TI::template run<true>(buf, tw, cols, c, scale, tid,
+                               [&](int, int, int, int n) { return buf[n * L + line]; },
+                               [&](int, int, int k, int, float2 v) { tp[(int64_t)k * Q] = v; });
+    }
+}
+
+// ---- the same middle pass along the LAST (contiguous) axis: t <- F^H_W( M^2 . F_W t ) on tiles of L rows; the forward
+// transform emits masked k-space rows into a second LDS tile in natural order, the inverse transform reads them from
+// there.  This is the variant the normal operator uses.
+// Measured at cfg2 (B = 32, 8 coils, 320 x 320; us per pass): expand 52-60 + cols 78 + THIS ~145 + cols^-1 71 + combine 38
+// = 0.389 ms (3-D cfg4 volume pair: 0.493 vs 0.578 ms).  The transforms themselves, not HBM, set the pace of this pass:
+// two of them on one 420 MB round trip take as long as two single-transform passes would.
+// The column variant above needs 171 us for its 420 MB round trip (234 VGPRs) and forces the planar 4-byte rows passes
+// on both ends (116 + 193 us): 0.473 ms in all vs 0.487 ms for dinv_mri_forward + dinv_mri_adjoint.  A first rows
+// variant that kept the forward outputs in registers (one LDS tile, L = 16) ran at 256 VGPRs + 22 AGPRs = one wave per
+// SIMD and took 234 us.
+template <class P, int L>
+__global__ __launch_bounds__(256) void mri_rows_normal_kernel(float2* __restrict__ t, const float* __restrict__ mask,
+                                                              int64_t nlines, int64_t R, int ncoil, int mask_batch,
+                                                              int64_t ntiles, const void* table, float scale) {
+    using TF = TileFft<P, false, true, L>;
+    using TI = TileFft<P, true, true, L>;
+    constexpr int N = P::N;
+    constexpr int KS = N + 4;   // row pitch of the k-space tile: rows start 32 B apart modulo the bank width
+    __shared__ __attribute__((aligned(16))) float2 buf[TF::lds_floats2];
+    __shared__ __attribute__((aligned(16))) float2 ksp[(size_t)L * KS];
+    const float2* tw = reinterpret_cast<const float2*>(table);
+    const int tid = threadIdx.x;
+    const int c = N / 2;
+    const int64_t vol = R * (int64_t)N;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t line0 = tile * L;
+        const int lines = (int)min((int64_t)L, nlines - line0);
+        __syncthreads();   // previous tile's inverse transform has left `buf`
+        TF::run(buf, tw, lines, c, scale, tid,
+                [&](int, int, int line, int n) { return t[(line0 + line) * N + n]; },
+                [&](int, int line, int k, int, float2 v) {
+                    if (mask) {
+                        const int64_t gl = line0 + line;               // (b, n, r) row
+                        const int64_t bn = gl / R, r = gl - bn * R;
+                        const float* m = mask + ((mask_batch > 1 ? bn / ncoil : 0) * 2) * vol + r * N + k;
+                        const float m0 = m[0], m1 = m[vol];
+                        v.x = m0 * (m0 * v.x);
+                        v.y = m1 * (m1 * v.y);
+                    }
+                    ksp[line * KS + k] = v;
+                });
+        __syncthreads();   // masked k-space rows complete; every read of `buf` by the forward transform is done
+        TI::run(buf, tw, lines, c, scale, tid,
+                [&](int, int, int line, int n) { return ksp[line * KS + n]; },
+                [&](int, int line, int k, int, float2 v) { t[(line0 + line) * N + k] = v; });
+    }
+}
+
+// rows per workgroup (two LDS tiles of L rows): measured at 320 x 320: L = 8 0.413 ms, L = 4 0.389 ms, L = 2 0.453 ms for the
+// whole normal operator; the 16-byte-per-lane variant of the transforms (run_v4) was slower here (0.431 ms at L = 8).
+template <int N> struct RowsNormalL { static constexpr int value = N >= 512 ? 4 : (N >= 320 ? 4 : (N >= 256 ? 8 : (N >= 128 ? 16 : 32))); };
+
+template <int N>
+int launch_rows_normal(float2* t, const float* mask, int64_t nlines, int64_t R, int ncoil, int mask_batch, const void* table,
+                       float scale, hipStream_t s) {
+    using P = typename PlanFor<N>::P;
+    constexpr int L = RowsNormalL<N>::value;
+    const int64_t ntiles = ceil_div(nlines, L);
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 4 * kMaxGrid);
+    hipLaunchKernelGGL((mri_rows_normal_kernel<P, L>), dim3(grid), dim3(256), 0, s, t, mask, nlines, R, ncoil, mask_batch,
+                       ntiles, table, scale);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int N>
+int launch_cols_normal(float2* t, const float* mask, int64_t P_, int ncoil, int mask_batch, int64_t Q, const void* table,
+                       float scale, hipStream_t s) {
+    using P = typename PlanFor<N>::P;
+    constexpr int L = ColsL<N>::value;
+    const int64_t qtiles = ceil_div(Q, L), ntiles = P_ * qtiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
+    hipLaunchKernelGGL((mri_cols_normal_kernel<P, L>), dim3(grid), dim3(256), 0, s, t, mask, ncoil, mask_batch, Q, qtiles,
+                       ntiles, table, scale);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
 #define DINV_ALL_STATIC(X) X(16) X(32) X(64) X(128) X(256) X(320) X(512)
 
 bool all_static(const dinv_mri_desc* d) {
@@ -832,4 +971,84 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
                        d->table[nd - 1], 1, 1.0f / sqrtf((float)W));
     DINV_CHECK_LAUNCH();
     return 0;
+}
+
+// A^T A x without the k-space tensor (what L2.grad / CG call every iteration):
+//   rows(W) [x, S -> t] ; (cols(H) in place) ; cols(first axis): F, M^2, F^H in one LDS tile ; (cols(H)^-1) ;
+//   rows(W)^-1 + coil combine [t, S -> out]
+// 2-D: 4 passes over t instead of the 10 of dinv_mri_forward + dinv_mri_adjoint (which also write and re-read y).
+extern "C" int dinv_mri_normal_supported(const dinv_mri_desc* d) { return d && validate(d) == 0 && all_static(d) ? 1 : 0; }
+
+extern "C" int dinv_mri_normal(const dinv_mri_desc* d, const float* x, const float* maps, const float* mask, float* out,
+                               void* workspace, size_t ws_bytes, dinv_stream_t stream) {
+    if (int e = validate(d)) return e;
+    if (d->batch == 0) return 0;
+    DINV_REQUIRE(all_static(d), "dinv_mri_normal needs statically planned sizes (see dinv_mri_normal_supported)");
+    DINV_REQUIRE(x && out && workspace, "null tensor pointer");
+    DINV_REQUIRE(ws_bytes >= dinv_mri_workspace_bytes(d), "workspace too small: %zu < %zu", ws_bytes,
+                 dinv_mri_workspace_bytes(d));
+    DINV_REQUIRE((d->maps_batch != 0) == (maps != nullptr), "maps pointer / maps_batch mismatch");
+    DINV_REQUIRE((d->mask_batch != 0) == (mask != nullptr), "mask pointer / mask_batch mismatch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nd = d->ndim;
+    const int64_t W = d->dims[nd - 1];
+    const int64_t vol = volume(d);
+    const int64_t R = vol / W;
+    float2* t = reinterpret_cast<float2*>(workspace);
+    const int64_t P = (int64_t)d->batch * d->coils;
+    const float2* mp = reinterpret_cast<const float2*>(maps);
+    const float scw = 1.0f / sqrtf((float)W);
+
+    const int64_t N0v = d->dims[0], Q0 = vol / N0v;
+    static const bool cols_order = [] { const char* e = getenv("DINV_MRI_NORMAL_ORDER"); return e && e[0] == 'c'; }();
+    if (!cols_order && vol % 4 == 0 && N0v > 16) {
+        // expand -> cols(first axis) -> (cols(H)) -> rows(W): F, M^2, F^H in one tile -> (cols(H)^-1) -> cols^-1 -> combine
+        const float sc0 = 1.0f / sqrtf((float)N0v);
+        const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
+        hipLaunchKernelGGL((mri_coil_expand_kernel<8>), grid, dim3(256), 0, s, x, mp, t, vol, d->batch, d->coils, d->maps_batch);
+        DINV_CHECK_LAUNCH();
+        C2CIo fio{t, t, 0, 0};
+        if (int e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s)) return e;
+        if (nd == 3)
+            if (int e = launch_cols(fio, P * d->dims[0], W, d->plan[1], d->table[1], 0, 1, 1.0f / sqrtf((float)d->dims[1]), s)) return e;
+        int e = 0;
+        switch ((int)W) {
+#define DINV_CASE(NN) case NN: e = launch_rows_normal<NN>(t, mask, P * R, R, d->coils, d->mask_batch, d->table[nd - 1], scw, s); break;
+            DINV_STATIC_SIZES(DINV_CASE)
+#undef DINV_CASE
+        }
+        if (e) return e;
+        if (nd == 3)
+            if ((e = launch_cols(fio, P * d->dims[0], W, d->plan[1], d->table[1], 1, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
+        if ((e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 1, 1, sc0, s))) return e;
+        hipLaunchKernelGGL((mri_coil_combine_kernel<8>), grid, dim3(256), 0, s, t, mp, out, vol, d->batch, d->coils, d->maps_batch);
+        DINV_CHECK_LAUNCH();
+        return 0;
+    }
+    // column order (DINV_MRI_NORMAL_ORDER=cols, and volumes the streaming expand / combine kernels do not take)
+    RowsCoilLoadIo rio{x, mp, t, d->coils, d->maps_batch, R, W, 0, 0};
+    if (int e = launch_rows(rio, P * R, d->plan[nd - 1], d->table[nd - 1], 0, 1, scw, s)) return e;
+    if (nd == 3) {
+        C2CIo mio{t, t, 0, 0};
+        if (int e = launch_cols(mio, P * d->dims[0], W, d->plan[1], d->table[1], 0, 1, 1.0f / sqrtf((float)d->dims[1]), s)) return e;
+    }
+    const int64_t N0 = d->dims[0];
+    int e = 0;
+    switch (d->dims[0]) {
+#define DINV_CASE(NN) case NN: e = launch_cols_normal<NN>(t, mask, P, d->coils, d->mask_batch, vol / N0, d->table[0], 1.0f / sqrtf((float)N0), s); break;
+        DINV_ALL_STATIC(DINV_CASE)
+#undef DINV_CASE
+    }
+    if (e) return e;
+    if (nd == 3) {
+        C2CIo mio{t, t, 0, 0};
+        if ((e = launch_cols(mio, P * d->dims[0], W, d->plan[1], d->table[1], 1, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
+    }
+    switch ((int)W) {
+#define DINV_CASE(NN) case NN: return launch_combine_static<NN>(t, mp, out, (int64_t)d->batch * R, R, d->coils, d->maps_batch, d->table[nd - 1], scw, s);
+        DINV_STATIC_SIZES(DINV_CASE)
+#undef DINV_CASE
+        default: break;
+    }
+    return fail(2, "unreachable: no static rows plan for %d", (int)W);
 }

@@ -7,6 +7,7 @@ Replaces the ATen sequences of ``MultiCoilMRI.A`` (mri.py:254-272), ``MultiCoilM
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -160,6 +161,56 @@ class _MriAdjoint(torch.autograd.Function):
         if mask is not None and ctx.needs_input_grad[2]:
             gmask = _mask_grad(_forward_raw(g, maps, None, ctx.coil_dim) * y, mask, ctx.coil_dim)
         return gy, gmaps, gmask, None
+
+
+def _normal_raw(x, maps, mask, coil_dim):
+    """A^T A x through ``dinv_mri_normal`` (no k-space tensor); None when the sizes have no static plan."""
+    dev = require_hip(x, maps, mask)
+    x = f32c(x)
+    if x.shape[1] != 2:
+        raise ValueError("x must be of shape (B,2,...,H,W)")
+    B, vol = x.shape[0], tuple(x.shape[2:])
+    maps = _prep_maps(maps, vol, B)
+    mask = _prep_mask(mask, vol, B)
+    N = 1 if maps is None else maps.shape[1]
+    d, keep = _desc(B, N, vol, mask, maps, coil_dim, dev)
+    if not lib().dinv_mri_normal_supported(ctypes.byref(d)):
+        return None
+    out = torch.empty_like(x)
+    ws = torch.empty(lib().dinv_mri_workspace_bytes(ctypes.byref(d)), device=dev, dtype=torch.uint8)
+    check(lib().dinv_mri_normal(ctypes.byref(d), ptr(x), ptr(None if maps is None else torch.view_as_real(maps)),
+                                ptr(mask), ptr(out), ptr(ws), ws.numel(), stream_ptr(dev)))
+    return out
+
+
+class _MriNormal(torch.autograd.Function):
+    """A^T A is self-adjoint: the backward of the fused normal operator is the same kernel chain."""
+
+    @staticmethod
+    def forward(ctx, x, maps, mask, coil_dim):
+        ctx.save_for_backward(maps, mask)
+        ctx.coil_dim = coil_dim
+        return _normal_raw(x, maps, mask, coil_dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        maps, mask = ctx.saved_tensors
+        return _MriNormal.apply(g, maps, mask, ctx.coil_dim), None, None, None
+
+
+def mri_normal(x, coil_maps=None, mask=None, coil_dim=True):
+    """``A^T A x = sum_n conj(S_n) F^H(mask^2 F(S_n x))`` in one kernel chain that never writes k-space.  Falls back to
+    adjoint(forward(x)) for sizes without a static FFT plan, or when the mask / coil maps themselves need gradients."""
+    needs_param_grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in (coil_maps, mask))
+    if not needs_param_grad and os.environ.get("DINV_MRI_NORMAL", "1") != "0":
+        B, vol = x.shape[0], tuple(x.shape[2:])
+        if all(_static_ok(n) for n in vol) and vol[-1] >= 64:
+            return _MriNormal.apply(x, coil_maps, mask, bool(coil_dim))
+    return mri_adjoint(mri_forward(x, coil_maps, mask, coil_dim), coil_maps, mask, coil_dim)
+
+
+def _static_ok(n: int) -> bool:   # sizes with a compile-time plan (csrc/fft_static.hpp: has_static_plan)
+    return n in (16, 32, 64, 128, 256, 320, 512)
 
 
 def mri_forward(x, coil_maps=None, mask=None, coil_dim=True):

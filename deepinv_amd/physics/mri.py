@@ -146,6 +146,12 @@ class MRI(MRIMixin, DecomposablePhysics):
             x = self.crop(x, crop=crop)
         return x
 
+    def A_adjoint_A(self, x: Tensor, mask: Tensor = None, **kwargs) -> Tensor:
+        """``F^H M^2 F x`` without materialising k-space (fused normal operator, csrc/mri.hip: dinv_mri_normal)."""
+        self.update_parameters(mask=mask, **kwargs)
+        self._check_ndim(x, self.three_d)
+        return hmri.mri_normal(x, None, self.mask, coil_dim=False)
+
     def noise(self, x, **kwargs):
         return self.U(self.noise_model(x, **kwargs) * self.mask)
 
@@ -178,6 +184,13 @@ class MultiCoilMRI(MRIMixin, LinearPhysics):
         self.update_parameters(mask=mask, coil_maps=coil_maps, **kwargs)
         self._check_ndim(x, self.three_d)
         return hmri.mri_forward(x, self.coil_maps, self.mask, coil_dim=True)
+
+    def A_adjoint_A(self, x: Tensor, mask: Tensor = None, coil_maps: Tensor = None, **kwargs) -> Tensor:
+        """``sum_n conj(S_n) F^H M^2 F (S_n x)``: what ``L2.grad`` and the CG prox evaluate every iteration, as one
+        kernel chain that never writes the k-space tensor (csrc/mri.hip: dinv_mri_normal)."""
+        self.update_parameters(mask=mask, coil_maps=coil_maps, **kwargs)
+        self._check_ndim(x, self.three_d)
+        return hmri.mri_normal(x, self.coil_maps, self.mask, coil_dim=True)
 
     def noise(self, x, **kwargs) -> Tensor:
         return self.mask[:, :, None] * self.noise_model(x, **kwargs)

@@ -100,6 +100,17 @@ int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const float* maps,
                      const float* mask, float* x, void* workspace, size_t ws_bytes,
                      dinv_stream_t stream);
 
+/* out = A^T A x = sum_n conj(S_n) F^H( M^2 F(S_n x) )   x, out: [B,2,vol] planar.
+ * What L2.grad (deepinv/optim/data_fidelity.py:335-338: A_adjoint(A(x) - y)) and the CG prox
+ * (deepinv/physics/forward.py:794-812, A_adjoint_A) evaluate every iteration; the k-space tensor is
+ * never materialised (forward, mask^2 and inverse transform of the first axis share one LDS tile).
+ * Same workspace as above.  Only for statically planned sizes: query dinv_mri_normal_supported first
+ * (1 = supported); callers fall back to dinv_mri_forward + dinv_mri_adjoint otherwise. */
+int dinv_mri_normal_supported(const dinv_mri_desc* d);
+int dinv_mri_normal(const dinv_mri_desc* d, const float* x, const float* maps,
+                    const float* mask, float* out, void* workspace, size_t ws_bytes,
+                    dinv_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* DRUNet convolutions on the fp32 matrix cores                                */
 /* (deepinv/models/drunet.py:200-210 forward_unet; layers :39-101, 323-434,    */

@@ -40,6 +40,13 @@ def bench_mri(B, coils, img, three_d):
     alg = B * 2 * vol * 4 + B * 2 * coils * vol * 4 + coils * vol * 8 + 2 * vol * 4
     tA = timeit(lambda: phys.A(x))
     tT = timeit(lambda: phys.A_adjoint(y))
+    tN = timeit(lambda: phys.A_adjoint_A(x))
+    tC = timeit(lambda: phys.A_adjoint(phys.A(x)))
+    algN = 2 * B * 2 * vol * 4 + coils * vol * 8 + 2 * vol * 4      # read x, write A^T A x (+ maps, mask once)
+    print(json.dumps({"op": "MultiCoilMRI.A_adjoint_A", "B": B, "coils": coils, "img": img, "ms": tN * 1e3,
+                      "composite_ms": tC * 1e3, "alg_MB": algN / 1e6, "GBps": algN / tN / 1e9,
+                      "t_traffic_floor_MB": 4 * B * coils * vol * 8 / 1e6,
+                      "scratch_GBps": 4 * B * coils * vol * 8 / tN / 1e9}))
     for name, t in (("A", tA), ("A_adjoint", tT)):
         print(json.dumps({"op": f"MultiCoilMRI.{name}", "B": B, "coils": coils, "img": img, "ms": t * 1e3,
                           "alg_MB": alg / 1e6, "GBps": alg / t / 1e9, "frac_hbm_peak": alg / t / HBM_PEAK}))

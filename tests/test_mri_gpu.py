@@ -161,3 +161,45 @@ def test_coil_parallel_partition_sums_to_full_operator(dev, img, three_d, coils)
     assert rel_err(aty, full.A_adjoint(y_full)) < 1e-5
     ata = sum(p.A_adjoint_A(x, reduce_op=None) for p in ranks)
     assert rel_err(ata, full.A_adjoint_A(x)) < 1e-5
+
+
+@pytest.mark.parametrize("img,three_d,coils", [((320, 320), False, 8), ((64, 128), False, 3), ((128, 64), False, 1),
+                                               ((256, 512), False, 2), ((512, 64), False, 2), ((32, 64), False, 2),
+                                               ((16, 64, 128), True, 3), ((16, 32, 64), True, 2), ((32, 128, 64), True, 1),
+                                               ((17, 64), False, 2)])     # last: no static plan -> composite fallback
+@pytest.mark.parametrize("batched", [False, True])
+def test_multicoil_normal_operator(dev, img, three_d, coils, batched):
+    """fused A^T A (dinv_mri_normal: k-space never written) == oracle A^T(A x) and == the two-kernel-chain composite"""
+    import deepinv_amd as dinv
+
+    B = 2
+    g = _g(11)
+    x = torch.randn(B, 2, *img, generator=g)
+    mb = B if batched else 1
+    maps = torch.randn(mb, coils, *img, dtype=torch.complex64, generator=g) / coils ** 0.5
+    mask = torch.rand(mb, 1, *img, generator=g)
+    mask = torch.where(mask > 0.5, mask, torch.zeros_like(mask))      # non-binary weights: M^2 != M
+    phys = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, *img), three_d=three_d, device=dev)
+    out = phys.A_adjoint_A(x.to(dev))
+    ref = O.multicoil_AT(O.multicoil_A(x, maps, mask, three_d), maps, mask, three_d)
+    assert rel_err(out, ref) < TOL
+    assert rel_err(out, phys.A_adjoint(phys.A(x.to(dev)))) < 1e-5
+    # symmetric: <A^T A u, v> == <u, A^T A v>
+    v = torch.randn(B, 2, *img, generator=g).to(dev)
+    a, b = (out * v).sum().item(), (x.to(dev) * phys.A_adjoint_A(v)).sum().item()
+    assert abs(a - b) <= 1e-4 * max(abs(a), abs(b), 1.0)
+
+
+def test_single_coil_normal_operator_and_autograd(dev):
+    import deepinv_amd as dinv
+
+    g = _g(12)
+    img = (64, 128)
+    mask = (torch.rand(*img, generator=g) > 0.6).float()
+    phys = dinv.physics.MRI(mask=mask, img_size=(2, *img), device=dev)
+    x = torch.randn(3, 2, *img, generator=g).to(dev).requires_grad_(True)
+    out = phys.A_adjoint_A(x)
+    assert rel_err(out.detach(), O.mri_AT(O.mri_A(x.detach().cpu(), mask), mask)) < TOL
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    assert rel_err(x.grad, phys.A_adjoint_A(w).detach()) < 1e-6        # self-adjoint: backward is the same chain
