@@ -26,7 +26,10 @@
 // random operands, cdna_hip_programming.md 5); the same loop without staging 0.63 ms, staging without MFMAs 0.40 ms.
 // Variants that were built and measured slower: loads two sub-steps ahead in a second register set (0.89 ms), a
 // three-slot ring with the next sub-step's first operands read before the barrier and sched_barrier-pinned phases
-// (0.89 ms: pinning keeps the split's vector work out of the MFMA blocks of the same wave).
+// (0.89 ms: pinning keeps the split's vector work out of the MFMA blocks of the same wave); persistent workgroups that
+// carry the staging pipeline across (pixel tile, cout tile) items, so that only the accumulator write-back separates
+// two items (47.6 ms per DRUNet forward against 45.3 ms: the bookkeeping in the hot loop costs more than the ~9 us of
+// pipeline fill + write-back per 512-pixel tile that a fit of t = tiles x (F + nsub x 2.0 us) shows).
 #include "drunet_common.hpp"
 
 using namespace dinv;
@@ -34,12 +37,17 @@ using namespace dinv_drunet;
 
 namespace {
 
-constexpr int TP = 512;                 // pixels per workgroup
-constexpr int SEGX = TP + 2;            // staged row segment (one halo pixel on each side)
-constexpr int XUNITS = 2 * 2 * SEGX;    // 16-byte units of a stage's activations: [plane][cblk][SEGX]
+constexpr int TPMAX = 512;              // pixels per workgroup of the widest variant (the geometry is padded for it)
 constexpr int WUNITS = 2 * 3 * 2 * 64;  // ... of its weights: [plane][dx][cblk][co 64]
-constexpr int STAGE = XUNITS + WUNITS;  // 2824 units = 45,184 bytes
 constexpr int NSTAGE = 2;
+// NW waves per workgroup: 8 -> 512 pixels, one workgroup per CU (2 x 45 KB of LDS); 4 -> 256 pixels, TWO workgroups per
+// CU (2 x 29 KB each) whose phases drift apart, so one's pipeline fill / epilogue runs under the other's MFMAs
+template <int NW> struct Tile {
+    static constexpr int TP = NW * 64;
+    static constexpr int SEGX = TP + 2;            // staged row segment (one halo pixel on each side)
+    static constexpr int XUNITS = 2 * 2 * SEGX;    // 16-byte units of a stage's activations: [plane][cblk][SEGX]
+    static constexpr int STAGE = XUNITS + WUNITS;  // NW = 8: 2824 units = 45,184 bytes
+};
 
 struct SArgs {
     Geom g;
@@ -92,11 +100,12 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, cons
 
 struct Staged {   // one sub-step's share of a thread, between its global loads and its LDS writes
     float4 x0a, x0b, x1a, x1b, x2a, x2b;
-    uint4 w0, w1;
+    uint4 w0, w1, w2;
 };
 
-template <bool RELU, int NRES>
-__global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
+template <bool RELU, int NRES, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_bf16s_kernel(SArgs a) {
+    constexpr int TP = Tile<NW>::TP, SEGX = Tile<NW>::SEGX, XUNITS = Tile<NW>::XUNITS, STAGE = Tile<NW>::STAGE;
     DINV_DYN_LDS(uint4, lds);   // [NSTAGE][STAGE]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -121,11 +130,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
     // tid of both channel blocks) and one weight unit; the 4 chunks of the two tail pixels and the remaining 256
     // weight units are LOADED by every thread (clamped, redundant addresses) and only WRITTEN by the threads that own
     // them, so the loads are straight-line code without divergent branches.
-    const int tq = tid & 3;                                  // tail chunk: channel block tq>>1, pixel 512 + (tq&1)
+    const int tq = tid & 3;                                  // tail chunk: channel block tq>>1, pixel TP + (tq&1)
     const int xg0 = tid * 8, xg1 = (int)(a.g.cs * 8) + tid * 8;                      // cs * 16 < 2^31 (launcher)
     const int xg2 = (int)((int64_t)(tq >> 1) * a.g.cs * 8) + (TP + (tq & 1)) * 8;
     const int xl0 = tid, xl1 = SEGX + tid, xl2 = (tq >> 1) * SEGX + TP + (tq & 1);    // + plane * 2 * SEGX
-    const int wu1 = 512 + (tid & 255);
+    const int wu1 = NW == 8 ? 512 + (tid & 255) : 256 + tid;    // NW = 4: three weight units per thread
     const uint4* wsrc0 = a.w + (int64_t)ty * nsub * WUNITS;
     const float* xsrc0 = a.x + (a.g.sl + p0 - 1) * 8;
 
@@ -139,6 +148,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
         const uint4* ws = wsrc0 + (int64_t)t * WUNITS;
         rg.w0 = ws[tid];
         rg.w1 = ws[wu1];
+        if constexpr (NW == 4) rg.w2 = ws[512 + tid];
     };
     auto commit = [&](int t) {   // split + write the registers of sub-step t into its ring slot
         uint4* st = lds + (t % NSTAGE) * STAGE;
@@ -150,7 +160,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
         split8(rg.x2a, rg.x2b, hi, lo);
         if (tid < 4) { st[xl2] = hi; st[2 * SEGX + xl2] = lo; }
         st[XUNITS + tid] = rg.w0;
-        if (tid < 256) st[XUNITS + wu1] = rg.w1;
+        if (NW == 4 || tid < 256) st[XUNITS + wu1] = rg.w1;
+        if constexpr (NW == 4) st[XUNITS + 512 + tid] = rg.w2;
     };
 
     // operand slots of this lane: A = weights (row = cout l31 of m-tile, k half = channel block lhi),
@@ -165,7 +176,9 @@ __global__ __launch_bounds__(512) void conv3x3_bf16s_kernel(SArgs a) {
     for (int t = 0; t < nsub; ++t) {
         // registers hold sub-step t+1 (loaded one iteration ago); its slot was last read in iteration t-1, before
         // the barrier that ended that iteration
-        const bool early = (wv & 4) != 0;   // waves w and w+4 share a SIMD (dispatch order 0,2,1,3): one of each kind per SIMD
+        // waves w and w+4 share a SIMD (dispatch order 0,2,1,3): one of each kind per SIMD; with four waves per
+        // workgroup the SIMD partner belongs to the other resident workgroup, whose phase is unrelated
+        const bool early = NW == 8 && (wv & 4) != 0;
         if (early) {
             if (t + 1 < nsub) commit(t + 1);
             if (t + 2 < nsub) issue(t + 2);
@@ -225,26 +238,38 @@ extern "C" int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const 
     DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0,
                  "bf16-split conv needs cin %% 16 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
     DINV_REQUIRE(!(relu && res1), "relu and residual are not combined in DRUNet");
-    DINV_REQUIRE(g->cs >= g->sl + ceil_div(g->np, TP) * TP + g->wp + HALO, "channel-block stride too small for 512-pixel tiles");
+    DINV_REQUIRE(g->cs >= g->sl + ceil_div(g->np, TPMAX) * TPMAX + g->wp + HALO, "channel-block stride too small for 512-pixel tiles");
     DINV_REQUIRE(g->cs * 16 < ((int64_t)1 << 31), "activation row too long for 32-bit staging offsets");
     SArgs a{make_geom(*g), x, reinterpret_cast<const uint4*>(w_split), y, res1, cin, cout / 8, 0, 0, 0};
-    a.ntiles = (int32_t)ceil_div(g->np, TP);
+    // 256-pixel workgroups (two per CU) by default: measured per DRUNet forward (56 ResBlock convs) 44.1 vs 45.3 ms at
+    // B = 32 and 6.5 vs 7.4 ms at B = 4 (the per-GPU batch of the 8-GPU run); DINV_BF16S_WAVES=8 selects the 512-pixel form
+    const char* env_nw = getenv("DINV_BF16S_WAVES");   // read per call: the emulated CPU tests switch it
+    const int nw = env_nw && atoi(env_nw) == 8 ? 8 : 4;
+    const int tp = nw * 64;
+    a.ntiles = (int32_t)ceil_div(g->np, tp);
     a.ytiles = cout / 64;
     a.tiles_per_xcd = (int32_t)ceil_div(a.ntiles, 8);
-    const dim3 grid((unsigned)(a.tiles_per_xcd * a.ytiles * 8)), block(512);
+    const dim3 grid((unsigned)(a.tiles_per_xcd * a.ytiles * 8)), block((unsigned)tp);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    constexpr size_t lds = (size_t)NSTAGE * STAGE * sizeof(uint4);
-    static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
-#define DINV_S_LAUNCH(R, N)                                                                                       \
+    static_assert((size_t)NSTAGE * Tile<8>::STAGE * sizeof(uint4) <= 160 * 1024, "ring does not fit the LDS");
+    static_assert((size_t)2 * NSTAGE * Tile<4>::STAGE * sizeof(uint4) <= 160 * 1024, "two 4-wave workgroups must fit one CU");
+#define DINV_S_LAUNCH(R, N, W)                                                                                    \
     do {                                                                                                          \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16s_kernel<R, N>),            \
+        constexpr size_t lds = (size_t)NSTAGE * Tile<W>::STAGE * sizeof(uint4);                                   \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16s_kernel<R, N, W>),         \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         if (e_ != hipSuccess) return fail(100 + (int)e_, "hipFuncSetAttribute: %s", hipGetErrorString(e_));       \
-        hipLaunchKernelGGL((conv3x3_bf16s_kernel<R, N>), grid, block, lds, st, a);                                \
+        hipLaunchKernelGGL((conv3x3_bf16s_kernel<R, N, W>), grid, block, lds, st, a);                             \
     } while (0)
-    if (relu) DINV_S_LAUNCH(true, 0);
-    else if (res1) DINV_S_LAUNCH(false, 1);
-    else DINV_S_LAUNCH(false, 0);
+#define DINV_S_LAUNCH_W(R, N)          \
+    do {                               \
+        if (nw == 4) DINV_S_LAUNCH(R, N, 4); \
+        else DINV_S_LAUNCH(R, N, 8);   \
+    } while (0)
+    if (relu) DINV_S_LAUNCH_W(true, 0);
+    else if (res1) DINV_S_LAUNCH_W(false, 1);
+    else DINV_S_LAUNCH_W(false, 0);
+#undef DINV_S_LAUNCH_W
 #undef DINV_S_LAUNCH
     DINV_CHECK_LAUNCH();
     return 0;

@@ -1,0 +1,31 @@
+"""Time the bf16-split ResBlock conv at the four DRUNet levels (B images of 320x320 at level 0).
+Usage: [DINV_BF16S_WAVES=4] python scripts/bench_bf16s.py [B]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepinv_amd.hip import drunet as K  # noqa: E402
+from bench_ops import timeit  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = torch.device("cuda:0")
+tot = 0.0
+for lvl, c in enumerate((64, 128, 256, 512)):
+    H = 320 >> lvl
+    g = K.geom(B, H, H)
+    x, y, r = K.alloc(g, c, dev), K.alloc(g, c, dev), K.alloc(g, c, dev)
+    x.normal_()
+    r.normal_()
+    w = torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5)
+    ws = K.pack_bf16s_weight(w)
+    fl = 2.0 * 9 * c * c * B * H * H
+    t1 = timeit(lambda: K.conv3x3_bf16s(g, x, ws, c, c, y, relu=True), iters=20, warmup=3)
+    t2 = timeit(lambda: K.conv3x3_bf16s(g, x, ws, c, c, y, res1=r), iters=20, warmup=3)
+    n = 8 if lvl == 3 else 16
+    tot += n / 2 * (t1 + t2)
+    print(json.dumps({"lvl": lvl, "B": B, "relu_ms": round(t1 * 1e3, 4), "res_ms": round(t2 * 1e3, 4),
+                      "executed_TF": round(3 * fl / t1 / 1e12, 1), "waves": os.environ.get("DINV_BF16S_WAVES", "8")}))
+print(json.dumps({"resblock_convs_ms_per_drunet": round(tot * 1e3, 2)}))

@@ -50,8 +50,11 @@ def pack(w):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 12, 20, 16, 64, "plain"), (2, 9, 14, 32, 64, "relu"),
-                                                 (1, 17, 33, 32, 128, "res"), (3, 16, 16, 64, 64, "plain")])
-def test_bf16_split_conv_matches_fp64(B, H, W, cin, cout, mode):
+                                                 (1, 17, 33, 32, 128, "res"), (3, 16, 16, 64, 64, "plain"),
+                                                 (4, 40, 52, 16, 128, "res")])
+@pytest.mark.parametrize("waves", [8, 4])      # 512-pixel workgroups / 256-pixel workgroups (two per CU, the default)
+def test_bf16_split_conv_matches_fp64(B, H, W, cin, cout, mode, waves, monkeypatch):
+    monkeypatch.setenv("DINV_BF16S_WAVES", str(waves))
     gen = torch.Generator().manual_seed(H * W + cin)
     x = torch.randn(B, cin, H, W, generator=gen)
     w = torch.randn(cout, cin, 3, 3, generator=gen) / (3.0 * cin ** 0.5)
