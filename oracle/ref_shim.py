@@ -3,11 +3,9 @@ importable inside the build container.
 
 TEST INFRASTRUCTURE ONLY.  Nothing under ``deepinv_amd/`` may import this module.
 It exists so that
-  * ``tests/golden/make_golden.py`` can generate golden input/output vectors from the
-    reference itself (the vectors are committed; the reference cannot travel to the
-    GPU box), and
-  * ``tests/test_oracle_vs_reference.py`` can pin the oracle restatement against the
-    reference whenever ``/root/reference`` is present (skipped otherwise).
+``tests/golden/make_golden*.py`` can generate golden input/output vectors from the
+reference itself (the vectors are committed; the reference cannot travel to the GPU
+box); ``tests/test_oracle_golden.py`` pins the oracle restatement against those vectors.
 
 The reference hard-imports ``torchvision``, ``torchmetrics``, ``h5py`` and ``natsort``
 (deepinv/__init__.py:3, utils/mixins.py:8, ...), none of which is installed here, and
