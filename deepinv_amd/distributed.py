@@ -188,3 +188,117 @@ def coil_parallel_mri(ctx: BatchParallelContext, mask, coil_maps, img_size, thre
                             three_d=three_d, device=device, **kwargs)
 
     return DistributedStackedLinearPhysics(ctx, ctx.world_size, factory)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Tile-parallel processing of one large signal (reference deepinv/distributed/distrib_framework.py:734-934 with the
+# "overlap_tiling" strategy of distributed/strategies.py:292-457): the signal is reflect-padded by the halo radius,
+# cut into equally sized windows (patch + halo on both sides; the last window of an axis is shifted inwards instead of
+# being smaller, so that all windows can ride one batch through the denoiser), the windows are dealt out round robin,
+# every rank runs `processor` on its windows, keeps the inner patch of each result, and ONE all-reduce of the
+# zero-initialised output assembles the signal on every rank.  Every output sample is written by exactly one window.
+# ----------------------------------------------------------------------------------------------------------------------
+class OverlapTiling:
+    def __init__(self, shape, patch_size=256, overlap=32, tiling_dims=None, pad_mode="reflect"):
+        shape = tuple(int(s) for s in shape)
+        if tiling_dims is None:
+            n = len(patch_size) if isinstance(patch_size, (tuple, list)) else 2
+            tiling_dims = tuple(range(len(shape) - n, len(shape)))
+        elif isinstance(tiling_dims, int):
+            tiling_dims = (tiling_dims,)
+        self.dims = tuple(d % len(shape) for d in tiling_dims)
+        as_tuple = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * len(self.dims)  # noqa: E731
+        self.patch, self.halo = list(as_tuple(patch_size)), list(as_tuple(overlap))
+        if len(self.patch) != len(self.dims) or len(self.halo) != len(self.dims):
+            raise ValueError("patch_size / overlap must have one entry per tiled dimension")
+        self.shape, self.pad_mode = shape, pad_mode
+        per_dim = []
+        for i, d in enumerate(self.dims):
+            D = shape[d]
+            if self.patch[i] >= D:            # one window spans the axis: shrink the patch so that a halo remains
+                self.patch[i] = D
+            if self.halo[i] >= D and pad_mode == "reflect":
+                self.halo[i] = max(0, D - 1)  # reflect padding needs halo < size
+            p = self.patch[i]
+            starts = list(range(0, max(D - p, 0) + 1, p))
+            if starts[-1] + p < D:
+                starts.append(D - p)          # shifted last window
+            wins, done = [], 0
+            for s in starts:                  # (window start in the padded axis, first owned sample, end)
+                wins.append((s, max(s, done), s + p))
+                done = s + p
+            per_dim.append(wins)
+        self.windows = []                     # cartesian product, row-major
+        def rec(i, cur):
+            if i == len(per_dim):
+                self.windows.append(tuple(cur))
+                return
+            for w in per_dim[i]:
+                rec(i + 1, cur + [w])
+        rec(0, [])
+
+    def __len__(self):
+        return len(self.windows)
+
+    def pad(self, x):
+        pads = [0] * (2 * x.ndim)
+        for i, d in enumerate(self.dims):
+            pads[2 * (x.ndim - 1 - d)] = pads[2 * (x.ndim - 1 - d) + 1] = self.halo[i]
+        while len(pads) >= 2 and pads[-1] == 0 and pads[-2] == 0:
+            pads = pads[:-2]
+        if not any(pads):
+            return x
+        return torch.nn.functional.pad(x, pads, mode=self.pad_mode)
+
+    def window(self, x_pad, k):
+        idx = [slice(None)] * x_pad.ndim
+        for i, d in enumerate(self.dims):
+            s = self.windows[k][i][0]
+            idx[d] = slice(s, s + self.patch[i] + 2 * self.halo[i])
+        return x_pad[tuple(idx)]
+
+    def place(self, out, k, processed):
+        src, dst = [slice(None)] * out.ndim, [slice(None)] * out.ndim
+        for i, d in enumerate(self.dims):
+            s, own, end = self.windows[k][i]
+            src[d] = slice(self.halo[i] + own - s, self.halo[i] + end - s)
+            dst[d] = slice(own, end)
+        out[tuple(dst)] = processed[tuple(src)]
+
+
+class DistributedProcessing:
+    """``processor`` (a denoiser, a prior's prox, any shape-preserving map with a bounded receptive field) applied to
+    one large signal tile by tile across the ranks; see the block comment above.  ``strategy_kwargs``: ``patch_size``,
+    ``overlap`` (halo radius >= receptive-field radius for exact agreement with untiled processing away from the
+    signal border), ``tiling_dims``, ``pad_mode``.  ``max_batch_size`` bounds the windows per processor call."""
+
+    def __init__(self, ctx: BatchParallelContext, processor, *, strategy: str | None = None, strategy_kwargs=None,
+                 max_batch_size: int | None = None):
+        if strategy not in (None, "overlap_tiling"):
+            raise ValueError("only the 'overlap_tiling' strategy is implemented")
+        self.ctx, self.processor = ctx, processor
+        self.kw = dict(strategy_kwargs or {})
+        self.max_batch_size = max_batch_size
+        self._tiling = None
+        if hasattr(processor, "to"):
+            processor.to(ctx.device)
+
+    def __call__(self, x, *args, gather: bool = True, **kwargs):
+        if self._tiling is None or self._tiling.shape != tuple(x.shape):
+            self._tiling = OverlapTiling(x.shape, **self.kw)
+        T = self._tiling
+        mine = [k for k in range(len(T)) if k % self.ctx.world_size == self.ctx.rank]
+        out = torch.zeros_like(x)
+        if mine:
+            xp = T.pad(x)
+            B = x.shape[0]
+            step = self.max_batch_size or len(mine)
+            for i0 in range(0, len(mine), step):
+                group = mine[i0:i0 + step]
+                batch = torch.cat([T.window(xp, k) for k in group], dim=0)       # windows ride the batch axis
+                res = self.processor(batch, *args, **kwargs)
+                for j, k in enumerate(group):
+                    T.place(out, k, res[j * B:(j + 1) * B])
+        if gather and self.ctx.world_size > 1:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        return out
