@@ -196,6 +196,139 @@ __global__ __launch_bounds__(256) void radon_adj_kernel(RadonGeom g, const float
     }
 }
 
+// =====================================================================================================
+// Fan-beam geometry (fan_beam_grid, deepinv/physics/functional/radon.py:16-52; Radon.forward with fan_beam=True
+// :252-342; Tomography uses the exact adjoint and RampFilter + adjoint for FBP, tomography.py:229-350).
+// Ray (detector d, angle a) samples the G points  R(theta_a) (xm_i, yd_d * sc_i), i = 0..G-1:
+//   xm = linspace(-1,1,G) runs along the central ray, yd = linspace(-1,1,n_det) across the detector, and the stretch
+//   sc_i = 0.5 * L_det * (xm_i + r_src) / (r_src + r_det) grows linearly from the source to the detector.
+// With sample_pos(c, s, xj := xm_i, xi := yd_d * sc_i) the arithmetic is that of the parallel-beam kernels with the
+// roles of the two lattice axes exchanged; the same gather structure applies (first-generation kernels: one thread per
+// ray / per pixel, operands through L1).  sino layout [n_img, n_det, A].
+// =====================================================================================================
+template <int NB>
+__global__ __launch_bounds__(256) void radon_fan_fwd_kernel(RadonGeom g, int n_det, const float* __restrict__ xp,
+                                                            const float* __restrict__ xm, const float* __restrict__ sc,
+                                                            const float* __restrict__ yd, const float2* __restrict__ cs,
+                                                            float* __restrict__ sino) {
+    DINV_DYN_LDS(float, tab);      // xm [G], sc [G]
+    float* xm_s = tab;
+    float* sc_s = tab + g.G;
+    for (int i = threadIdx.x; i < g.G; i += 256) { xm_s[i] = xm[i]; sc_s[i] = sc[i]; }
+    __syncthreads();
+    const int d = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int a = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int grp = blockIdx.z;
+    if (d >= n_det || a >= g.A) return;
+    const float2 t = cs[a];
+    const float c = t.x, s = t.y;
+    const float gm1 = (float)(g.G - 1);
+    const int GP = g.G + 2;
+    const float* img = xp + (int64_t)grp * GP * GP * NB;
+    const float ydd = yd[d];
+    float acc[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc[k] = 0.f;
+    for (int i = 0; i < g.G; ++i) {
+        float ix, iy;
+        sample_pos(c, s, xm_s[i], ydd * sc_s[i], gm1, ix, iy);
+        const float fx = floorf(ix), fy = floorf(iy);
+        // range test in floating point: far-away detector pixels produce coordinates beyond the int range
+        if (!(fx >= -1.0f && fx <= (float)(g.G - 1) && fy >= -1.0f && fy <= (float)(g.G - 1))) continue;
+        const float tx = ix - fx, ty = iy - fy;
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float w00 = (1.0f - tx) * (1.0f - ty), w01 = tx * (1.0f - ty);
+        const float w10 = (1.0f - tx) * ty, w11 = tx * ty;
+        const float* p = img + ((int64_t)(y0 + 1) * GP + (x0 + 1)) * NB;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            acc[k] = fmaf(w00, p[k], acc[k]);
+            acc[k] = fmaf(w01, p[NB + k], acc[k]);
+            acc[k] = fmaf(w10, p[(int64_t)GP * NB + k], acc[k]);
+            acc[k] = fmaf(w11, p[(int64_t)GP * NB + NB + k], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int n = grp * NB + k;
+        if (n < g.n_img) sino[((int64_t)n * n_det + d) * g.A + a] = acc[k] * g.scale;
+    }
+}
+
+// exact adjoint as a gather: one thread = one image pixel of NB images.  For every angle the pixel is rotated back into
+// the fan frame (qx along the central ray, qy across); only the 4 march indices around qx and, for each of them, the
+// detector pixels within the rotated pixel footprint divided by the local stretch can touch it; each candidate is
+// re-evaluated with the forward kernel's coordinate code and its tap weights are selected by integer comparison.
+template <int NB>
+__global__ __launch_bounds__(256) void radon_fan_adj_kernel(RadonGeom g, int n_det, const float* __restrict__ sp,
+                                                            const float* __restrict__ xm, const float* __restrict__ sc,
+                                                            const float* __restrict__ yd, const float2* __restrict__ cs,
+                                                            float* __restrict__ x) {
+    DINV_DYN_LDS(float, tab);      // xm [G], sc [G], yd [n_det]
+    float* xm_s = tab;
+    float* sc_s = tab + g.G;
+    float* yd_s = tab + 2 * g.G;
+    for (int i = threadIdx.x; i < g.G; i += 256) { xm_s[i] = xm[i]; sc_s[i] = sc[i]; }
+    for (int i = threadIdx.x; i < n_det; i += 256) yd_s[i] = yd[i];
+    __syncthreads();
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int grp = blockIdx.z;
+    if (col >= g.W || row >= g.W) return;
+    const int px = col + g.pad, py = row + g.pad;
+    const float gm1 = (float)(g.G - 1), dm1 = (float)(n_det - 1);
+    const float gx = 2.0f * (float)px / gm1 - 1.0f, gy = 2.0f * (float)py / gm1 - 1.0f;   // pixel centre, normalised
+    float acc[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc[k] = 0.f;
+    bool live = true;
+    if (g.circle) {
+        const float ya = 2.0f * (float)col / (float)(g.W - 1) - 1.0f;
+        const float xa = 2.0f * (float)row / (float)(g.W - 1) - 1.0f;
+        live = (xa * xa + ya * ya) <= 1.0f;
+    }
+    if (live) {
+        for (int a = 0; a < g.A; ++a) {
+            const float c = cs[a].x, s = cs[a].y;
+            const float qx = c * gx - s * gy, qy = s * gx + c * gy;          // inverse rotation (candidates only)
+            const int i0 = (int)floorf((qx + 1.0f) * 0.5f * gm1) - 1;
+            const float reach = (fabsf(c) + fabsf(s)) * (2.0f / gm1);        // footprint of the pixel's bilinear support
+            const float* sa = sp + ((int64_t)grp * g.A + a) * n_det * NB;
+            for (int di = 0; di < 4; ++di) {
+                const int i = i0 + di;
+                if (i < 0 || i >= g.G) continue;
+                const float sci = sc_s[i], xmi = xm_s[i];
+                int dlo = 0, dhi = n_det - 1;
+                if (fabsf(sci) > 1e-20f && n_det > 1) {
+                    const float dc = (qy / sci + 1.0f) * 0.5f * dm1;
+                    const float m = reach / fabsf(sci) * 0.5f * dm1 + 1.0f;
+                    const float lo = floorf(dc - m), hi = ceilf(dc + m);
+                    if (!(hi >= 0.0f && lo <= dm1)) continue;
+                    dlo = lo > 0.0f ? (int)lo : 0;
+                    dhi = hi < dm1 ? (int)hi : n_det - 1;
+                }
+                for (int d = dlo; d <= dhi; ++d) {
+                    float ix, iy;
+                    sample_pos(c, s, xmi, yd_s[d] * sci, gm1, ix, iy);
+                    const float fx = floorf(ix), fy = floorf(iy);
+                    const float ex = (float)px - fx, ey = (float)py - fy;   // 0 -> tap weight (1-t), 1 -> t
+                    if (!((ex == 0.0f || ex == 1.0f) && (ey == 0.0f || ey == 1.0f))) continue;
+                    const float tx = ix - fx, ty = iy - fy;
+                    const float w = (ex == 0.0f ? 1.0f - tx : tx) * (ey == 0.0f ? 1.0f - ty : ty);
+                    const float* v = sa + (int64_t)d * NB;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) acc[k] = fmaf(w, v[k], acc[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int n = grp * NB + k;
+        if (n < g.n_img) x[((int64_t)n * g.W + row) * g.W + col] = acc[k] * g.scale;
+    }
+}
+
 // ---- interpolating back-projection (IRadon.forward, radon.py:396-444; used when adjoint_via_backprop=False):
 // reco[y][x] = sum_a bilinear(sino, col = ixtab[a] (~ a), row = ((x*cos - y*sin + 1)/2)(G-1)), zero padding,
 // on the G x G grid, cropped to W x W, optional disc mask.  One thread per output pixel of one image.
@@ -374,6 +507,64 @@ extern "C" int dinv_radon_ramp(int32_t n_img, int32_t n_det, int32_t n_angles, c
     DINV_REQUIRE(n_img <= 65535, "too many sinograms per call");
     hipLaunchKernelGGL(ramp_kernel, dim3((n_angles + 255) / 256, (n_det + RJ - 1) / RJ, n_img), dim3(256),
                        n_det * sizeof(float), reinterpret_cast<hipStream_t>(stream), n_img, n_det, n_angles, sino, out);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t dinv_radon_fan_workspace_bytes(const dinv_radon_desc* d, int32_t n_det, int32_t adjoint) {
+    RadonGeom g;
+    if (!d || n_det < 1 || check_desc(d, &g)) return 0;
+    if (adjoint) return (size_t)g.groups * g.A * n_det * g.NB * sizeof(float);
+    return (size_t)g.groups * (g.G + 2) * (g.G + 2) * g.NB * sizeof(float);
+}
+
+extern "C" int dinv_radon_fan_forward(const dinv_radon_desc* d, int32_t n_det, const float* x, const float* xm,
+                                      const float* sc, const float* yd, const float* cs, float* sino, void* ws,
+                                      size_t ws_bytes, dinv_stream_t stream) {
+    RadonGeom g;
+    if (int e = check_desc(d, &g)) return e;
+    DINV_REQUIRE(n_det >= 1, "bad detector count %d", n_det);
+    if (g.n_img == 0) return 0;
+    DINV_REQUIRE(x && xm && sc && yd && cs && sino && ws, "null pointer");
+    DINV_REQUIRE(ws_bytes >= dinv_radon_fan_workspace_bytes(d, n_det, 0), "workspace too small");
+    DINV_REQUIRE((size_t)2 * g.G * sizeof(float) <= 64 * 1024, "grid too large for the LDS tables");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* xp = reinterpret_cast<float*>(ws);
+    const float2* cs2 = reinterpret_cast<const float2*>(cs);
+    const int64_t npk = (int64_t)g.groups * (g.G + 2) * (g.G + 2);
+    const unsigned pk_blocks = (unsigned)std::min<int64_t>(ceil_div(npk, 256), 65535);
+    const dim3 grid((n_det + 63) / 64, (g.A + 3) / 4, g.groups);
+    DINV_NB_DISPATCH(g.NB, {
+        hipLaunchKernelGGL(radon_pack_image<NB>, dim3(pk_blocks), dim3(256), 0, s, g, x, xp);
+        hipLaunchKernelGGL(radon_fan_fwd_kernel<NB>, grid, dim3(256), 2 * g.G * sizeof(float), s, g, n_det, xp, xm, sc, yd, cs2, sino);
+    });
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_radon_fan_adjoint(const dinv_radon_desc* d, int32_t n_det, const float* sino, const float* xm,
+                                      const float* sc, const float* yd, const float* cs, float* x, void* ws,
+                                      size_t ws_bytes, dinv_stream_t stream) {
+    RadonGeom g;
+    if (int e = check_desc(d, &g)) return e;
+    DINV_REQUIRE(n_det >= 1, "bad detector count %d", n_det);
+    if (g.n_img == 0) return 0;
+    DINV_REQUIRE(x && xm && sc && yd && cs && sino && ws, "null pointer");
+    DINV_REQUIRE(ws_bytes >= dinv_radon_fan_workspace_bytes(d, n_det, 1), "workspace too small");
+    const size_t lds = (size_t)(2 * g.G + n_det) * sizeof(float);
+    DINV_REQUIRE(lds <= 64 * 1024, "grid / detector too large for the LDS tables (%zu B)", lds);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* sp = reinterpret_cast<float*>(ws);
+    const float2* cs2 = reinterpret_cast<const float2*>(cs);
+    RadonGeom gs = g;
+    gs.G = n_det;   // radon_pack_sino: [n_img, n_det, A] -> [groups][A][n_det][NB]
+    const int64_t npk = (int64_t)g.groups * g.A * n_det;
+    const unsigned pk_blocks = (unsigned)std::min<int64_t>(ceil_div(npk, 256), 65535);
+    const dim3 grid((g.W + 63) / 64, (g.W + 3) / 4, g.groups);
+    DINV_NB_DISPATCH(g.NB, {
+        hipLaunchKernelGGL(radon_pack_sino<NB>, dim3(pk_blocks), dim3(256), 0, s, gs, sino, sp);
+        hipLaunchKernelGGL(radon_fan_adj_kernel<NB>, grid, dim3(256), lds, s, g, n_det, sp, xm, sc, yd, cs2, x);
+    });
     DINV_CHECK_LAUNCH();
     return 0;
 }

@@ -53,6 +53,10 @@ def _l():
         l.dinv_radon_ramp_padded_size.argtypes = [i32]
         l.dinv_radon_ramp_filter_init.argtypes = [i32, vp, vp]
         l.dinv_radon_ramp_fft.argtypes = [i32, i32, i32, i32, F, vp, vp, vp, vp, vp]
+        l.dinv_radon_fan_workspace_bytes.restype = sz
+        l.dinv_radon_fan_workspace_bytes.argtypes = [D, i32, i32]
+        l.dinv_radon_fan_forward.argtypes = [D, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        l.dinv_radon_fan_adjoint.argtypes = [D, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         _declared = True
     return l
 
@@ -211,6 +215,99 @@ def radon_forward(x, geo, norm=None):
 
 def radon_adjoint(y, geo, norm=None):
     return _RadonAdj.apply(y, geo, norm)
+
+
+# --------------------------------------------------------------------------- fan-beam geometry
+FAN_DEFAULTS = {"source_radius": 57.5, "detector_radius": 57.5, "n_detector_pixels": 258, "detector_spacing": 0.077}
+
+
+def fan_tables(grid: int, width: int, fan_parameters=None):
+    """Host tables of the fan-beam sampling lattice (fan_beam_grid, functional/radon.py:16-52; defaults of
+    Radon.__init__ :224-240): xm [G] runs along the central ray, yd [n_det] across the detector, sc [G] is the stretch of
+    the detector axis at march position xm (it grows linearly from the source to the detector).  Pure torch, CPU."""
+    fp = dict(fan_parameters or {})
+    fp.setdefault("pixel_spacing", 0.5 / width)
+    for k, v in FAN_DEFAULTS.items():
+        fp.setdefault(k, v)
+    n_det = int(fp["n_detector_pixels"])
+    if n_det < 2:
+        raise ValueError("fan-beam geometry needs at least 2 detector pixels")
+    unit = 2.0 / (grid * fp["pixel_spacing"])               # physical length -> normalised [-1, 1] image coordinates
+    r_src, r_det = fp["source_radius"] * unit, fp["detector_radius"] * unit
+    det_len = fp["detector_spacing"] * unit * (n_det - 1)
+    xm = torch.linspace(-1, 1, grid)
+    yd = torch.linspace(-1, 1, n_det)
+    sc = 0.5 * det_len * (xm + r_src) / (r_src + r_det)
+    return fp, xm.contiguous(), sc.contiguous(), yd.contiguous()
+
+
+class FanGeometry(RadonGeometry):
+    """RadonGeometry (padding, angle table) plus the fan-beam lattice tables; no tiled plan (gather kernels)."""
+
+    def __init__(self, angles_deg, width, circle, device, fan_parameters=None):
+        super().__init__(angles_deg, width, circle, "cpu")      # host part only: no window plan for this geometry
+        self.fan_parameters, xm, sc, yd = fan_tables(self.G, self.W, fan_parameters)
+        self.n_det = int(yd.numel())
+        self.device = torch.device(device)
+        self.cs, self.xn = self.cs.to(device), self.xn.to(device)
+        self.xm, self.sc, self.yd = xm.to(device), sc.to(device), yd.to(device)
+
+
+def _fan_fwd(x, geo: FanGeometry, norm):
+    dev = require_hip(x, geo.xm)
+    x = f32c(x)
+    B, C = x.shape[:2]
+    sino = torch.empty((B, C, geo.n_det, geo.A), device=dev, dtype=torch.float32)
+    d = geo.desc(B * C, 1.0)
+    ws = torch.empty(_l().dinv_radon_fan_workspace_bytes(ctypes.byref(d), geo.n_det, 0), device=dev, dtype=torch.uint8)
+    check(_l().dinv_radon_fan_forward(ctypes.byref(d), geo.n_det, ptr(x), ptr(geo.xm), ptr(geo.sc), ptr(geo.yd), ptr(geo.cs),
+                                      ptr(sino), ptr(ws), ws.numel(), stream_ptr(dev)))
+    return sino if norm is None else sino.div_(norm)
+
+
+def _fan_adj(y, geo: FanGeometry, norm):
+    dev = require_hip(y, geo.xm)
+    y = f32c(y)
+    B, C, N, A = y.shape
+    if N != geo.n_det or A != geo.A:
+        raise ValueError(f"sinogram of shape {tuple(y.shape)} does not match the operator ({geo.n_det} detector pixels, "
+                         f"{geo.A} angles)")
+    x = torch.empty((B, C, geo.W, geo.W), device=dev, dtype=torch.float32)
+    d = geo.desc(B * C, 1.0)
+    ws = torch.empty(_l().dinv_radon_fan_workspace_bytes(ctypes.byref(d), geo.n_det, 1), device=dev, dtype=torch.uint8)
+    check(_l().dinv_radon_fan_adjoint(ctypes.byref(d), geo.n_det, ptr(y), ptr(geo.xm), ptr(geo.sc), ptr(geo.yd), ptr(geo.cs),
+                                      ptr(x), ptr(ws), ws.numel(), stream_ptr(dev)))
+    return x if norm is None else x.div_(norm)
+
+
+class _FanFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, geo, norm):
+        ctx.geo, ctx.norm = geo, norm
+        return _fan_fwd(x, geo, norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _FanAdj.apply(g, ctx.geo, ctx.norm), None, None
+
+
+class _FanAdj(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, geo, norm):
+        ctx.geo, ctx.norm = geo, norm
+        return _fan_adj(y, geo, norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _FanFwd.apply(g, ctx.geo, ctx.norm), None, None
+
+
+def fan_forward(x, geo: FanGeometry, norm=None):
+    return _FanFwd.apply(x, geo, norm)
+
+
+def fan_adjoint(y, geo: FanGeometry, norm=None):
+    return _FanAdj.apply(y, geo, norm)
 
 
 # --------------------------------------------------------------------------- ramp filter

@@ -3,7 +3,9 @@
 Differences from the reference, all internal: no precomputed sampling grids (3 GB at 512/720 angles),
 the exact adjoint is a deterministic gather kernel instead of an autograd replay
 (``adjoint_via_backprop=True`` keeps its meaning: *exact* adjoint), the ramp filter is the reference's zero-padded
-rFFT product done in one LDS-resident kernel, and the operator norm of ``normalize=True`` stays on the device.  Fan-beam geometry is out of scope.
+rFFT product done in one LDS-resident kernel, and the operator norm of ``normalize=True`` stays on the device.
+``fan_beam=True`` (fan_beam_grid, functional/radon.py:16-52) runs on gather kernels with the same exact-adjoint
+construction; as in the reference it always uses the exact adjoint and ``RampFilter`` + adjoint for FBP.
 """
 from __future__ import annotations
 
@@ -34,8 +36,6 @@ class Tomography(LinearPhysics):
                  fbp_interpolate_boundary=False, normalize=None, fan_beam=False, fan_parameters=None,
                  device=torch.device("cpu"), dtype=torch.float, **kwargs):
         super().__init__(device=device, **kwargs)
-        if fan_beam:
-            raise NotImplementedError("fan-beam geometry is not on the accelerated path")
         if isinstance(angles, int):
             angles = torch.linspace(0, 180, steps=angles + 1, device=device)[:-1].to(device)
         elif isinstance(angles, (list, tuple, ndarray)):
@@ -43,7 +43,8 @@ class Tomography(LinearPhysics):
         elif not isinstance(angles, torch.Tensor):
             raise ValueError(f"angles must be int, float, iterable or Tensor, but got {type(angles)}")
         self.register_buffer("angles", angles)
-        self.fan_beam = False
+        self.fan_beam = bool(fan_beam)
+        self.fan_parameters = dict(fan_parameters) if fan_parameters is not None else None
         self.adjoint_via_backprop = adjoint_via_backprop
         if circle and fbp_interpolate_boundary:
             warn("The argument fbp_interpolate_boundary=True is not applicable if circle=True. The value "
@@ -78,7 +79,10 @@ class Tomography(LinearPhysics):
         ver = None if a.is_inference() else a._version
         key = (torch.device(device), a.data_ptr(), ver, a.numel())
         if self._geo is None or self._geo_key != key:
-            self._geo = hr.RadonGeometry(a, self.img_width, self.circle, device)
+            if self.fan_beam:
+                self._geo = hr.FanGeometry(a, self.img_width, self.circle, device, self.fan_parameters)
+            else:
+                self._geo = hr.RadonGeometry(a, self.img_width, self.circle, device)
             self._geo_key = key
         return self._geo
 
@@ -109,11 +113,15 @@ class Tomography(LinearPhysics):
         if not x.shape[-2:] == (self.img_width, self.img_width):
             raise ValueError(f"Input image size {x.shape[-2:]} does not match the operator image size "
                              f"{(self.img_width, self.img_width)}.")
+        if self.fan_beam:
+            return hr.fan_forward(x, self._geometry(x.device), self._norm())
         if self.adjoint_via_backprop:
             return hr.radon_forward(x, self._geometry(x.device), self._norm())
         return hr.apply_radon(x, self._geometry(x.device), self._scale_host(), False)   # ApplyRadon (radon.py:493-531)
 
     def A_adjoint(self, y, **kwargs):
+        if self.fan_beam:
+            return hr.fan_adjoint(y, self._geometry(y.device), self._norm())
         if self.adjoint_via_backprop:
             return hr.radon_adjoint(y, self._geometry(y.device), self._norm())
         # ApplyRadon(adjoint=True) = iradon(y, filtering=False) / pi * 2A = plain interpolated sum; / operator_norm
@@ -121,7 +129,7 @@ class Tomography(LinearPhysics):
 
     def fbp(self, y, **kwargs):
         """filtered back-projection (tomography.py:258-293)"""
-        if not self.adjoint_via_backprop:
+        if not self.adjoint_via_backprop and not self.fan_beam:
             out = hr.apply_radon(self.filter(y), self._geometry(y.device), 1.0, True) * torch.pi / (2 * self.angles.numel())
             if self.normalize:
                 out = out * self.operator_norm

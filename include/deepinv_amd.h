@@ -210,6 +210,20 @@ int dinv_radon_backproject(const dinv_radon_desc* d, const float* sino, const fl
 int dinv_radon_ramp(int32_t n_img, int32_t n_det, int32_t n_angles, const float* sino, float* out,
                     dinv_stream_t stream);
 
+/* ---- fan-beam geometry (fan_beam_grid, functional/radon.py:16-52; Radon(fan_beam=True) :205-342; Tomography with
+ * fan_beam=True uses the exact adjoint and RampFilter + adjoint for FBP, tomography.py:229-350).
+ * sino:[n_img,n_det,A].  Host tables, all fp32, built as the reference builds its grid: xm:[G] = linspace(-1,1,G)
+ * (march along the central ray), yd:[n_det] = linspace(-1,1,n_det), sc:[G] = 0.5*L_det*(xm+r_src)/(r_src+r_det) with
+ * the radii / detector length scaled by 2/(G*pixel_spacing); cs as above.  d->grid is the padded image size G. */
+size_t dinv_radon_fan_workspace_bytes(const dinv_radon_desc* d, int32_t n_det, int32_t adjoint);
+int dinv_radon_fan_forward(const dinv_radon_desc* d, int32_t n_det, const float* x, const float* xm,
+                           const float* sc, const float* yd, const float* cs, float* sino, void* ws,
+                           size_t ws_bytes, dinv_stream_t stream);
+/* exact transpose of dinv_radon_fan_forward (deterministic gather): sino:[n_img,n_det,A] -> x:[n_img,W,W] */
+int dinv_radon_fan_adjoint(const dinv_radon_desc* d, int32_t n_det, const float* sino, const float* xm,
+                           const float* sc, const float* yd, const float* cs, float* x, void* ws,
+                           size_t ws_bytes, dinv_stream_t stream);
+
 /* ---- LDS-tiled kernels (csrc/radon_tiled.hip): same operators, same arithmetic, operands staged in LDS.
  * The plan is host-built once per (angles, grid): angle chunks by marching class/direction and the window
  * column range of every (chunk, 64-ray block, 16-row band).  `fits` == 0 (irregular angle lists whose chunks

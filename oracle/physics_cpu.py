@@ -210,6 +210,71 @@ def tomography_fbp(y, angles_deg, W, operator_norm=None, circle=False):
         out = out * operator_norm ** 2
     return out
 
+
+FAN_DEFAULTS = {"source_radius": 57.5, "detector_radius": 57.5, "n_detector_pixels": 258, "detector_spacing": 0.077}
+
+
+def fan_parameters_filled(W, fan_parameters=None):
+    """defaults of Radon.__init__ (radon.py:224-240): pixel_spacing defaults to 0.5 / in_size"""
+    fp = dict(fan_parameters or {})
+    fp.setdefault("pixel_spacing", 0.5 / W)
+    for k, v in FAN_DEFAULTS.items():
+        fp.setdefault(k, v)
+    return fp
+
+
+def fan_grid(theta_rad, grid_size, fp):
+    """fan_beam_grid (radon.py:16-52): [1, G (march), n_det, 2]; march coordinate x_i = linspace(-1,1,G)[i], detector
+    coordinate linspace(-1,1,n_det)[d] stretched by a factor that grows linearly along the march, then rotated"""
+    k = 2.0 / (grid_size * fp["pixel_spacing"])
+    n_det = fp["n_detector_pixels"]
+    src, det = fp["source_radius"] * k, fp["detector_radius"] * k
+    length = fp["detector_spacing"] * k * (n_det - 1)
+    eye = torch.tensor([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]])
+    base = F.affine_grid(eye, torch.Size([1, 1, n_det, grid_size]), align_corners=True)
+    xs = base[0, 0, :, 0]
+    base[:, :, :, 1] *= (0.5 * length * (xs + src) / (src + det))[None, None, :]
+    rot = torch.tensor([[theta_rad.cos(), theta_rad.sin()], [-theta_rad.sin(), theta_rad.cos()]])
+    pts = base.reshape(-1, 2) @ rot.T
+    return pts.reshape(1, n_det, grid_size, 2).transpose(1, 2)
+
+
+def radon_fan_forward(x, angles_deg, fan_parameters=None, circle=False):
+    """Radon.forward with fan_beam=True (radon.py:252-342): x [N,C,W,W] -> [N,C,n_det,A]"""
+    N, C, W, _ = x.shape
+    fp = fan_parameters_filled(W, fan_parameters)
+    if not circle:
+        pb, pa = radon_pad(W)
+        x = F.pad(x, (pb, pa, pb, pa))
+    else:
+        yax = 2 * torch.arange(W, dtype=torch.float)[None, :].expand(W, -1)[None, None] / (W - 1) - 1.0
+        x = x * ((yax.transpose(-2, -1) ** 2 + yax ** 2 <= 1).to(torch.float))
+    G = x.shape[-1]
+    out = torch.zeros(N, C, fp["n_detector_pixels"], len(angles_deg), dtype=x.dtype)
+    for i, theta in enumerate(angles_deg):
+        grid = fan_grid(_deg2rad(theta), G, fp)
+        out[..., i] = F.grid_sample(x, grid.repeat(N, 1, 1, 1), align_corners=True, mode="bilinear").sum(2)
+    return out
+
+
+def radon_fan_adjoint(y, angles_deg, W, fan_parameters=None, circle=False):
+    """exact adjoint by the vector-Jacobian product (tomography.py:311-341 with fan_beam=True)"""
+    N, C = y.shape[:2]
+    x = torch.ones(N, C, W, W, requires_grad=True)
+    _, vjp = torch.func.vjp(lambda v: radon_fan_forward(v, angles_deg, fan_parameters, circle), x)
+    return vjp(y)[0]
+
+
+def tomography_fan_fbp(y, angles_deg, W, fan_parameters=None, operator_norm=None, circle=False):
+    """Tomography.fbp with fan_beam=True (tomography.py:270-279): ramp filter, exact adjoint, pi / (2A) (, norm^2)"""
+    out = radon_fan_adjoint(ramp_filter(y), angles_deg, W, fan_parameters, circle)
+    if operator_norm is not None:
+        out = out / operator_norm
+    out = out * torch.pi / (2 * len(angles_deg))
+    if operator_norm is not None:
+        out = out * operator_norm ** 2
+    return out
+
 # --------------------------------------------------------------------------------------
 # Blur / BlurFFT / Downsampling
 # (deepinv/physics/functional/convolution.py:42-164, 790-865; deepinv/physics/blur.py:255-363, 639-690)

@@ -154,3 +154,41 @@ def ramp_fft(y):
     out = torch.full_like(y, float("nan"))
     check(l.dinv_radon_ramp_fft(B * C, N, A, P, ctypes.byref(plan), p(table), p(filt), p(y), p(out), None))
     return out
+
+
+class FanGeom(RadonGeom):
+    """fan-beam tables from the product's own host code (deepinv_amd.hip.radon.fan_tables: pure torch)"""
+
+    def __init__(self, angles_deg, width, circle, fan_parameters=None):
+        super().__init__(angles_deg, width, circle)
+        import sys
+        sys.path.insert(0, os.path.dirname(HERE))
+        from deepinv_amd.hip.radon import fan_tables
+        self.fp, self.xm, self.sc, self.yd = fan_tables(self.G, self.W, fan_parameters)
+        self.n_det = int(self.yd.numel())
+
+
+def radon_fan_forward(x, geo):
+    l = lib()
+    l.dinv_radon_fan_workspace_bytes.restype = ctypes.c_size_t
+    B, C, W, _ = x.shape
+    x = x.contiguous().float()
+    d = geo.desc(B * C)
+    sino = torch.full((B, C, geo.n_det, geo.A), float("nan"))
+    ws = np.zeros(l.dinv_radon_fan_workspace_bytes(ctypes.byref(d), geo.n_det, 0), np.uint8)
+    check(l.dinv_radon_fan_forward(ctypes.byref(d), geo.n_det, p(x), p(geo.xm), p(geo.sc), p(geo.yd), p(geo.cs), p(sino), p(ws),
+                                   ctypes.c_size_t(ws.size), None))
+    return sino
+
+
+def radon_fan_adjoint(y, geo):
+    l = lib()
+    l.dinv_radon_fan_workspace_bytes.restype = ctypes.c_size_t
+    B, C, N, A = y.shape
+    y = y.contiguous().float()
+    d = geo.desc(B * C)
+    x = torch.full((B, C, geo.W, geo.W), float("nan"))
+    ws = np.zeros(l.dinv_radon_fan_workspace_bytes(ctypes.byref(d), geo.n_det, 1), np.uint8)
+    check(l.dinv_radon_fan_adjoint(ctypes.byref(d), geo.n_det, p(y), p(geo.xm), p(geo.sc), p(geo.yd), p(geo.cs), p(x), p(ws),
+                                   ctypes.c_size_t(ws.size), None))
+    return x

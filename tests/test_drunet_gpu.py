@@ -231,8 +231,9 @@ def test_drunet_bf16s_matches_oracle(dev, monkeypatch):
 
 def test_tile_parallel_drunet_single_rank(dev):
     """DistributedProcessing (overlap tiling) around the HIP DRUNet on one rank: the four 96x96 windows of a 128x128 image
-    ride ONE denoiser call as a batch, the result is assembled without gaps, and it agrees with the untiled denoiser up
-    to what the 16-pixel halo cannot see of DRUNet's receptive field (a few 1e-3 with the random-init weights)"""
+    ride ONE denoiser call as a batch and the assembled result equals denoising every reflect-padded window on its own
+    and pasting its inner 64x64 patch (what the halo cannot see of DRUNet's receptive field is NOT tested here: with
+    random-init weights a 16-pixel halo leaves ~10 % on the seams)"""
     import deepinv_amd as dinv
     from deepinv_amd.distributed import BatchParallelContext, DistributedProcessing
 
@@ -249,9 +250,11 @@ def test_tile_parallel_drunet_single_rank(dev):
     proc = DistributedProcessing(ctx, denoiser, strategy_kwargs={"patch_size": 64, "overlap": 16})
     with torch.no_grad():
         y = proc(x, 0.05)
-        ref = model(x, 0.05)
+        xp = torch.nn.functional.pad(x, (16, 16, 16, 16), mode="reflect")
+        ref = torch.empty_like(x)
+        for r in (0, 64):
+            for c in (0, 64):
+                ref[:, :, r:r + 64, c:c + 64] = model(xp[:, :, r:r + 96, c:c + 96].contiguous(), 0.05)[:, :, 16:80, 16:80]
     assert calls == [(4, 2, 96, 96)]
     assert y.shape == x.shape and torch.isfinite(y).all()
-    assert rel_err(y, ref) < 2e-2
-    inner = (slice(None), slice(None), slice(24, 40), slice(24, 40))      # centre of the first tile: far from every seam
-    assert rel_err(y[inner], ref[inner]) < 5e-3
+    assert rel_err(y, ref) < 1e-5

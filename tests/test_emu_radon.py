@@ -120,3 +120,35 @@ def test_plan_covers_every_tap_at_config3_geometry():
                 assert np.all(band[ok] < plan.n_bands)
                 assert np.all((u0 >= wx0)[ok] & (u0 + 1 <= wx0 + ww - 1)[ok])
                 assert np.all(ww[ok] <= plan.win_w)
+
+
+FAN_A = {"pixel_spacing": 0.1, "source_radius": 6.0, "detector_radius": 6.0, "n_detector_pixels": 20, "detector_spacing": 0.34}
+FAN_CASES = [
+    # W, angles, n_img, circle, fan parameters (None: the reference's defaults, 258 detector pixels that mostly miss)
+    (16, torch.linspace(0, 360, 11)[:-1], 2, False, FAN_A),
+    (16, torch.linspace(0, 360, 11)[:-1], 2, True, FAN_A),
+    (16, torch.linspace(0, 180, 7)[:-1], 2, False, None),
+    (31, torch.tensor([-20., 33., 91., 180., 271.5]), 3, False,
+     {"pixel_spacing": 0.05, "source_radius": 3.0, "detector_radius": 5.0, "n_detector_pixels": 47, "detector_spacing": 0.11}),
+    (24, torch.linspace(0, 360, 9)[:-1], 9, True,                     # detector finer than the pixels: many d per pixel
+     {"pixel_spacing": 0.1, "source_radius": 8.0, "detector_radius": 2.0, "n_detector_pixels": 150, "detector_spacing": 0.03}),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FAN_CASES)))
+def test_fan_beam_forward_adjoint_match_oracle(case):
+    """fan-beam kernels of radon.hip (fan_beam_grid, radon.py:16-52) on the host emulation vs the CPU oracle; the adjoint
+    is the exact transpose (dot test) although the detector-candidate window is only a bound"""
+    W, ang, B, circle, fan = FAN_CASES[case]
+    geo = E.FanGeom(ang, W, circle, fan)
+    g = torch.Generator().manual_seed(100 + case)
+    x = torch.rand(B, 1, W, W, generator=g)
+    y = E.radon_fan_forward(x, geo)
+    assert not torch.isnan(y).any() and y.shape == (B, 1, geo.n_det, len(ang))
+    y_ref = O.radon_fan_forward(x, ang, fan, circle)
+    assert rel(y, y_ref) < 2e-6
+    v = torch.randn(y.shape, generator=g)
+    xa = E.radon_fan_adjoint(v, geo)
+    assert rel(xa, O.radon_fan_adjoint(v, ang, W, fan, circle)) < 1e-5
+    dot = abs(float((y.double() * v.double()).sum()) - float((x.double() * xa.double()).sum()))
+    assert dot / float(y.double().norm() * v.double().norm()) < 1e-7

@@ -252,3 +252,24 @@ def test_unfolded_pgd_golden(dev):
     assert abs(float(loss) - float(d["loss"])) / float(d["loss"]) < TOL
     for n, p in model.named_parameters():
         assert rel_err(p.grad, d["grad_" + n.replace(".", "_")]) < 1e-3, n
+
+
+@pytest.mark.parametrize("circle", [0, 1])
+def test_tomography_fan_beam_golden(dev, circle):
+    """Tomography(fan_beam=True) (fan_beam_grid radon.py:16-52; exact adjoint + RampFilter FBP, tomography.py:229-350)"""
+    import deepinv_amd as dinv
+
+    raw = np.load(os.path.join(G, "tomo_fan.npz"))
+    fan = dict(zip([str(k) for k in raw["fan_keys"]], [float(v) for v in raw["fan"]]))
+    fan["n_detector_pixels"] = int(fan["n_detector_pixels"])
+    d = {k: torch.from_numpy(raw[k]).to(dev) for k in raw.files if k != "fan_keys"}
+    p = dinv.physics.Tomography(angles=d["angles"], img_width=16, circle=bool(circle), normalize=False, fan_beam=True,
+                                fan_parameters=fan, device=dev)
+    assert rel_err(p.A(d["x"]), d[f"y_c{circle}"]) < TOL
+    assert rel_err(p.A_adjoint(d[f"v_c{circle}"]), d[f"vadj_c{circle}"]) < TOL
+    assert rel_err(p.A_dagger(d[f"y_c{circle}"], fbp=True), d[f"fbp_c{circle}"]) < TOL
+    if not circle:      # the reference's default parameters: 258 detector pixels, most rays miss the image
+        p = dinv.physics.Tomography(angles=6, img_width=16, normalize=False, fan_beam=True, device=dev)
+        y = p.A(d["x"])
+        assert rel_err(y, d["y_default"]) < TOL and torch.equal(y == 0, d["y_default"] == 0)
+        assert rel_err(p.A_adjoint(d["v_default"]), d["vadj_default"]) < TOL

@@ -227,3 +227,19 @@ def test_diffpir_matches_reference_sample_path():
     # 2e-3 in that step's output and decays to 2e-5 in the final sample (measured).  Any implementation that is not
     # bit-identical to the reference's A^T sees this; the bound below is the north_star's 1e-4.
     assert close(out, d["out"], 1e-4)
+
+
+def test_tomography_fan_beam():
+    """fan_beam_grid / Radon(fan_beam=True) / Tomography.fbp with the fan branch (radon.py:16-52, tomography.py:229-350)"""
+    import numpy as np
+    raw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tomo_fan.npz"))
+    fan = dict(zip([str(k) for k in raw["fan_keys"]], [float(v) for v in raw["fan"]]))
+    fan["n_detector_pixels"] = int(fan["n_detector_pixels"])
+    t = lambda k: torch.from_numpy(raw[k])
+    for c in (0, 1):
+        assert close(O.radon_fan_forward(t("x"), t("angles"), fan, bool(c)), t(f"y_c{c}"))
+        assert close(O.radon_fan_adjoint(t(f"v_c{c}"), t("angles"), 16, fan, bool(c)), t(f"vadj_c{c}"))
+        assert close(O.tomography_fan_fbp(t(f"y_c{c}"), t("angles"), 16, fan, None, bool(c)), t(f"fbp_c{c}"))
+    a6 = torch.linspace(0, 180, 7)[:-1]                      # the reference's default fan parameters
+    assert close(O.radon_fan_forward(t("x"), a6), t("y_default"))
+    assert close(O.radon_fan_adjoint(t("v_default"), a6, 16), t("vadj_default"))

@@ -147,3 +147,39 @@ def test_angles_update_rebuilds_geometry(dev):
     assert rel_err(phys.A(x.to(dev)), O.radon_forward(x, a2)) < TOL
     phys.angles.copy_(a1.to(dev))          # in-place edit: caught by the version counter
     assert rel_err(phys.A(x.to(dev)), O.radon_forward(x, a1)) < TOL
+
+
+FAN_B = {"pixel_spacing": 0.02, "source_radius": 4.0, "detector_radius": 3.0, "n_detector_pixels": 96, "detector_spacing": 0.05}
+
+
+@pytest.mark.parametrize("W,angles,circle,B,C,fan", [
+    (32, 24, False, 3, 1, FAN_B), (48, 36, True, 2, 2, FAN_B), (64, 30, False, 9, 1, None),
+    (40, 17, False, 1, 1, {"pixel_spacing": 0.05, "source_radius": 8.0, "detector_radius": 2.0, "n_detector_pixels": 200,
+                           "detector_spacing": 0.02})])
+def test_fan_beam_forward_adjoint_fbp(dev, W, angles, circle, B, C, fan):
+    """Tomography(fan_beam=True) vs the CPU oracle (fan_beam_grid, radon.py:16-52): forward, exact adjoint (dot test),
+    normalisation by the power method, FBP = RampFilter + adjoint (tomography.py:270-279), autograd"""
+    import deepinv_amd as dinv
+
+    g = torch.Generator().manual_seed(W)
+    x = torch.rand(B, C, W, W, generator=g)
+    phys = dinv.physics.Tomography(angles=angles, img_width=W, circle=circle, normalize=False, fan_beam=True,
+                                   fan_parameters=fan, device=dev)
+    ang = phys.angles.cpu()
+    y = phys.A(x.to(dev))
+    y_ref = O.radon_fan_forward(x, ang, fan, circle)
+    assert y.shape == y_ref.shape and rel_err(y, y_ref) < TOL
+    v = torch.randn(y_ref.shape, generator=g)
+    assert rel_err(phys.A_adjoint(v.to(dev)), O.radon_fan_adjoint(v, ang, W, fan, circle)) < TOL
+    assert dot_test(phys, x.to(dev), y) < 1e-5
+    assert rel_err(phys.A_dagger(y, fbp=True), O.tomography_fan_fbp(y_ref, ang, W, fan, None, circle)) < TOL
+    xg = x.to(dev).requires_grad_(True)
+    (phys.A(xg) * v.to(dev)).sum().backward()
+    assert rel_err(xg.grad, phys.A_adjoint(v.to(dev))) < 1e-6
+    if fan is FAN_B and not circle:
+        pn = dinv.physics.Tomography(angles=angles, img_width=W, circle=circle, normalize=True, fan_beam=True,
+                                     fan_parameters=fan, device=dev)
+        nrm = float(pn.operator_norm)
+        assert rel_err(pn.A(x.to(dev)) * nrm, y) < 1e-5
+        assert 0.9 < float(pn.compute_norm(torch.randn(1, 1, W, W, device=dev), squared=False, verbose=False)) < 1.1
+        assert rel_err(pn.A_dagger(pn.A(x.to(dev)), fbp=True), phys.A_dagger(y, fbp=True)) < 1e-4
