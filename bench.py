@@ -66,39 +66,34 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the operator rows of configs 3-5")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
-
     import deepinv_amd as dinv
+    from deepinv_amd.distributed import BatchParallelContext
     from deepinv_amd.hip import drunet as K
+
+    # rank / device / rendez-vous conventions, slab partition and the gather are those of deepinv_amd.distributed
+    # (the same code the world-size-2 gloo tests run on CPU tensors, tests/test_distributed_cpu.py)
+    ctx = BatchParallelContext(backend="nccl")   # "nccl" is RCCL on ROCm
+    world, rank = ctx.world_size, ctx.rank
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    ctx.__enter__()
+    device = ctx.device
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
 
     H = W = args.size
     if args.batch % world:
         raise SystemExit("global batch must be divisible by the number of GPUs")
-    B_local = args.batch // world
-    physics, x_true, y, maps, mask = make_problem(dinv, B_local, rank * B_local, H, W, args.coils, device)
+    slab = ctx.slab(args.batch)
+    B_local = slab.stop - slab.start
+    physics, x_true, y, maps, mask = make_problem(dinv, B_local, slab.start, H, W, args.coils, device)
 
     torch.manual_seed(0)
     denoiser = dinv.models.DRUNet(2, 2, pretrained=None).to(device).eval()
     model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(denoiser), stepsize=1.0, g_param=0.05,
                            max_iter=args.iters, early_stop=False)
-    gathered = torch.empty((args.batch, 2, H, W), device=device)
-
     def step():
-        xr = model(y, physics)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, xr.contiguous())
-            return gathered
-        return xr
+        return ctx.all_gather_batch(model(y, physics), args.batch)     # one RCCL all-gather per step (identity at N = 1)
 
     def fence():
         if world > 1:
@@ -204,8 +199,7 @@ def main():
                                                x_gpu0=out[:1].cpu())
             res["parity_rel_err_50it"] = res["cpu_baseline"].pop("parity_rel_err")
         print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    ctx.__exit__(None, None, None)
 
 
 def other_config_ops(dinv, device, op_row):
