@@ -229,6 +229,107 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_bf16s_kernel(SArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 2x2 stride-2 convolution (downsample_strideconv, deepinv/models/drunet.py:524-552) with the same operand split.
+// K = 4 taps x Cin.  Every input pixel feeds exactly one output pixel and tap, so the B operand goes global -> registers
+// -> split -> MFMA with no LDS stage (that stream IS the HBM traffic of the layer: the fp32 kernel of drunet.hip is
+// bound by the fp32 matrix pipe, 0.66 ms at level 0; this one by HBM); the pre-split weights of a K step (one tap, 16
+// channels, 64 couts: 4 KB) are shared by the four waves and double-buffered in LDS, one LDS-only barrier per K step.
+struct DownSArgs {
+    Geom gi, go;
+    const float* x;    // [cin/8][gi.cs][8]
+    const uint4* w;    // [tap 4][cin/16][plane 2][cblk 2][cout] x (8 bf16)
+    float* y;          // [cout/8][go.cs][8]
+    int32_t cin, cout;
+    int64_t ntiles, per_xcd;
+};
+
+__global__ __launch_bounds__(256) void down2x2_bf16s_kernel(DownSArgs a) {
+    __shared__ uint4 wl[2][256];   // [stage][plane 2][cblk 2][co 64]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // cout tiles of one pixel tile next to each other on one XCD (they read the same input pixels)
+    const int64_t logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.ntiles) return;
+    const int nct = a.cout / 64;
+    const int64_t q0 = (logical / nct) * 256 + wv * 64;
+    const int co0 = (int)(logical % nct) * 64;
+    int64_t ioff[2];
+    bool in[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int64_t q = q0 + n * 32 + l31;
+        in[n] = interior(a.go, q);
+        ioff[n] = a.gi.sl;     // border / out-of-range lanes read a valid (zero frame) pixel; their result is not stored
+        if (in[n]) {
+            const int64_t b = q / a.go.plane;
+            const int qi = (int)(q - b * a.go.plane);
+            const int R = qi / a.go.wp, C = qi - R * a.go.wp;
+            ioff[n] = a.gi.sl + b * a.gi.plane + (int64_t)(2 * (R - 1) + 1) * a.gi.wp + (2 * (C - 1) + 1);
+        }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int S = a.cin / 16, nsteps = 4 * S;
+    // this thread's weight unit of a K step: plane (tid >> 7), channel block ((tid >> 6) & 1), cout tid & 63
+    const int64_t wunit = (int64_t)(tid >> 6) * a.cout + co0 + (tid & 63);
+    float4 ba[2], bb[2];
+    uint4 wreg;
+    auto issue = [&](int g) {
+        const int tap = g / S, s = g - tap * S;
+        const int64_t toff = (int64_t)(tap >> 1) * a.gi.wp + (tap & 1);
+        wreg = a.w[(int64_t)g * 4 * a.cout + wunit];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float* xb = a.x + ((int64_t)(2 * s + lhi) * a.gi.cs + ioff[n] + toff) * 8;
+            ba[n] = ld4(xb);
+            bb[n] = ld4(xb + 4);
+        }
+    };
+    issue(0);
+    wl[0][tid] = wreg;
+    uint4 Bh[2], Bl[2];
+    split8(ba[0], bb[0], Bh[0], Bl[0]);
+    split8(ba[1], bb[1], Bh[1], Bl[1]);
+    if (nsteps > 1) issue(1);
+    __syncthreads();
+    for (int g = 0; g < nsteps; ++g) {
+        const uint4* ws = wl[g & 1];
+        uint4 A[2][2];   // [plane][m]
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) A[pl][m] = ws[pl * 128 + lhi * 64 + m * 32 + l31];
+        // smallest terms first (ah*bl, al*bh, ah*bh), product-major: consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int pa = e == 1 ? 1 : 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(A[pa][m], e == 0 ? Bl[n] : Bh[n], acc[m][n]);
+        }
+        if (g + 1 < nsteps) {   // registers hold step g+1 (loaded one iteration ago)
+            wl[(g + 1) & 1][tid] = wreg;
+            split8(ba[0], bb[0], Bh[0], Bl[0]);
+            split8(ba[1], bb[1], Bh[1], Bl[1]);
+            if (g + 2 < nsteps) issue(g + 2);
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int64_t q = q0 + n * 32 + l31;
+        if (q >= a.go.np) continue;
+        store_tile<2, false, 0>(acc, n, a.go.sl + q, in[n], co0 / 8, a.cout / 8, a.go.cs, lhi, a.y, nullptr, nullptr);
+    }
+}
+
 }  // namespace
 
 extern "C" int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin,
@@ -271,6 +372,23 @@ extern "C" int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const 
     else DINV_S_LAUNCH_W(false, 0);
 #undef DINV_S_LAUNCH_W
 #undef DINV_S_LAUNCH
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_conv_down2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
+                                       const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream) {
+    if (int e = check_geom(gin)) return e;
+    if (int e = check_geom(gout)) return e;
+    DINV_REQUIRE(x && w_split && y, "null tensor pointer");
+    DINV_REQUIRE(gin->height == 2 * gout->height && gin->width == 2 * gout->width && gin->batch == gout->batch,
+                 "down2x2 geometry mismatch");
+    DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout % 64 == 0, "bf16-split down2x2 needs cin %% 16 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
+    DownSArgs a{make_geom(*gin), make_geom(*gout), x, reinterpret_cast<const uint4*>(w_split), y, cin, cout, 0, 0};
+    a.ntiles = ceil_div(gout->np, 256) * (cout / 64);
+    a.per_xcd = ceil_div(a.ntiles, 8);
+    hipLaunchKernelGGL(down2x2_bf16s_kernel, dim3((unsigned)(a.per_xcd * 8)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
     DINV_CHECK_LAUNCH();
     return 0;
 }

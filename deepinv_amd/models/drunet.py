@@ -214,7 +214,9 @@ class DRUNet(Denoiser):
         for name in ("m_down1", "m_down2", "m_down3"):
             seq = getattr(self, name)
             e[name] = [(c3(b.res[0]), c3(b.res[2])) for b in list(seq)[:-1]]
-            e[name + "_s"] = K.pack_down_weight(seq[-1].weight.to(device))
+            wd = seq[-1].weight.to(device)
+            e[name + "_s"] = K.pack_down_weight(wd)
+            e[name + "_sb"] = K.pack_down_bf16s_weight(wd) if (wd.shape[0] % 64 == 0 and wd.shape[1] % 16 == 0) else None
         e["m_body"] = [(c3(b.res[0]), c3(b.res[2])) for b in self.m_body]
         for name in ("m_up3", "m_up2", "m_up1"):
             seq = getattr(self, name)
@@ -303,7 +305,10 @@ class DRUNet(Denoiser):
         downs = ("m_down1", "m_down2", "m_down3")
         for i, name in enumerate(downs):
             r = self._res_chain(g[i], e[name], nc[i], cur, ws[f"a{i}"], ws[f"b{i}"], ws[f"t{i}"])
-            K.down2x2(g[i], g[i + 1], r, e[name + "_s"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])   # x2, x3, x4
+            if e[name + "_sb"] is not None and _resblock_conv() == "bf16s":   # same arithmetic as the ResBlock convs
+                K.down2x2_bf16s(g[i], g[i + 1], r, e[name + "_sb"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])   # x2, x3, x4
+            else:
+                K.down2x2(g[i], g[i + 1], r, e[name + "_s"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])
             cur = ws[f"skip{i + 1}"]
         r = self._res_chain(g[3], e["m_body"], nc[3], cur, ws["a3"], ws["b3"], ws["t3"])
         skip_add = ws["skip3"]  # x + x4 is fused into the up-conv's operand load

@@ -168,6 +168,12 @@ int dinv_conv3x3_bf16x3(const dinv_act_geom* g, const float* x, const void* w_sp
  * w_split: [cout/64][cin/16][dy 3][plane 2][dx 3][cblk 2][co 64][8] bf16; cin % 16 == 0, cout % 64 == 0. */
 int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin, int32_t cout,
                        float* y, const float* res1, int32_t relu, dinv_stream_t stream);
+
+/* 2x2 stride-2 convolution (downsample_strideconv, drunet.py:524-552) on the bf16 matrix cores with the same exact
+ * two-part operand split; w_split: [tap = dy*2+dx][Cin/16][plane hi/lo][cblk 2][Cout][ci 8] bf16.  Same operator as
+ * dinv_conv_down2x2 (fp32 pipe). */
+int dinv_conv_down2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
+                            const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
 /* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin/8][cout][8] */
 int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                       const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);

@@ -29,3 +29,14 @@ for lvl, c in enumerate((64, 128, 256, 512)):
     print(json.dumps({"lvl": lvl, "B": B, "relu_ms": round(t1 * 1e3, 4), "res_ms": round(t2 * 1e3, 4),
                       "executed_TF": round(3 * fl / t1 / 1e12, 1), "waves": os.environ.get("DINV_BF16S_WAVES", "8")}))
 print(json.dumps({"resblock_convs_ms_per_drunet": round(tot * 1e3, 2)}))
+for lvl, (ci, co) in enumerate(((64, 128), (128, 256), (256, 512))):
+    H = 320 >> lvl
+    gi, go = K.geom(B, H, H), K.geom(B, H // 2, H // 2)
+    x, y = K.alloc(gi, ci, dev), K.alloc(go, co, dev)
+    x.normal_()
+    w = torch.randn(co, ci, 2, 2, device=dev) / (2 * ci ** 0.5)
+    wf, wb = K.pack_down_weight(w), K.pack_down_bf16s_weight(w)
+    t1 = timeit(lambda: K.down2x2(gi, go, x, wf, ci, co, y), iters=20, warmup=3)
+    t2 = timeit(lambda: K.down2x2_bf16s(gi, go, x, wb, ci, co, y), iters=20, warmup=3)
+    print(json.dumps({"down": lvl, "B": B, "fp32_ms": round(t1 * 1e3, 4), "bf16s_ms": round(t2 * 1e3, 4),
+                      "hbm_floor_ms": round((x.numel() + y.numel()) * 4 / 5e12 * 1e3, 4)}))

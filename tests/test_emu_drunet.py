@@ -79,3 +79,30 @@ def test_bf16_split_conv_matches_fp64(B, H, W, cin, cout, mode, waves, monkeypat
     full = ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
     assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
     assert float(full[:, :, H + 1].abs().max()) == 0 and float(full[:, :, :, W + 1:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(1, 8, 12, 16, 64), (2, 10, 6, 32, 128), (3, 16, 16, 64, 64)])
+def test_bf16_split_down2x2_matches_fp64(B, H, W, cin, cout):
+    """2x2 stride-2 convolution of drunet_bf16s.hip (downsample_strideconv, drunet.py:524-552) on the host emulation"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_down_bf16s_weight
+
+    gen = torch.Generator().manual_seed(H * W + cin)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, 2, 2, generator=gen) / (2.0 * cin ** 0.5)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=2)
+    gi, go = geom(B, H, W), geom(B, H // 2, W // 2)
+    xa = to_act(x, gi)
+    ya = torch.full((cout // 8, go.cs, 8), float("nan"))
+    ya[:, :go.sl] = 0
+    wp = pack_down_bf16s_weight(w)
+    l = E.lib()
+    E.check(l.dinv_conv_down2x2_bf16s(ctypes.byref(gi), ctypes.byref(go), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout,
+                                      E.p(ya), None))
+    out = from_act(ya, go, cout)
+    assert not torch.isnan(out).any()
+    err = float((out.double() - ref).norm() / ref.norm())
+    assert err < 2e-5, err
+    full = ya[:, go.sl:go.sl + go.np].view(-1, B, go.hp, go.wp, 8)       # the zero frame of the output is written as zeros
+    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
