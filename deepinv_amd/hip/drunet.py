@@ -35,6 +35,7 @@ def _l():
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_down2x2_bf16s.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
+        l.dinv_conv_up2x2_bf16s.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
         _declared = True
     return l
@@ -129,6 +130,18 @@ def pack_down_bf16s_weight(w: torch.Tensor) -> torch.Tensor:
     lo = (w - hi.float()).bfloat16()
     planes = torch.stack((hi, lo)).reshape(2, cout, cin // 16, 2, 8, 2, 2)        # pl, co, s, cblk, ci, dy, dx
     return planes.permute(5, 6, 2, 0, 3, 1, 4).contiguous()                       # dy, dx, s, pl, cblk, co, ci
+
+
+def pack_up_bf16s_weight(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d k2 s2 weight [Cin,Cout,2,2] -> two-part bf16 split packed [Cin/16][tap=dy*2+dx][plane 2][cblk 2][Cout][ci 8]"""
+    cin, cout = w.shape[:2]
+    if cin % 16 or cout % 64:
+        raise ValueError(f"bf16-split up packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
+    w = w.detach().float()
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    planes = torch.stack((hi, lo)).reshape(2, cin // 16, 2, 8, cout, 2, 2)        # pl, s, cblk, ci, co, dy, dx
+    return planes.permute(1, 5, 6, 0, 2, 4, 3).contiguous()                       # s, dy, dx, pl, cblk, co, ci
 
 
 def pack_up_weight(w: torch.Tensor) -> torch.Tensor:
@@ -260,6 +273,12 @@ def down2x2_bf16s(gi, go, x, wsplit, cin, cout, y):
     """the same 2x2 stride-2 convolution on the bf16 matrix cores (weights from pack_down_bf16s_weight)"""
     check(_l().dinv_conv_down2x2_bf16s(ctypes.byref(gi), ctypes.byref(go), ptr(x), ptr(wsplit), cin, cout, ptr(y),
                                        stream_ptr(y.device)))
+
+
+def up2x2_bf16s(gi, go, x, x2, wsplit, cin, cout, y):
+    """the same transposed convolution on the bf16 matrix cores (weights from pack_up_bf16s_weight)"""
+    check(_l().dinv_conv_up2x2_bf16s(ctypes.byref(gi), ctypes.byref(go), ptr(x), ptr(x2), ptr(wsplit), cin, cout, ptr(y),
+                                     stream_ptr(y.device)))
 
 
 def up2x2(gi, go, x, x2, w, cin, cout, y):

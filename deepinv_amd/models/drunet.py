@@ -220,7 +220,9 @@ class DRUNet(Denoiser):
         e["m_body"] = [(c3(b.res[0]), c3(b.res[2])) for b in self.m_body]
         for name in ("m_up3", "m_up2", "m_up1"):
             seq = getattr(self, name)
-            e[name + "_s"] = K.pack_up_weight(seq[0].weight.to(device))
+            wu = seq[0].weight.to(device)
+            e[name + "_s"] = K.pack_up_weight(wu)
+            e[name + "_sb"] = K.pack_up_bf16s_weight(wu) if (wu.shape[0] % 16 == 0 and wu.shape[1] % 64 == 0) else None
             e[name] = [(c3(b.res[0]), c3(b.res[2])) for b in list(seq)[1:]]
         self._engine = e
         return e
@@ -313,7 +315,10 @@ class DRUNet(Denoiser):
         r = self._res_chain(g[3], e["m_body"], nc[3], cur, ws["a3"], ws["b3"], ws["t3"])
         skip_add = ws["skip3"]  # x + x4 is fused into the up-conv's operand load
         for i, name in zip((2, 1, 0), ("m_up3", "m_up2", "m_up1")):
-            K.up2x2(g[i + 1], g[i], r, skip_add, e[name + "_s"], nc[i + 1], nc[i], ws[f"t{i}"])
+            if e[name + "_sb"] is not None and _resblock_conv() == "bf16s":
+                K.up2x2_bf16s(g[i + 1], g[i], r, skip_add, e[name + "_sb"], nc[i + 1], nc[i], ws[f"t{i}"])
+            else:
+                K.up2x2(g[i + 1], g[i], r, skip_add, e[name + "_s"], nc[i + 1], nc[i], ws[f"t{i}"])
             # t{i} holds the up-conv output; run the ResBlocks with a/b ping-pong and a fresh temporary
             r = self._res_chain_from_t(g[i], e[name], ws[f"t{i}"], ws[f"a{i}"], ws[f"b{i}"])
             skip_add = ws[f"skip{i}"]

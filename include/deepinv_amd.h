@@ -174,6 +174,12 @@ int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const void* w_spl
  * dinv_conv_down2x2 (fp32 pipe). */
 int dinv_conv_down2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                             const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
+
+/* 2x2 stride-2 transposed convolution (upsample_convtranspose, drunet.py:493-521) of x (+ x2, the U-Net skip add) on
+ * the bf16 matrix cores; w_split: [Cin/16][tap = dy*2+dx][plane hi/lo][cblk 2][Cout][ci 8] bf16.  Same operator as
+ * dinv_conv_up2x2 (fp32 pipe); writes interior output pixels only. */
+int dinv_conv_up2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
+                          const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
 /* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin/8][cout][8] */
 int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                       const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);

@@ -40,3 +40,15 @@ for lvl, (ci, co) in enumerate(((64, 128), (128, 256), (256, 512))):
     t2 = timeit(lambda: K.down2x2_bf16s(gi, go, x, wb, ci, co, y), iters=20, warmup=3)
     print(json.dumps({"down": lvl, "B": B, "fp32_ms": round(t1 * 1e3, 4), "bf16s_ms": round(t2 * 1e3, 4),
                       "hbm_floor_ms": round((x.numel() + y.numel()) * 4 / 5e12 * 1e3, 4)}))
+for lvl, (ci, co) in enumerate(((128, 64), (256, 128), (512, 256))):
+    H = 160 >> lvl
+    gi, go = K.geom(B, H, H), K.geom(B, 2 * H, 2 * H)
+    x, x2, y = K.alloc(gi, ci, dev), K.alloc(gi, ci, dev), K.alloc(go, co, dev)
+    x.normal_()
+    x2.normal_()
+    w = torch.randn(ci, co, 2, 2, device=dev) / ci ** 0.5
+    wf, wb = K.pack_up_weight(w), K.pack_up_bf16s_weight(w)
+    t1 = timeit(lambda: K.up2x2(gi, go, x, x2, wf, ci, co, y), iters=20, warmup=3)
+    t2 = timeit(lambda: K.up2x2_bf16s(gi, go, x, x2, wb, ci, co, y), iters=20, warmup=3)
+    print(json.dumps({"up": lvl, "B": B, "fp32_ms": round(t1 * 1e3, 4), "bf16s_ms": round(t2 * 1e3, 4),
+                      "hbm_floor_ms": round((2 * x.numel() + y.numel()) * 4 / 5e12 * 1e3, 4)}))

@@ -106,3 +106,32 @@ def test_bf16_split_down2x2_matches_fp64(B, H, W, cin, cout):
     assert err < 2e-5, err
     full = ya[:, go.sl:go.sl + go.np].view(-1, B, go.hp, go.wp, 8)       # the zero frame of the output is written as zeros
     assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,skip", [(1, 5, 7, 16, 64, False), (2, 6, 4, 32, 128, True), (3, 8, 8, 64, 64, True)])
+def test_bf16_split_up2x2_matches_fp64(B, H, W, cin, cout, skip):
+    """2x2 stride-2 transposed convolution of drunet_bf16s.hip (upsample_convtranspose, drunet.py:493-521), input = x (+ x2)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_up_bf16s_weight
+
+    gen = torch.Generator().manual_seed(H * W + cin)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    x2 = torch.randn(B, cin, H, W, generator=gen)
+    w = torch.randn(cin, cout, 2, 2, generator=gen) / (cin ** 0.5)
+    ref = torch.nn.functional.conv_transpose2d((x + x2 if skip else x).double(), w.double(), stride=2)
+    gi, go = geom(B, H, W), geom(B, 2 * H, 2 * W)
+    xa, x2a = to_act(x, gi), to_act(x2, gi)
+    ya = torch.zeros((cout // 8, go.cs, 8))
+    ya[:, go.sl:go.sl + go.np].view(-1, B, go.hp, go.wp, 8)[:, :, 1:2 * H + 1, 1:2 * W + 1] = float("nan")   # interior must be written
+    wp = pack_up_bf16s_weight(w)
+    l = E.lib()
+    E.check(l.dinv_conv_up2x2_bf16s(ctypes.byref(gi), ctypes.byref(go), E.p(xa), E.p(x2a) if skip else None,
+                                    ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya), None))
+    out = from_act(ya, go, cout)
+    assert not torch.isnan(ya).any()
+    err = float((out.double() - ref).norm() / ref.norm())
+    assert err < 2e-5, err
+    full = ya[:, go.sl:go.sl + go.np].view(-1, B, go.hp, go.wp, 8)       # the zero frame is never touched
+    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
+    assert float(full[:, :, 2 * H + 1].abs().max()) == 0 and float(full[:, :, :, 2 * W + 1:].abs().max()) == 0
