@@ -36,6 +36,10 @@ def _l():
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_down2x2_bf16s.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2_bf16s.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
+        l.dinv_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+        l.dinv_conv_wgrad_workspace_bytes.argtypes = [G, i32, i32, i32]
+        l.dinv_conv_wgrad.argtypes = [G, G, vp, i32, vp, i32, i32, vp, i32, vp, ctypes.c_size_t, vp]
+        l.dinv_relu_backward.argtypes = [ctypes.c_int64, vp, vp, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
         _declared = True
     return l
@@ -284,3 +288,21 @@ def up2x2_bf16s(gi, go, x, x2, wsplit, cin, cout, y):
 def up2x2(gi, go, x, x2, w, cin, cout, y):
     check(_l().dinv_conv_up2x2(ctypes.byref(gi), ctypes.byref(go), ptr(x), ptr(x2), ptr(w), cin, cout, ptr(y),
                                stream_ptr(y.device)))
+
+
+def conv_wgrad(gs, gl, s, m, l, n, taps, dw=None, accumulate=False):
+    """dw[m][n][t] (+)= sum_p S[m][p] L[n][map(p) + off_t] (csrc/drunet_bwd.hip); returns dw of shape [m, n, k, k]"""
+    k = 3 if taps == 9 else 2
+    if dw is None:
+        dw = torch.empty((m, n, k, k), device=s.device, dtype=torch.float32)
+        accumulate = False
+    ws = torch.empty(_l().dinv_conv_wgrad_workspace_bytes(ctypes.byref(gs), m, n, taps), device=s.device, dtype=torch.uint8)
+    check(_l().dinv_conv_wgrad(ctypes.byref(gs), ctypes.byref(gl), ptr(s), m, ptr(l), n, taps, ptr(dw), int(accumulate), ptr(ws),
+                               ws.numel(), stream_ptr(s.device)))
+    return dw
+
+
+def relu_backward(act, grad):
+    """grad <- grad * (act > 0) in place, on whole activation buffers"""
+    check(_l().dinv_relu_backward(grad.numel(), ptr(act), ptr(grad), stream_ptr(grad.device)))
+    return grad

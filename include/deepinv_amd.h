@@ -180,6 +180,21 @@ int dinv_conv_down2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout,
  * dinv_conv_up2x2 (fp32 pipe); writes interior output pixels only. */
 int dinv_conv_up2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
                           const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
+
+/* ---- training through the DRUNet prior (deepinv/unfolded/unfolded.py:116-226 with deepinv/models/drunet.py:39-263).
+ * Data gradients reuse the forward kernels with re-packed weights (3x3: transposed + flipped; 2x2 down <-> 2x2 up).
+ * Weight gradients:  dw[m][n][t] (+)= sum_p S[m][p] * L[n][map(p) + off_t]
+ *   taps == 9: 3x3 conv, S = dL/dy [m = Cout], L = x [n = Cin], one grid (gs == gl), dw laid out [Cout][Cin][3][3];
+ *   taps == 4: 2x2 stride-2 conv:   S = dL/dy on the half grid gs, L = x on the full grid gl -> [Cout][Cin][2][2];
+ *              2x2 transposed conv: S = x on the half grid, L = dL/dy on the full grid       -> [Cin][Cout][2][2].
+ * Both tensors in the padded channel-blocked activation layout with zero frames; fp32 matrix cores; deterministic
+ * (per-slice partial sums in `ws`, fixed-order reduction).  accumulate != 0 adds to dw. */
+size_t dinv_conv_wgrad_workspace_bytes(const dinv_act_geom* gs, int32_t m, int32_t n, int32_t taps);
+int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m, const float* l,
+                    int32_t n, int32_t taps, float* dw, int32_t accumulate, void* ws, size_t ws_bytes,
+                    dinv_stream_t stream);
+/* grad <- grad where act > 0 else 0 (ReLU backward on whole activation buffers; n floats, n % 4 == 0) */
+int dinv_relu_backward(int64_t n, const float* act, float* grad, dinv_stream_t stream);
 /* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin/8][cout][8] */
 int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                       const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);

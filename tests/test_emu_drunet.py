@@ -30,6 +30,9 @@ def geom(B, H, W):
 
 def to_act(t, g):
     B, C, H, W = t.shape
+    if C % 8:       # channel blocks are 8 wide: pad with zero channels
+        t = torch.cat((t, torch.zeros(B, 8 - C % 8, H, W, dtype=t.dtype)), 1)
+        C = t.shape[1]
     a = torch.zeros(C // 8, g.cs, 8)
     av = a[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
     av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
@@ -135,3 +138,53 @@ def test_bf16_split_up2x2_matches_fp64(B, H, W, cin, cout, skip):
     full = ya[:, go.sl:go.sl + go.np].view(-1, B, go.hp, go.wp, 8)       # the zero frame is never touched
     assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
     assert float(full[:, :, 2 * H + 1].abs().max()) == 0 and float(full[:, :, :, 2 * W + 1:].abs().max()) == 0
+
+
+def _wgrad(gs, gl, s, m, l, n, taps):
+    lib = E.lib()
+    lib.dinv_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    k = 3 if taps == 9 else 2
+    dw = torch.full((m, n, k, k), float("nan"))
+    ws = torch.zeros(lib.dinv_conv_wgrad_workspace_bytes(ctypes.byref(gs), m, n, taps), dtype=torch.uint8)
+    E.check(lib.dinv_conv_wgrad(ctypes.byref(gs), ctypes.byref(gl), E.p(s), m, E.p(l), n, taps, E.p(dw), 0, E.p(ws),
+                                ctypes.c_size_t(ws.numel()), None))
+    return dw
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 9, 14, 16, 64), (1, 12, 8, 3, 64), (3, 8, 8, 64, 2), (1, 20, 33, 40, 24)])
+def test_wgrad_3x3_matches_autograd(B, H, W, cin, cout):
+    """dW of a 3x3 convolution (csrc/drunet_bwd.hip on the host emulation) vs torch autograd in fp64"""
+    gen = torch.Generator().manual_seed(cin * cout + H)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    gy = torch.randn(B, cout, H, W, generator=gen)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(x.double(), w, padding=1) * gy.double()).sum().backward()
+    g = geom(B, H, W)
+    dw = _wgrad(g, g, to_act(gy, g), cout, to_act(x, g), cin, 9)
+    assert not torch.isnan(dw).any()
+    assert float((dw.double() - w.grad).norm() / w.grad.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,cs,cl,up", [(2, 6, 8, 64, 16, False), (1, 5, 4, 32, 128, True), (2, 8, 8, 24, 40, False)])
+def test_wgrad_2x2_matches_autograd(B, H, W, cs, cl, up):
+    """dW of the 2x2 stride-2 convolution (S = dL/dy on the half grid) and of the transposed one (S = x on the half grid)"""
+    gen = torch.Generator().manual_seed(cs + cl)
+    small = torch.randn(B, cs, H, W, generator=gen)
+    big = torch.randn(B, cl, 2 * H, 2 * W, generator=gen)
+    w = torch.zeros(cs, cl, 2, 2, dtype=torch.float64, requires_grad=True)
+    if up:      # y = convT(x = small, w [Cin, Cout, 2, 2]), dL/dy = big
+        (torch.nn.functional.conv_transpose2d(small.double(), w, stride=2) * big.double()).sum().backward()
+    else:       # y = conv(x = big, w [Cout, Cin, 2, 2], stride 2), dL/dy = small
+        (torch.nn.functional.conv2d(big.double(), w, stride=2) * small.double()).sum().backward()
+    gs, gl = geom(B, H, W), geom(B, 2 * H, 2 * W)
+    dw = _wgrad(gs, gl, to_act(small, gs), cs, to_act(big, gl), cl, 4)
+    assert not torch.isnan(dw).any()
+    assert float((dw.double() - w.grad).norm() / w.grad.norm()) < 1e-5
+
+
+def test_relu_backward():
+    a = torch.randn(1000)
+    g = torch.randn(1000)
+    ref = g * (a > 0)
+    E.check(E.lib().dinv_relu_backward(ctypes.c_int64(1000), E.p(a), E.p(g), None))
+    assert torch.equal(g, ref)
