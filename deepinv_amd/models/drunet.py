@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from ..hip import HipExtensionError
 from ..hip import drunet as K
+from . import drunet_train
 from .base import Denoiser
 
 
@@ -168,11 +169,18 @@ class DRUNet(Denoiser):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         return self.dim == 2 and not needs_grad
 
+    def _use_hip_train(self):
+        """gradients requested: the hand-written backward (models/drunet_train.py) for the 2-D architectures it covers;
+        DINV_DRUNET_TRAIN=torch selects the PyTorch-ROCm graph (always used for dim=3)"""
+        return drunet_train.supported(self) and os.environ.get("DINV_DRUNET_TRAIN", "hip") != "torch"
+
     def forward(self, x, sigma):
         if not x.is_cuda:
             raise HipExtensionError("deepinv_amd.models.DRUNet runs only on a HIP device; there is no CPU fallback")
         if self._use_hip(x):
             run = lambda inp: self._hip_forward(inp[:, :-1], inp[:, -1:])
+        elif self._use_hip_train():
+            run = lambda inp: drunet_train.forward_train(self, inp)     # forward AND backward on the HIP kernels
         else:
             run = self.forward_unet_torch
         xin = torch.cat((x, self._noise_map(x, sigma)), 1)

@@ -1,0 +1,38 @@
+import copy, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deepinv_amd as dinv
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
+if len(sys.argv) > 1:
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".res." in n:
+                torch.nn.init.orthogonal_(p, gain=float(sys.argv[1]))
+B, H, W = 2, 48, 64
+g = torch.Generator().manual_seed(3)
+x0 = torch.rand(B, 2, H, W, generator=g)
+sig0 = 0.05 + 0.1 * torch.rand(B, 1, H, W, generator=g)
+v = torch.randn(B, 2, H, W, generator=g)
+ref = copy.deepcopy(model).cpu().double()
+xin = torch.cat((x0, sig0), 1).double().requires_grad_(True)
+(ref.forward_unet_torch(xin) * v.double()).sum().backward()
+gw_ref = {n: p.grad for n, p in ref.named_parameters()}
+
+def run(mode):
+    os.environ["DINV_DRUNET_TRAIN"] = mode
+    model.zero_grad()
+    x = x0.to(dev).requires_grad_(True)
+    sig = sig0.to(dev).requires_grad_(True)
+    (model(x, sig) * v.to(dev)).sum().backward()
+    return torch.cat((x.grad, sig.grad), 1).cpu(), {n: p.grad.cpu() for n, p in model.named_parameters()}
+
+def rel(a, b):
+    return float((a.double() - b).norm() / b.norm())
+
+for mode in ("torch", "hip"):
+    gx, gw = run(mode)
+    errs = sorted(((rel(gw[n], gw_ref[n]), n) for n in gw_ref), reverse=True)
+    print(mode, "gx", rel(gx, xin.grad), "worst w", errs[:4], "median", errs[len(errs) // 2][0])

@@ -1,4 +1,6 @@
 """DRUNet MFMA path vs the CPU oracle (same seeded weights via state_dict)."""
+import os
+
 import pytest
 import torch
 
@@ -258,3 +260,97 @@ def test_tile_parallel_drunet_single_rank(dev):
     assert calls == [(4, 2, 96, 96)]
     assert y.shape == x.shape and torch.isfinite(y).all()
     assert rel_err(y, ref) < 1e-5
+
+
+def _grad_run(model, x0, sig0, v, mode, monkeypatch):
+    monkeypatch.setenv("DINV_DRUNET_TRAIN", mode)
+    model.zero_grad()
+    x = x0.clone().requires_grad_(True)
+    sig = sig0.clone().requires_grad_(True)
+    y = model(x, sig)
+    (y * v).sum().backward()
+    return y.detach(), x.grad, sig.grad, {n: p.grad.clone() for n, p in model.named_parameters()}
+
+
+def _grad_problem(dev, gain):
+    import deepinv_amd as dinv
+
+    torch.manual_seed(0)
+    model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
+    if gain != 0.2:
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if ".res." in n:
+                    torch.nn.init.orthogonal_(p, gain=gain)
+    B, H, W = 2, 48, 64
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.rand(B, 2, H, W, generator=g).to(dev)
+    sig0 = (0.05 + 0.1 * torch.rand(B, 1, H, W, generator=g)).to(dev)
+    v = torch.randn(B, 2, H, W, generator=g).to(dev)
+    return model, x0, sig0, v
+
+
+def test_drunet_hip_backward_matches_autograd(dev, monkeypatch):
+    """models/drunet_train.py (forward + backward on the HIP kernels: data gradients through the forward kernels with
+    re-packed weights, weight gradients through dinv_conv_wgrad) against autograd through the PyTorch graph of the same
+    module: output, gradient of the image, of the noise-level map (the trainable g_param of unfolded PnP) and of every
+    convolution weight."""
+    model, x0, sig0, v = _grad_problem(dev, 0.2)
+    y_t, gx_t, gs_t, gw_t = _grad_run(model, x0, sig0, v, "torch", monkeypatch)
+    y_h, gx_h, gs_h, gw_h = _grad_run(model, x0, sig0, v, "hip", monkeypatch)
+    assert rel_err(y_h, y_t) < 1e-4
+    assert rel_err(gx_h, gx_t) < 1e-4 and rel_err(gs_h, gs_t) < 1e-4
+    worst = max((rel_err(gw_h[n], gw_t[n]), n) for n in gw_t)
+    assert worst[0] < 1e-4, worst            # measured ~1e-5 (fp32 forward: same ReLU masks as the fp32 reference)
+    # the inference kernels in the forward pass (bf16 split, a few 1e-6): data gradients stay fp32-class, a few ReLU
+    # masks at |z| ~ 1e-6 flip and move single rows of single weight gradients (see models/drunet_train.py)
+    monkeypatch.setenv("DINV_DRUNET_TRAIN_PRECISION", "bf16s")
+    y_b, gx_b, gs_b, gw_b = _grad_run(model, x0, sig0, v, "hip", monkeypatch)
+    assert rel_err(y_b, y_t) < 1e-4 and rel_err(gx_b, gx_t) < 1e-4 and rel_err(gs_b, gs_t) < 1e-4
+    errs = sorted(rel_err(gw_b[n], gw_t[n]) for n in gw_t)
+    assert errs[len(errs) // 2] < 2e-3 and errs[-1] < 5e-2
+
+
+def test_drunet_hip_backward_unit_gain_linearised(dev, monkeypatch):
+    """O(1)-gain ResBlock weights, where the 56 ResBlock convolutions carry the gradient.  With unit gains a single ReLU
+    mask that differs between two fp32 implementations (|z| ~ 1e-7) moves every upstream gradient by ~1e-4, which
+    says nothing about the kernels; so the activation is taken out on BOTH sides (identity instead of ReLU) and the
+    whole chain - data-gradient convolutions, 2x2 down / up gradients, all weight gradients - must agree to 1e-4."""
+    from deepinv_amd.hip import drunet as K
+    from deepinv_amd.models import drunet_train as T
+
+    model, x0, sig0, v = _grad_problem(dev, 1.0)
+    for m in model.modules():
+        if hasattr(m, "res"):
+            m.res[1] = torch.nn.Identity()
+    conv3 = T._conv3
+    monkeypatch.setattr(T, "_conv3", lambda g, w, x, relu=False, res1=None, fp32=False: conv3(g, w, x, False, res1, fp32))
+    monkeypatch.setattr(K, "relu_backward", lambda act, grad: grad)
+    y_t, gx_t, gs_t, gw_t = _grad_run(model, x0, sig0, v, "torch", monkeypatch)
+    y_h, gx_h, gs_h, gw_h = _grad_run(model, x0, sig0, v, "hip", monkeypatch)
+    assert rel_err(y_h, y_t) < 1e-4
+    assert rel_err(gx_h, gx_t) < 1e-4 and rel_err(gs_h, gs_t) < 1e-4
+    worst = max((rel_err(gw_h[n], gw_t[n]), n) for n in gw_t)
+    assert worst[0] < 1e-4, worst
+
+
+def test_drunet_hip_backward_frozen_weights_and_unsafe_shape(dev):
+    """frozen denoiser inside an unrolled loop: only the data gradient is needed (no weight-gradient launches), and the
+    padded path for sizes that are not multiples of 8 (test_pad, drunet.py:266-287) differentiates through the pad"""
+    import deepinv_amd as dinv
+
+    torch.manual_seed(1)
+    model = dinv.models.DRUNet(1, 1, pretrained=None).to(dev)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = torch.rand(1, 1, 45, 50, device=dev, requires_grad=True)
+    y = model(x, 0.07)
+    y.square().sum().backward()
+    g_hip = x.grad.clone()
+    os.environ["DINV_DRUNET_TRAIN"] = "torch"
+    try:
+        x2 = x.detach().clone().requires_grad_(True)
+        model(x2, 0.07).square().sum().backward()
+    finally:
+        del os.environ["DINV_DRUNET_TRAIN"]
+    assert rel_err(g_hip, x2.grad) < 1e-4
