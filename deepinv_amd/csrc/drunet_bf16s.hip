@@ -242,8 +242,10 @@ struct DownSArgs {
     float* y;          // [cout/8][go.cs][8]
     int32_t cin, cout;
     int64_t ntiles, per_xcd;
+    DepthMap dm;       // 3-D: output image (half grid) -> input image (full grid) for depth tap dm.dz
 };
 
+template <bool ACC>    // ACC: y += conv (second depth tap of a 2x2x2 convolution)
 __global__ __launch_bounds__(256) void down2x2_bf16s_kernel(DownSArgs a) {
     __shared__ uint4 wl[2][256];   // [stage][plane 2][cblk 2][co 64]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -263,9 +265,13 @@ __global__ __launch_bounds__(256) void down2x2_bf16s_kernel(DownSArgs a) {
         ioff[n] = a.gi.sl;     // border / out-of-range lanes read a valid (zero frame) pixel; their result is not stored
         if (in[n]) {
             const int64_t b = q / a.go.plane;
-            const int qi = (int)(q - b * a.go.plane);
-            const int R = qi / a.go.wp, C = qi - R * a.go.wp;
-            ioff[n] = a.gi.sl + b * a.gi.plane + (int64_t)(2 * (R - 1) + 1) * a.gi.wp + (2 * (C - 1) + 1);
+            const int64_t bi = depth_pair(a.dm, b);
+            if (bi < 0) in[n] = false;          // zero slice of a 3-D volume: stays zero
+            else {
+                const int qi = (int)(q - b * a.go.plane);
+                const int R = qi / a.go.wp, C = qi - R * a.go.wp;
+                ioff[n] = a.gi.sl + bi * a.gi.plane + (int64_t)(2 * (R - 1) + 1) * a.gi.wp + (2 * (C - 1) + 1);
+            }
         }
     }
     f32x16 acc[2][2];
@@ -326,7 +332,8 @@ __global__ __launch_bounds__(256) void down2x2_bf16s_kernel(DownSArgs a) {
     for (int n = 0; n < 2; ++n) {
         const int64_t q = q0 + n * 32 + l31;
         if (q >= a.go.np) continue;
-        store_tile<2, false, 0>(acc, n, a.go.sl + q, in[n], co0 / 8, a.cout / 8, a.go.cs, lhi, a.y, nullptr, nullptr);
+        store_tile<2, false, ACC ? 1 : 0>(acc, n, a.go.sl + q, in[n], co0 / 8, a.cout / 8, a.go.cs, lhi, a.y, ACC ? a.y : nullptr,
+                                          nullptr);
     }
 }
 
@@ -347,6 +354,7 @@ struct UpSArgs {
     const uint4* w;    // [cin/16][tap 4][plane 2][cblk 2][cout] x (8 bf16)
     float* y;          // [cout/8][go.cs][8]
     int32_t cin, cout;
+    DepthMap dm;       // 3-D: input image (half grid) -> output image (full grid) for depth tap dm.dz
 };
 
 template <bool SKIP>
@@ -367,9 +375,13 @@ __global__ __launch_bounds__(256) void up2x2_bf16s_kernel(UpSArgs a) {
         ooff[n] = 0;
         if (in[n]) {
             const int64_t b = p / a.gi.plane;
-            const int pi = (int)(p - b * a.gi.plane);
-            const int r = pi / a.gi.wp, c = pi - r * a.gi.wp;
-            ooff[n] = a.go.sl + b * a.go.plane + (int64_t)(2 * (r - 1) + 1 + tp) * a.go.wp + (2 * (c - 1) + 1);
+            const int64_t bo = depth_pair(a.dm, b);
+            if (bo < 0) in[n] = false;          // zero slice of a 3-D volume: nothing to scatter
+            else {
+                const int pi = (int)(p - b * a.gi.plane);
+                const int r = pi / a.gi.wp, c = pi - r * a.gi.wp;
+                ooff[n] = a.go.sl + bo * a.go.plane + (int64_t)(2 * (r - 1) + 1 + tp) * a.go.wp + (2 * (c - 1) + 1);
+            }
         }
     }
     f32x16 acc[2][2][2];   // [dx][m][n]
@@ -500,36 +512,70 @@ extern "C" int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const 
     return 0;
 }
 
-extern "C" int dinv_conv_down2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
-                                       const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream) {
+static int down2x2_bf16s_launch(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const void* w_split,
+                                int32_t cin, int32_t cout, float* y, DepthMap dm, int accumulate, dinv_stream_t stream) {
     if (int e = check_geom(gin)) return e;
     if (int e = check_geom(gout)) return e;
     DINV_REQUIRE(x && w_split && y, "null tensor pointer");
-    DINV_REQUIRE(gin->height == 2 * gout->height && gin->width == 2 * gout->width && gin->batch == gout->batch,
-                 "down2x2 geometry mismatch");
+    DINV_REQUIRE(gin->height == 2 * gout->height && gin->width == 2 * gout->width, "down2x2 geometry mismatch");
+    if (dm.dep_s == 0) DINV_REQUIRE(gin->batch == gout->batch, "down2x2 geometry mismatch");
+    else
+        DINV_REQUIRE(dm.dep_s >= 3 && dm.dep_l == 2 * (dm.dep_s - 2) + 2 && gout->batch % dm.dep_s == 0 &&
+                     gin->batch / dm.dep_l == gout->batch / dm.dep_s && gin->batch % dm.dep_l == 0 && (dm.dz == 0 || dm.dz == 1),
+                     "down2x2: bad depth pairing (%d, %d, %d)", dm.dep_s, dm.dep_l, dm.dz);
     DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout % 64 == 0, "bf16-split down2x2 needs cin %% 16 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
-    DownSArgs a{make_geom(*gin), make_geom(*gout), x, reinterpret_cast<const uint4*>(w_split), y, cin, cout, 0, 0};
+    DownSArgs a{make_geom(*gin), make_geom(*gout), x, reinterpret_cast<const uint4*>(w_split), y, cin, cout, 0, 0, dm};
     a.ntiles = ceil_div(gout->np, 256) * (cout / 64);
     a.per_xcd = ceil_div(a.ntiles, 8);
-    hipLaunchKernelGGL(down2x2_bf16s_kernel, dim3((unsigned)(a.per_xcd * 8)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), a);
+    const dim3 grid((unsigned)(a.per_xcd * 8));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (accumulate) hipLaunchKernelGGL(down2x2_bf16s_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(down2x2_bf16s_kernel<false>, grid, dim3(256), 0, st, a);
     DINV_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int dinv_conv_up2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
-                                     const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream) {
+extern "C" int dinv_conv_down2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
+                                       const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream) {
+    return down2x2_bf16s_launch(gin, gout, x, w_split, cin, cout, y, DepthMap{0, 0, 0}, 0, stream);
+}
+
+extern "C" int dinv_conv_down2x2_bf16s_3d(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
+                                          const void* w_split, int32_t cin, int32_t cout, float* y, int32_t depth_out,
+                                          int32_t dz, int32_t accumulate, dinv_stream_t stream) {
+    DINV_REQUIRE(depth_out >= 1, "bad depth %d", depth_out);
+    return down2x2_bf16s_launch(gin, gout, x, w_split, cin, cout, y, DepthMap{depth_out + 2, 2 * depth_out + 2, dz}, accumulate, stream);
+}
+
+static int up2x2_bf16s_launch(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
+                              const void* w_split, int32_t cin, int32_t cout, float* y, DepthMap dm, dinv_stream_t stream) {
     if (int e = check_geom(gin)) return e;
     if (int e = check_geom(gout)) return e;
     DINV_REQUIRE(x && w_split && y, "null tensor pointer");
-    DINV_REQUIRE(gout->height == 2 * gin->height && gout->width == 2 * gin->width && gin->batch == gout->batch,
-                 "up2x2 geometry mismatch");
+    DINV_REQUIRE(gout->height == 2 * gin->height && gout->width == 2 * gin->width, "up2x2 geometry mismatch");
+    if (dm.dep_s == 0) DINV_REQUIRE(gin->batch == gout->batch, "up2x2 geometry mismatch");
+    else
+        DINV_REQUIRE(dm.dep_s >= 3 && dm.dep_l == 2 * (dm.dep_s - 2) + 2 && gin->batch % dm.dep_s == 0 &&
+                     gout->batch % dm.dep_l == 0 && gout->batch / dm.dep_l == gin->batch / dm.dep_s && (dm.dz == 0 || dm.dz == 1),
+                     "up2x2: bad depth pairing (%d, %d, %d)", dm.dep_s, dm.dep_l, dm.dz);
     DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout % 64 == 0, "bf16-split up2x2 needs cin %% 16 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
-    UpSArgs a{make_geom(*gin), make_geom(*gout), x, x2, reinterpret_cast<const uint4*>(w_split), y, cin, cout};
+    UpSArgs a{make_geom(*gin), make_geom(*gout), x, x2, reinterpret_cast<const uint4*>(w_split), y, cin, cout, dm};
     const dim3 grid((unsigned)ceil_div(gin->np, 128), (unsigned)(cout / 64));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (x2) hipLaunchKernelGGL(up2x2_bf16s_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(up2x2_bf16s_kernel<false>, grid, dim3(256), 0, st, a);
     DINV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dinv_conv_up2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
+                                     const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream) {
+    return up2x2_bf16s_launch(gin, gout, x, x2, w_split, cin, cout, y, DepthMap{0, 0, 0}, stream);
+}
+
+extern "C" int dinv_conv_up2x2_bf16s_3d(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
+                                        const void* w_split, int32_t cin, int32_t cout, float* y, int32_t depth_in, int32_t dz,
+                                        dinv_stream_t stream) {
+    DINV_REQUIRE(depth_in >= 1, "bad depth %d", depth_in);
+    return up2x2_bf16s_launch(gin, gout, x, x2, w_split, cin, cout, y, DepthMap{depth_in + 2, 2 * depth_in + 2, dz}, stream);
 }

@@ -35,6 +35,7 @@ struct WgradArgs {
     int32_t mt, nt;       // 32-wide tiles
     int32_t nsplit;
     int64_t per_split;    // pixels per slice (even)
+    DepthMap dm;          // 3-D stride-2 layers: image of S (half grid) -> image of L (full grid)
 };
 
 template <int T, bool STRIDE2>
@@ -73,8 +74,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 const int pi = (int)(p - b * a.gs.plane);
                 const int r = pi / a.gs.wp, c = pi - r * a.gs.wp;
                 // frame pixels of S are zero: send them to a valid address
-                if (r >= 1 && r <= a.gs.h && c >= 1 && c <= a.gs.w)
-                    q = b * a.gl.plane + (int64_t)(2 * (r - 1) + 1) * a.gl.wp + (2 * (c - 1) + 1);
+                const int64_t bl = depth_pair(a.dm, b);
+                if (bl >= 0 && r >= 1 && r <= a.gs.h && c >= 1 && c <= a.gs.w)
+                    q = bl * a.gl.plane + (int64_t)(2 * (r - 1) + 1) * a.gl.wp + (2 * (c - 1) + 1);
             }
         }
         const float sv = (pv && mv) ? sp[p * 8] : 0.f;
@@ -121,6 +123,14 @@ __global__ __launch_bounds__(256) void relu_backward_kernel(int64_t n4, const fl
     }
 }
 
+__global__ __launch_bounds__(256) void relu_kernel(int64_t n4, float4* __restrict__ x) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = x[i];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        x[i] = v;
+    }
+}
+
 int split_count(const dinv_act_geom* gs, int mt, int nt) {
     // enough waves for ~8 per CU, slices of at least 512 pixels, an even number of pixels per slice
     const int64_t want = (int64_t)256 * 8 / std::max(1, mt * nt);
@@ -136,9 +146,9 @@ extern "C" size_t dinv_conv_wgrad_workspace_bytes(const dinv_act_geom* gs, int32
     return (size_t)split_count(gs, mt, nt) * m * n * taps * sizeof(float);
 }
 
-extern "C" int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m,
-                               const float* l, int32_t n, int32_t taps, float* dw, int32_t accumulate, void* ws,
-                               size_t ws_bytes, dinv_stream_t stream) {
+static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m, const float* l, int32_t n,
+                        int32_t taps, float* dw, int32_t accumulate, void* ws, size_t ws_bytes, DepthMap dm,
+                        dinv_stream_t stream) {
     if (int e = check_geom(gs)) return e;
     if (int e = check_geom(gl)) return e;
     DINV_REQUIRE(s && l && dw && ws, "null pointer");
@@ -146,9 +156,13 @@ extern "C" int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl,
     if (taps == 9)
         DINV_REQUIRE(gs->height == gl->height && gs->width == gl->width && gs->batch == gl->batch && gs->cs == gl->cs,
                      "3x3 weight gradient needs both tensors on one grid");
-    else
-        DINV_REQUIRE(gl->height == 2 * gs->height && gl->width == 2 * gs->width && gs->batch == gl->batch,
-                     "2x2 weight gradient: the second tensor lives on the doubled grid");
+    else {
+        DINV_REQUIRE(gl->height == 2 * gs->height && gl->width == 2 * gs->width, "2x2 weight gradient: the second tensor lives on the doubled grid");
+        if (dm.dep_s == 0) DINV_REQUIRE(gs->batch == gl->batch, "2x2 weight gradient: batch mismatch");
+        else
+            DINV_REQUIRE(dm.dep_s >= 3 && dm.dep_l == 2 * (dm.dep_s - 2) + 2 && gs->batch % dm.dep_s == 0 && gl->batch % dm.dep_l == 0 &&
+                         gs->batch / dm.dep_s == gl->batch / dm.dep_l && (dm.dz == 0 || dm.dz == 1), "2x2x2 weight gradient: bad depth pairing");
+    }
     DINV_REQUIRE(ws_bytes >= dinv_conv_wgrad_workspace_bytes(gs, m, n, taps), "workspace too small");
     WgradArgs a{};
     a.gs = make_geom(*gs); a.gl = make_geom(*gl);
@@ -158,6 +172,7 @@ extern "C" int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl,
     a.mt = (m + 31) / 32; a.nt = (n + 31) / 32;
     a.nsplit = split_count(gs, a.mt, a.nt);
     a.per_split = (ceil_div(gs->np, a.nsplit) + 1) / 2 * 2;
+    a.dm = dm;
     const int64_t units = (int64_t)a.mt * a.nt * a.nsplit;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)ceil_div(units, 4)), block(256);
@@ -171,6 +186,19 @@ extern "C" int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl,
     return 0;
 }
 
+extern "C" int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m,
+                               const float* l, int32_t n, int32_t taps, float* dw, int32_t accumulate, void* ws,
+                               size_t ws_bytes, dinv_stream_t stream) {
+    return wgrad_launch(gs, gl, s, m, l, n, taps, dw, accumulate, ws, ws_bytes, DepthMap{0, 0, 0}, stream);
+}
+
+extern "C" int dinv_conv_wgrad_3d(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m,
+                                  const float* l, int32_t n, float* dw, int32_t accumulate, void* ws, size_t ws_bytes,
+                                  int32_t depth_s, int32_t dz, dinv_stream_t stream) {
+    DINV_REQUIRE(depth_s >= 1, "bad depth %d", depth_s);
+    return wgrad_launch(gs, gl, s, m, l, n, 4, dw, accumulate, ws, ws_bytes, DepthMap{depth_s + 2, 2 * depth_s + 2, dz}, stream);
+}
+
 extern "C" int dinv_relu_backward(int64_t n, const float* act, float* grad, dinv_stream_t stream) {
     DINV_REQUIRE(n >= 0 && n % 4 == 0, "length must be a multiple of 4");
     if (n == 0) return 0;
@@ -178,6 +206,17 @@ extern "C" int dinv_relu_backward(int64_t n, const float* act, float* grad, dinv
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n / 4, 256), 8192);
     hipLaunchKernelGGL(relu_backward_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n / 4,
                        reinterpret_cast<const float4*>(act), reinterpret_cast<float4*>(grad));
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_relu_inplace(int64_t n, float* x, dinv_stream_t stream) {
+    DINV_REQUIRE(n >= 0 && n % 4 == 0, "length must be a multiple of 4");
+    if (n == 0) return 0;
+    DINV_REQUIRE(x != nullptr, "null pointer");
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n / 4, 256), 8192);
+    hipLaunchKernelGGL(relu_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n / 4,
+                       reinterpret_cast<float4*>(x));
     DINV_CHECK_LAUNCH();
     return 0;
 }

@@ -31,6 +31,22 @@ __device__ __forceinline__ bool interior(const Geom& g, int64_t p) {
     return r >= 1 && r <= g.h && c >= 1 && c <= g.w;
 }
 
+// 3-D volumes ride the 2-D kernels as stacks of slices: a volume of D slices occupies D + 2 consecutive "images" of the
+// padded layout (one zero slice at each end), so a 3x3x3 convolution is three 3x3 launches on slice-shifted views.
+// The stride-2 layers pair slice z of the half grid with slice 2 z + dz of the full grid:
+struct DepthMap {
+    int32_t dep_s, dep_l;   // images per volume (D + 2) on the half grid / on the full grid; 0: plain 2-D
+    int32_t dz;             // depth tap (0 or 1)
+};
+// image of the full grid paired with image `b` of the half grid; -1 for a zero (padding) slice
+__device__ __forceinline__ int64_t depth_pair(const DepthMap& d, int64_t b) {
+    if (d.dep_s == 0) return b;
+    const int64_t vol = b / d.dep_s;
+    const int z = (int)(b - vol * d.dep_s);
+    if (z < 1 || z > d.dep_s - 2) return -1;
+    return vol * d.dep_l + 2 * (z - 1) + d.dz + 1;
+}
+
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load and
 // store of the wave, which the software pipelines of the conv kernels want to keep in flight across the barrier.
 __device__ __forceinline__ void lds_barrier() {

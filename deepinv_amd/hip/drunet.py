@@ -40,6 +40,10 @@ def _l():
         l.dinv_conv_wgrad_workspace_bytes.argtypes = [G, i32, i32, i32]
         l.dinv_conv_wgrad.argtypes = [G, G, vp, i32, vp, i32, i32, vp, i32, vp, ctypes.c_size_t, vp]
         l.dinv_relu_backward.argtypes = [ctypes.c_int64, vp, vp, vp]
+        l.dinv_relu_inplace.argtypes = [ctypes.c_int64, vp, vp]
+        l.dinv_conv_down2x2_bf16s_3d.argtypes = [G, G, vp, vp, i32, i32, vp, i32, i32, i32, vp]
+        l.dinv_conv_up2x2_bf16s_3d.argtypes = [G, G, vp, vp, vp, i32, i32, vp, i32, i32, vp]
+        l.dinv_conv_wgrad_3d.argtypes = [G, G, vp, i32, vp, i32, vp, i32, vp, ctypes.c_size_t, i32, i32, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
         _declared = True
     return l
@@ -306,3 +310,29 @@ def relu_backward(act, grad):
     """grad <- grad * (act > 0) in place, on whole activation buffers"""
     check(_l().dinv_relu_backward(grad.numel(), ptr(act), ptr(grad), stream_ptr(grad.device)))
     return grad
+
+
+def relu_inplace(x):
+    check(_l().dinv_relu_inplace(x.numel(), ptr(x), stream_ptr(x.device)))
+    return x
+
+
+def down2x2_bf16s_3d(gi, go, x, wsplit, cin, cout, y, depth_out, dz, accumulate):
+    """depth tap dz of a 2x2x2 stride-2 convolution (volumes as stacks of D + 2 slices); wsplit = pack_down_bf16s_weight(w[:, :, dz])"""
+    check(_l().dinv_conv_down2x2_bf16s_3d(ctypes.byref(gi), ctypes.byref(go), ptr(x), ptr(wsplit), cin, cout, ptr(y), depth_out, dz,
+                                          int(accumulate), stream_ptr(y.device)))
+
+
+def up2x2_bf16s_3d(gi, go, x, wsplit, cin, cout, y, depth_in, dz):
+    """depth tap dz of a 2x2x2 stride-2 transposed convolution: writes the slices 2 z + dz of the output volume"""
+    check(_l().dinv_conv_up2x2_bf16s_3d(ctypes.byref(gi), ctypes.byref(go), ptr(x), None, ptr(wsplit), cin, cout, ptr(y), depth_in,
+                                        dz, stream_ptr(y.device)))
+
+
+def conv_wgrad_3d(gs, gl, s, m, l, n, depth_s, dz):
+    """[m, n, 2, 2] weight gradient of depth tap dz of a 2x2x2 stride-2 layer"""
+    dw = torch.empty((m, n, 2, 2), device=s.device, dtype=torch.float32)
+    ws = torch.empty(_l().dinv_conv_wgrad_workspace_bytes(ctypes.byref(gs), m, n, 4), device=s.device, dtype=torch.uint8)
+    check(_l().dinv_conv_wgrad_3d(ctypes.byref(gs), ctypes.byref(gl), ptr(s), m, ptr(l), n, ptr(dw), 0, ptr(ws), ws.numel(), depth_s,
+                                  dz, stream_ptr(s.device)))
+    return dw

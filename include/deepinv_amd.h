@@ -195,6 +195,27 @@ int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl, const floa
                     dinv_stream_t stream);
 /* grad <- grad where act > 0 else 0 (ReLU backward on whole activation buffers; n floats, n % 4 == 0) */
 int dinv_relu_backward(int64_t n, const float* act, float* grad, dinv_stream_t stream);
+/* x <- max(x, 0) on a whole activation buffer (the ReLU of a 3-D ResBlock, applied after the three depth taps are summed) */
+int dinv_relu_inplace(int64_t n, float* x, dinv_stream_t stream);
+
+/* ---- 3-D volumes (DRUNet with dim = 3, deepinv/models/drunet.py:39-263 with Conv3d / ConvTranspose3d) on the 2-D
+ * kernels: a volume of D slices occupies D + 2 consecutive images of the padded layout (a zero slice at each end).
+ *   3x3x3 convolution = three 3x3 launches (dinv_conv3x3_bf16s / dinv_conv3x3) on views of x shifted by -1 / 0 / +1
+ *     slices (pointer + dz * plane * 8 floats), accumulated through `res1 = y`; same for its weight gradient
+ *     (dinv_conv_wgrad with a shifted L);
+ *   2x2x2 stride-2 layers pair slice z of the half grid with slice 2 z + dz of the full grid: the _3d entry points
+ *     below take the depth of the half-grid volume and the depth tap dz in {0, 1}; zero slices are skipped / kept zero. */
+int dinv_conv_down2x2_bf16s_3d(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
+                               const void* w_split, int32_t cin, int32_t cout, float* y, int32_t depth_out,
+                               int32_t dz, int32_t accumulate, dinv_stream_t stream);
+int dinv_conv_up2x2_bf16s_3d(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
+                             const void* w_split, int32_t cin, int32_t cout, float* y, int32_t depth_in, int32_t dz,
+                             dinv_stream_t stream);
+/* weight gradient of the depth tap dz of a 2x2x2 stride-2 (transposed) convolution: S on the half grid (depth_s slices
+ * per volume), L on the full grid; dw [m][n][2][2] */
+int dinv_conv_wgrad_3d(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m, const float* l,
+                       int32_t n, float* dw, int32_t accumulate, void* ws, size_t ws_bytes, int32_t depth_s,
+                       int32_t dz, dinv_stream_t stream);
 /* 2x2 stride-2 conv (downsample_strideconv, drunet.py:524-552); w: [4 taps][cin/8][cout][8] */
 int dinv_conv_down2x2(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                       const float* w, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
