@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from ..hip import HipExtensionError
 from ..hip import drunet as K
-from . import drunet_train
+from . import drunet3d, drunet_train
 from .base import Denoiser
 
 
@@ -179,6 +179,8 @@ class DRUNet(Denoiser):
             raise HipExtensionError("deepinv_amd.models.DRUNet runs only on a HIP device; there is no CPU fallback")
         if self._use_hip(x):
             run = lambda inp: self._hip_forward(inp[:, :-1], inp[:, -1:])
+        elif drunet3d.supported(self):
+            run = lambda inp: drunet3d.forward3d(self, inp)             # volumes as stacks of slices on the 2-D kernels
         elif self._use_hip_train():
             run = lambda inp: drunet_train.forward_train(self, inp)     # forward AND backward on the HIP kernels
         else:

@@ -1,0 +1,260 @@
+"""DRUNet with ``dim=3`` (Conv3d / ConvTranspose3d, deepinv/models/drunet.py:39-263) forward + backward on the 2-D HIP
+kernels - BASELINE config 4's denoiser (unfolded PGD on 3-D multi-coil MRI, deepinv/unfolded/unfolded.py:116-226).
+
+A volume of D slices lives in the padded channel-blocked activation layout as D + 2 consecutive "images" (one zero
+slice at each end), so that
+
+* a 3x3x3 convolution is three 3x3 launches on views of the input shifted by -1 / 0 / +1 slices, accumulated through the
+  kernels' residual input (``res1 = y``), followed by re-zeroing the two padding slices; the ReLU of a ResBlock is a
+  separate in-place pass (it must see the sum of the three taps);
+* the 2x2x2 stride-2 convolution / transposed convolution are two launches of the 2-D kernels with the slice pairing
+  z <-> 2 z + dz done inside the kernel (``dinv_conv_down2x2_bf16s_3d`` / ``dinv_conv_up2x2_bf16s_3d``);
+* data gradients are the same operators on re-packed weights (flipped + transposed 3x3x3 filters; down <-> up);
+* weight gradients are ``dinv_conv_wgrad`` per depth tap (shifted views) and ``dinv_conv_wgrad_3d`` for the 2x2x2 layers.
+
+Channel counts are zero-padded to multiples of 64 (the small config-4 network has 16 / 32 / 64 / 128 channels): padded
+channels stay exactly zero through convolutions, ReLUs and residual adds, and their weight gradients are sliced away.
+The forward pass of the 3x3x3 convolutions runs on the fp32 matrix cores when gradients are requested (same reasoning
+as models/drunet_train.py: ReLU masks of an fp32 reference), on the bf16-split kernels otherwise."""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from ..hip import drunet as K
+from ..hip import elementwise as ew
+
+
+def supported(model) -> bool:
+    return model.dim == 3 and len(model.nc) == 4 and os.environ.get("DINV_DRUNET3D", "hip") != "torch"
+
+
+def _r64(c):
+    return (c + 63) // 64 * 64
+
+
+class Vol:
+    """activation volume: tensor [C/8, cs, 8] with one guard plane in front, so that slice-shifted views stay inside"""
+
+    def __init__(self, lv, channels, device):
+        self.lv = lv
+        self.t = torch.zeros(((channels + 7) // 8, lv.g.cs, 8), device=device, dtype=torch.float32)
+
+    def view(self, dz=0):
+        return self.t[:, self.lv.guard + dz * self.lv.g.plane:]
+
+    def zero_pads(self):
+        lv = self.lv
+        v = self.t[:, lv.guard + lv.g.sl: lv.guard + lv.g.sl + lv.g.np].view(self.t.shape[0], lv.B, lv.D + 2, lv.g.plane, 8)
+        v[:, :, 0].zero_()
+        v[:, :, lv.D + 1].zero_()
+
+
+class Level:
+    def __init__(self, B, D, H, W):
+        self.B, self.D, self.H, self.W = B, D, H, W
+        self.g = K.geom(B * (D + 2), H, W)
+        self.guard = int(self.g.plane)
+        self.g.cs = (self.g.cs + 2 * self.guard + 3) // 4 * 4
+
+
+def _pad_w(w, d0, d1):
+    if w.shape[0] == d0 and w.shape[1] == d1:
+        return w
+    out = torch.zeros((d0, d1, *w.shape[2:]), device=w.device, dtype=torch.float32)
+    out[:w.shape[0], :w.shape[1]] = w
+    return out
+
+
+def _conv2d(g, w, x, y, res1, fp32):
+    cout, cin = w.shape[:2]
+    if cout % 64 == 0 and cin % 16 == 0 and not fp32:
+        K.conv3x3_bf16s(g, x, K.pack_bf16s_weight(w), cin, cout, y, res1=res1)
+    else:
+        wpk, ci_p, co_p = K.pack_conv3x3_weight(w)
+        K.conv3x3(g, x, wpk, ci_p, co_p, y, cout_valid=cout, res1=res1)
+
+
+def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False) -> Vol:
+    """3x3x3 convolution, stride 1, zero padding 1, no bias; w5 [Cout, Cin, 3, 3, 3] (channel counts as allocated)"""
+    y = Vol(lv, w5.shape[0], x.t.device)
+    for dz in range(3):
+        r = (res.view() if res is not None else None) if dz == 0 else y.view()
+        _conv2d(lv.g, w5[:, :, dz].contiguous(), x.view(dz - 1), y.view(), r, fp32)
+    y.zero_pads()
+    if relu:
+        K.relu_inplace(y.t)
+    return y
+
+
+def down(lvi, lvo, w5, x: Vol) -> Vol:
+    """2x2x2 stride-2 convolution; w5 [Cout, Cin, 2, 2, 2]"""
+    cout, cin = w5.shape[:2]
+    y = Vol(lvo, cout, x.t.device)
+    for dz in range(2):
+        K.down2x2_bf16s_3d(lvi.g, lvo.g, x.view(), K.pack_down_bf16s_weight(w5[:, :, dz].contiguous()), cin, cout, y.view(),
+                           lvo.D, dz, dz > 0)
+    return y
+
+
+def up(lvi, lvo, w5, x: Vol) -> Vol:
+    """2x2x2 stride-2 transposed convolution; w5 [Cin, Cout, 2, 2, 2]"""
+    cin, cout = w5.shape[:2]
+    y = Vol(lvo, cout, x.t.device)
+    for dz in range(2):
+        K.up2x2_bf16s_3d(lvi.g, lvo.g, x.view(), K.pack_up_bf16s_weight(w5[:, :, dz].contiguous()), cin, cout, y.view(), lvi.D, dz)
+    return y
+
+
+def add(lv, a: Vol, b: Vol) -> Vol:
+    out = Vol.__new__(Vol)
+    out.lv, out.t = lv, ew.lincomb(1.0, a.t, 1.0, b.t)
+    return out
+
+
+def _flip_t(w5):
+    return w5.flip(2, 3, 4).transpose(0, 1).contiguous()
+
+
+def wgrad3(lv, gout: Vol, x: Vol, m, n):
+    """[m, n, 3, 3, 3] weight gradient of conv3 (S = dL/dy, L = x shifted by the depth tap)"""
+    return torch.stack([K.conv_wgrad(lv.g, lv.g, gout.view(), m, x.view(dz - 1), n, 9) for dz in range(3)], dim=2)
+
+
+def wgrad2(lvs, lvl, small: Vol, m, large: Vol, n):
+    """[m, n, 2, 2, 2] weight gradient of a 2x2x2 stride-2 layer (S on the half grid, L on the full grid)"""
+    return torch.stack([K.conv_wgrad_3d(lvs.g, lvl.g, small.view(), m, large.view(), n, lvs.D, dz) for dz in range(2)], dim=2)
+
+
+class DRUNet3dFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, xin, *params):
+        names = [n for n, _ in model.named_parameters()]
+        nb, nc = model.nb, model.nc
+        ncp = [_r64(c) for c in nc]
+        dev = xin.device
+        B, C, D, H, Wd = xin.shape
+        if D % 8 or H % 8 or Wd % 8:
+            raise ValueError("3-D DRUNet on the HIP kernels needs depth, height and width to be multiples of 8")
+        train = any(ctx.needs_input_grad[1:])
+        f32 = train and os.environ.get("DINV_DRUNET_TRAIN_PRECISION", "fp32") == "fp32"
+        lv = [Level(B, D >> i, H >> i, Wd >> i) for i in range(4)]
+        # zero-padded weights: [cout_p, cin_p, k, k, k]
+        W = {}
+        for n, p in zip(names, params):
+            p = p.detach().float()
+            if n == "m_head.weight":
+                W[n] = _pad_w(p, ncp[0], p.shape[1])
+            elif n == "m_tail.weight":
+                W[n] = _pad_w(p, p.shape[0], ncp[0])
+            else:
+                W[n] = _pad_w(p, _r64(p.shape[0]), _r64(p.shape[1]))
+        # pack the input volume: [B, C, D, H, W] -> slices [B (D+2), C, H, W] with zero end slices
+        x2 = torch.nn.functional.pad(xin.detach().float().permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, 0, 1, 1))
+        x2 = x2.reshape(B * (D + 2), C, H, Wd).contiguous()
+        x_act = Vol(lv[0], C, dev)
+        K.pack_input(lv[0].g, x2[:, :-1].contiguous(), x2[:, -1:].contiguous(), x_act.view())
+        saved = {"x_act": x_act, "res": {}, "down_in": {}, "up_in": {}}
+
+        def res_chain(l, prefix, first, cur):
+            for k in range(first, first + nb):
+                a1 = conv3(l, W[f"{prefix}.{k}.res.0.weight"], cur, relu=True, fp32=f32)
+                out = conv3(l, W[f"{prefix}.{k}.res.2.weight"], a1, res=cur, fp32=f32)
+                if train:
+                    saved["res"][f"{prefix}.{k}"] = (cur, a1)
+                cur = out
+            return cur
+
+        x1 = conv3(lv[0], W["m_head.weight"], x_act, fp32=f32)
+        skips = [x1]
+        cur = x1
+        for i, name in enumerate(("m_down1", "m_down2", "m_down3")):
+            r = res_chain(lv[i], name, 0, cur)
+            saved["down_in"][name] = r
+            cur = down(lv[i], lv[i + 1], W[f"{name}.{nb}.weight"], r)
+            skips.append(cur)
+        cur = res_chain(lv[3], "m_body", 0, cur)
+        for i, name in zip((2, 1, 0), ("m_up3", "m_up2", "m_up1")):
+            s = add(lv[i + 1], cur, skips[i + 1])
+            saved["up_in"][name] = s
+            cur = up(lv[i + 1], lv[i], W[f"{name}.0.weight"], s)
+            cur = res_chain(lv[i], name, 1, cur)
+        s0 = add(lv[0], cur, x1)
+        saved["tail_in"] = s0
+        y_act = conv3(lv[0], W["m_tail.weight"], s0, fp32=f32)
+        y2 = torch.empty((B * (D + 2), model.out_channels, H, Wd), device=dev, dtype=torch.float32)
+        K.unpack_output(lv[0].g, y_act.view(), model.out_channels, y2)
+        y = y2.view(B, D + 2, model.out_channels, H, Wd)[:, 1:-1].permute(0, 2, 1, 3, 4).contiguous()
+        if train:
+            ctx.model, ctx.names, ctx.W, ctx.lv, ctx.saved = model, names, W, lv, saved
+            ctx.shapes = {n: tuple(p.shape) for n, p in zip(names, params)}
+            ctx.in_shape = (B, C, D, H, Wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        model, names, W, lv, saved = ctx.model, ctx.names, ctx.W, ctx.lv, ctx.saved
+        nb = model.nb
+        B, C, D, H, Wd = ctx.in_shape
+        dev = gy.device
+        want_w = any(ctx.needs_input_grad[2:])
+        dW = {}
+
+        def keep(name, full):     # slice the zero-padded gradient back to the parameter's shape
+            sh = ctx.shapes[name]
+            dW[name] = full[:sh[0], :sh[1]].contiguous()
+
+        def res_back(l, prefix, first, gout):
+            for k in range(first + nb - 1, first - 1, -1):
+                x_in, a1 = saved["res"][f"{prefix}.{k}"]
+                n1, n2 = f"{prefix}.{k}.res.0.weight", f"{prefix}.{k}.res.2.weight"
+                if want_w:
+                    keep(n2, wgrad3(l, gout, a1, W[n2].shape[0], W[n2].shape[1]))
+                gt = conv3(l, _flip_t(W[n2]), gout)
+                K.relu_backward(a1.t, gt.t)
+                if want_w:
+                    keep(n1, wgrad3(l, gt, x_in, W[n1].shape[0], W[n1].shape[1]))
+                gout = conv3(l, _flip_t(W[n1]), gt, res=gout)
+            return gout
+
+        g2 = torch.nn.functional.pad(gy.contiguous().float().permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, 0, 1, 1))
+        g2 = g2.reshape(B * (D + 2), model.out_channels, H, Wd).contiguous()
+        gy_act = Vol(lv[0], model.out_channels, dev)
+        K.pack_input(lv[0].g, g2, 0.0, gy_act.view())
+        wt = W["m_tail.weight"]
+        if want_w:
+            keep("m_tail.weight", wgrad3(lv[0], gy_act, saved["tail_in"], wt.shape[0], wt.shape[1]))
+        gcur = conv3(lv[0], _flip_t(wt), gy_act)
+        gskip = {0: gcur}
+        for i, name in zip((0, 1, 2), ("m_up1", "m_up2", "m_up3")):
+            gcur = res_back(lv[i], name, 1, gcur)
+            wu = W[f"{name}.0.weight"]        # [Cin (level i+1), Cout (level i), 2, 2, 2]
+            if want_w:
+                keep(f"{name}.0.weight", wgrad2(lv[i + 1], lv[i], saved["up_in"][name], wu.shape[0], gcur, wu.shape[1]))
+            gcur = down(lv[i], lv[i + 1], wu, gcur)
+            gskip[i + 1] = gcur
+        gcur = add(lv[3], res_back(lv[3], "m_body", 0, gcur), gskip[3])
+        for i, name in zip((2, 1, 0), ("m_down3", "m_down2", "m_down1")):
+            wd = W[f"{name}.{nb}.weight"]     # [Cout (level i+1), Cin (level i), 2, 2, 2]
+            if want_w:
+                keep(f"{name}.{nb}.weight", wgrad2(lv[i + 1], lv[i], gcur, wd.shape[0], saved["down_in"][name], wd.shape[1]))
+            gcur = up(lv[i + 1], lv[i], wd, gcur)
+            gcur = add(lv[i], res_back(lv[i], name, 0, gcur), gskip[i])
+        wh = W["m_head.weight"]
+        if want_w:
+            keep("m_head.weight", wgrad3(lv[0], gcur, saved["x_act"], wh.shape[0], wh.shape[1]))
+        gx = None
+        if ctx.needs_input_grad[1]:
+            gin = conv3(lv[0], _flip_t(wh), gcur)
+            g2 = torch.empty((B * (D + 2), C, H, Wd), device=dev, dtype=torch.float32)
+            K.unpack_output(lv[0].g, gin.view(), C, g2)
+            gx = g2.view(B, D + 2, C, H, Wd)[:, 1:-1].permute(0, 2, 1, 3, 4).contiguous()
+        ctx.saved = None
+        grads = [dW.get(n) if need else None for n, need in zip(names, ctx.needs_input_grad[2:])]
+        return (None, gx, *grads)
+
+
+def forward3d(model, xin):
+    """DRUNet(dim=3)(xin) as one autograd node; xin = cat(volume, noise map) [B, C+1, D, H, W]"""
+    return DRUNet3dFunction.apply(model, xin, *[p for _, p in model.named_parameters()])
