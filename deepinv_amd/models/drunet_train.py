@@ -33,8 +33,21 @@ from ..hip import elementwise as ew
 
 
 def supported(model) -> bool:
-    """the 2x2 kernels take 64-multiples of output channels; the default DRUNet (64,128,256,512) qualifies"""
-    return model.dim == 2 and len(model.nc) == 4 and all(c % 64 == 0 for c in model.nc)
+    """any 4-level 2-D DRUNet: channel counts that are not multiples of 64 (what the 2x2 kernels take) are zero-padded -
+    padded channels stay exactly zero through convolutions, ReLUs and residual adds, their gradients are sliced away"""
+    return model.dim == 2 and len(model.nc) == 4
+
+
+def _r64(c):
+    return (c + 63) // 64 * 64
+
+
+def _pad_w(w, d0, d1):
+    if w.shape[0] == d0 and w.shape[1] == d1:
+        return w
+    out = torch.zeros((d0, d1, *w.shape[2:]), device=w.device, dtype=torch.float32)
+    out[:w.shape[0], :w.shape[1]] = w
+    return out
 
 
 def _flip_t(w):
@@ -93,7 +106,15 @@ class DRUNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, xin, *params):
         names = [n for n, _ in model.named_parameters()]
-        W = {n: p.detach() for n, p in zip(names, params)}
+        W = {}
+        for n, p in zip(names, params):
+            p = p.detach().float()
+            if n == "m_head.weight":
+                W[n] = _pad_w(p, _r64(p.shape[0]), p.shape[1])
+            elif n == "m_tail.weight":
+                W[n] = _pad_w(p, p.shape[0], _r64(p.shape[1]))
+            else:
+                W[n] = _pad_w(p, _r64(p.shape[0]), _r64(p.shape[1]))
         nb, nc = model.nb, model.nc
         dev = xin.device
         B, C, H, Wd = xin.shape
@@ -132,6 +153,7 @@ class DRUNetFunction(torch.autograd.Function):
         y = torch.empty((B, model.out_channels, H, Wd), device=dev, dtype=torch.float32)
         K.unpack_output(g[0], y_act, model.out_channels, y)
         ctx.model, ctx.names, ctx.W, ctx.g, ctx.saved = model, names, W, g, saved
+        ctx.shapes = {n: tuple(p.shape) for n, p in zip(names, params)}
         ctx.in_channels = C
         return y
 
@@ -146,7 +168,8 @@ class DRUNetFunction(torch.autograd.Function):
         def wgrad(name, gs, gl, s, l, taps):
             if want_w:
                 m, n = W[name].shape[:2]
-                dW[name] = K.conv_wgrad(gs, gl, s, m, l, n, taps)
+                sh = ctx.shapes[name]
+                dW[name] = K.conv_wgrad(gs, gl, s, m, l, n, taps)[:sh[0], :sh[1]].contiguous()
 
         def res_back(gl, prefix, first, gout):
             for k in range(first + nb - 1, first - 1, -1):

@@ -393,3 +393,21 @@ def test_drunet3d_hip_matches_torch_graph(dev, monkeypatch):
     assert all(gw_h[n].shape == gw_t[n].shape for n in gw_t)
     worst = max((rel_err(gw_h[n], gw_t[n]), n) for n in gw_t)
     assert worst[0] < 2e-4, worst
+
+
+def test_drunet_hip_backward_padded_channels(dev, monkeypatch):
+    """a 2-D DRUNet whose channel counts are not multiples of 64 (24, 48, 96, 160): zero-padded inside the training node"""
+    import deepinv_amd as dinv
+
+    torch.manual_seed(3)
+    model = dinv.models.DRUNet(1, 1, nc=(24, 48, 96, 160), nb=2, pretrained=None).to(dev)
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.rand(2, 1, 32, 40, generator=g).to(dev)
+    sig0 = (0.05 + 0.1 * torch.rand(2, 1, 32, 40, generator=g)).to(dev)
+    v = torch.randn(2, 1, 32, 40, generator=g).to(dev)
+    y_t, gx_t, gs_t, gw_t = _grad_run(model, x0, sig0, v, "torch", monkeypatch)
+    y_h, gx_h, gs_h, gw_h = _grad_run(model, x0, sig0, v, "hip", monkeypatch)
+    assert rel_err(y_h, y_t) < 1e-4 and rel_err(gx_h, gx_t) < 1e-4 and rel_err(gs_h, gs_t) < 1e-4
+    assert all(gw_h[n].shape == gw_t[n].shape for n in gw_t)
+    worst = max((rel_err(gw_h[n], gw_t[n]), n) for n in gw_t)
+    assert worst[0] < 2e-4, worst
