@@ -12,8 +12,10 @@ slice at each end), so that
 * data gradients are the same operators on re-packed weights (flipped + transposed 3x3x3 filters; down <-> up);
 * weight gradients are ``dinv_conv_wgrad`` per depth tap (shifted views) and ``dinv_conv_wgrad_3d`` for the 2x2x2 layers.
 
-Channel counts are zero-padded to multiples of 64 (the small config-4 network has 16 / 32 / 64 / 128 channels): padded
-channels stay exactly zero through convolutions, ReLUs and residual adds, and their weight gradients are sliced away.
+Activation buffers are allocated with channel counts rounded up to 64 and every kernel gets its weights zero-padded to
+what IT needs (bf16-split kernels: Cin to 16, Cout to 64; fp32 direct kernel: Cin to 8, Cout to 32; weight gradients:
+the true counts) - the small config-4 network has 16 / 32 / 64 / 128 channels; padded channels stay exactly zero
+through convolutions, ReLUs and residual adds.
 The forward pass of the 3x3x3 convolutions runs on the fp32 matrix cores when gradients are requested (same reasoning
 as models/drunet_train.py: ReLU masks of an fp32 reference), on the bf16-split kernels otherwise."""
 from __future__ import annotations
@@ -34,12 +36,16 @@ def _r64(c):
     return (c + 63) // 64 * 64
 
 
+def _r16(c):
+    return (c + 15) // 16 * 16
+
+
 class Vol:
     """activation volume: tensor [C/8, cs, 8] with one guard plane in front, so that slice-shifted views stay inside"""
 
     def __init__(self, lv, channels, device):
         self.lv = lv
-        self.t = torch.zeros(((channels + 7) // 8, lv.g.cs, 8), device=device, dtype=torch.float32)
+        self.t = torch.zeros((_r64(channels) // 8, lv.g.cs, 8), device=device, dtype=torch.float32)
 
     def view(self, dz=0):
         return self.t[:, self.lv.guard + dz * self.lv.g.plane:]
@@ -69,15 +75,15 @@ def _pad_w(w, d0, d1):
 
 def _conv2d(g, w, x, y, res1, fp32):
     cout, cin = w.shape[:2]
-    if cout % 64 == 0 and cin % 16 == 0 and not fp32:
-        K.conv3x3_bf16s(g, x, K.pack_bf16s_weight(w), cin, cout, y, res1=res1)
-    else:
+    if cin >= 16 and cout >= 16 and not fp32:
+        K.conv3x3_bf16s(g, x, K.pack_bf16s_weight(_pad_w(w, _r64(cout), _r16(cin))), _r16(cin), _r64(cout), y, res1=res1)
+    else:           # thin head / tail layers, and the mask-exact forward of the training path
         wpk, ci_p, co_p = K.pack_conv3x3_weight(w)
         K.conv3x3(g, x, wpk, ci_p, co_p, y, cout_valid=cout, res1=res1)
 
 
 def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False) -> Vol:
-    """3x3x3 convolution, stride 1, zero padding 1, no bias; w5 [Cout, Cin, 3, 3, 3] (channel counts as allocated)"""
+    """3x3x3 convolution, stride 1, zero padding 1, no bias; w5 [Cout, Cin, 3, 3, 3] (true channel counts)"""
     y = Vol(lv, w5.shape[0], x.t.device)
     for dz in range(3):
         r = (res.view() if res is not None else None) if dz == 0 else y.view()
@@ -92,8 +98,9 @@ def down(lvi, lvo, w5, x: Vol) -> Vol:
     """2x2x2 stride-2 convolution; w5 [Cout, Cin, 2, 2, 2]"""
     cout, cin = w5.shape[:2]
     y = Vol(lvo, cout, x.t.device)
+    cop, cip = _r64(cout), _r16(cin)
     for dz in range(2):
-        K.down2x2_bf16s_3d(lvi.g, lvo.g, x.view(), K.pack_down_bf16s_weight(w5[:, :, dz].contiguous()), cin, cout, y.view(),
+        K.down2x2_bf16s_3d(lvi.g, lvo.g, x.view(), K.pack_down_bf16s_weight(_pad_w(w5[:, :, dz], cop, cip)), cip, cop, y.view(),
                            lvo.D, dz, dz > 0)
     return y
 
@@ -102,8 +109,9 @@ def up(lvi, lvo, w5, x: Vol) -> Vol:
     """2x2x2 stride-2 transposed convolution; w5 [Cin, Cout, 2, 2, 2]"""
     cin, cout = w5.shape[:2]
     y = Vol(lvo, cout, x.t.device)
+    cip, cop = _r16(cin), _r64(cout)
     for dz in range(2):
-        K.up2x2_bf16s_3d(lvi.g, lvo.g, x.view(), K.pack_up_bf16s_weight(w5[:, :, dz].contiguous()), cin, cout, y.view(), lvi.D, dz)
+        K.up2x2_bf16s_3d(lvi.g, lvo.g, x.view(), K.pack_up_bf16s_weight(_pad_w(w5[:, :, dz], cip, cop)), cip, cop, y.view(), lvi.D, dz)
     return y
 
 
@@ -132,7 +140,6 @@ class DRUNet3dFunction(torch.autograd.Function):
     def forward(ctx, model, xin, *params):
         names = [n for n, _ in model.named_parameters()]
         nb, nc = model.nb, model.nc
-        ncp = [_r64(c) for c in nc]
         dev = xin.device
         B, C, D, H, Wd = xin.shape
         if D % 8 or H % 8 or Wd % 8:
@@ -140,16 +147,7 @@ class DRUNet3dFunction(torch.autograd.Function):
         train = any(ctx.needs_input_grad[1:])
         f32 = train and os.environ.get("DINV_DRUNET_TRAIN_PRECISION", "fp32") == "fp32"
         lv = [Level(B, D >> i, H >> i, Wd >> i) for i in range(4)]
-        # zero-padded weights: [cout_p, cin_p, k, k, k]
-        W = {}
-        for n, p in zip(names, params):
-            p = p.detach().float()
-            if n == "m_head.weight":
-                W[n] = _pad_w(p, ncp[0], p.shape[1])
-            elif n == "m_tail.weight":
-                W[n] = _pad_w(p, p.shape[0], ncp[0])
-            else:
-                W[n] = _pad_w(p, _r64(p.shape[0]), _r64(p.shape[1]))
+        W = {n: p.detach().float() for n, p in zip(names, params)}      # true shapes; each kernel pads what it needs
         # pack the input volume: [B, C, D, H, W] -> slices [B (D+2), C, H, W] with zero end slices
         x2 = torch.nn.functional.pad(xin.detach().float().permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, 0, 1, 1))
         x2 = x2.reshape(B * (D + 2), C, H, Wd).contiguous()
@@ -188,7 +186,6 @@ class DRUNet3dFunction(torch.autograd.Function):
         y = y2.view(B, D + 2, model.out_channels, H, Wd)[:, 1:-1].permute(0, 2, 1, 3, 4).contiguous()
         if train:
             ctx.model, ctx.names, ctx.W, ctx.lv, ctx.saved = model, names, W, lv, saved
-            ctx.shapes = {n: tuple(p.shape) for n, p in zip(names, params)}
             ctx.in_shape = (B, C, D, H, Wd)
         return y
 
@@ -201,9 +198,8 @@ class DRUNet3dFunction(torch.autograd.Function):
         want_w = any(ctx.needs_input_grad[2:])
         dW = {}
 
-        def keep(name, full):     # slice the zero-padded gradient back to the parameter's shape
-            sh = ctx.shapes[name]
-            dW[name] = full[:sh[0], :sh[1]].contiguous()
+        def keep(name, grad):
+            dW[name] = grad
 
         def res_back(l, prefix, first, gout):
             for k in range(first + nb - 1, first - 1, -1):
