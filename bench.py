@@ -231,7 +231,20 @@ def other_config_ops(dinv, device, op_row):
     alg = B * 2 * nv * 4 + B * 2 * coils * nv * 4 + coils * nv * 8 + 2 * nv * 4
     op_row("MultiCoilMRI3D.A", "cfg4", B, lambda: phys.A(x), alg)
     op_row("MultiCoilMRI3D.A_adjoint", "cfg4", B, lambda: phys.A_adjoint(y), alg)
-    del phys, x, y, maps
+    # cfg4's loop: one training step (forward + backward) of 10-iteration unfolded PGD with the 3-D DRUNet prior
+    torch.manual_seed(0)
+    den = dinv.models.DRUNet(2, 2, nc=(16, 32, 64, 128), nb=1, pretrained=None, dim=3).to(device)
+    net = dinv.unfolded.unfolded_builder("PGD", data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den),
+                                         params_algo={"stepsize": 1.0, "g_param": 0.05, "lambda": 1.0}, max_iter=10,
+                                         trainable_params=["stepsize", "g_param"], device=device).to(device)
+
+    def train_step():
+        net.zero_grad()
+        (net(y, phys) - x).pow(2).mean().backward()
+
+    op_row("unfolded PGD x10 + DRUNet3D(16..128, nb=1): training step", "cfg4", B, train_step, 0, n=2,
+           volumes_per_s=float(B), denoiser_backend="hip (models/drunet3d.py)")
+    del phys, x, y, maps, den, net
     # cfg5: Downsampling x4 (bicubic, circular) on 3x256x256, 16 images per GPU
     B, img = 16, (3, 256, 256)
     phys = dinv.physics.Downsampling(img_size=img, filter="bicubic", factor=4, padding="circular", device=device)
