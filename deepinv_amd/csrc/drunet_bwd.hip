@@ -63,28 +63,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int64_t pbeg = (int64_t)split * a.per_split;
     const int64_t pend = min(pbeg + a.per_split, a.gs.np);
-    for (int64_t p2 = pbeg; p2 < pend; p2 += 2) {
-        const int64_t p = p2 + lhi;
-        const bool pv = p < pend;
-        int64_t q = p;                                   // pixel of L that tap (0,0) of pixel p reads
-        if (STRIDE2) {
-            q = 0;
-            if (pv) {
-                const int64_t b = p / a.gs.plane;
-                const int pi = (int)(p - b * a.gs.plane);
-                const int r = pi / a.gs.wp, c = pi - r * a.gs.wp;
-                // frame pixels of S are zero: send them to a valid address
-                const int64_t bl = depth_pair(a.dm, b);
-                if (bl >= 0 && r >= 1 && r <= a.gs.h && c >= 1 && c <= a.gs.w)
-                    q = bl * a.gl.plane + (int64_t)(2 * (r - 1) + 1) * a.gl.wp + (2 * (c - 1) + 1);
+    // U k-steps (2 pixels each) per iteration: all operand loads of the iteration are issued before its first MFMA, so
+    // one memory latency is paid per U * T MFMAs instead of per T (the loop is latency-, not bandwidth-bound)
+    constexpr int U = 4;
+    for (int64_t p2 = pbeg; p2 < pend; p2 += 2 * U) {
+        float sv[U], lv[U][T];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p2 + 2 * u + lhi;
+            const bool pv = p < pend;
+            int64_t q = pv ? p : 0;                          // pixel of L that tap (0,0) of pixel p reads
+            if (STRIDE2) {
+                q = 0;
+                if (pv) {
+                    const int64_t b = p / a.gs.plane;
+                    const int pi = (int)(p - b * a.gs.plane);
+                    const int r = pi / a.gs.wp, c = pi - r * a.gs.wp;
+                    // frame pixels (and zero slices) of S are zero: send them to a valid address
+                    const int64_t bl = depth_pair(a.dm, b);
+                    if (bl >= 0 && r >= 1 && r <= a.gs.h && c >= 1 && c <= a.gs.w)
+                        q = bl * a.gl.plane + (int64_t)(2 * (r - 1) + 1) * a.gl.wp + (2 * (c - 1) + 1);
+                }
             }
+            sv[u] = (pv && mv) ? sp[p * 8] : 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) lv[u][t] = (pv && nv) ? lp[q * 8 + off[t]] : 0.f;
         }
-        const float sv = (pv && mv) ? sp[p * 8] : 0.f;
-        float lv[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) lv[t] = (pv && nv) ? lp[q * 8 + off[t]] : 0.f;
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, lv[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[u], lv[u][t], acc[t], 0, 0, 0);
     }
     // D[i][j]: j = l31 (column n), i = (reg & 3) + 8 (reg >> 2) + 4 lhi (row m)
     float* out = a.part + (int64_t)split * a.M * a.N * T;
@@ -100,14 +108,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dw[e] (+)= sum over slices, fixed order
+// dw[e] (+)= sum over slices in a fixed order: 16 lanes share an element (lane j adds slices j, j + 16, ... in order,
+// then the 16 partial sums are added in lane order), 16 elements per workgroup
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int nsplit, int accumulate,
                                                            float* __restrict__ dw) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    float v = accumulate ? dw[e] : 0.f;
-    for (int s = 0; s < nsplit; ++s) v += part[(int64_t)s * n + e];
-    dw[e] = v;
+    __shared__ float red[16][17];
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t e = (int64_t)blockIdx.x * 16 + el;
+    float v = 0.f;
+    if (e < n)
+        for (int s = grp; s < nsplit; s += 16) v += part[(int64_t)s * n + e];
+    red[grp][el] = v;
+    __syncthreads();
+    if (grp == 0 && e < n) {
+        float t = accumulate ? dw[e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][el];
+        dw[e] = t;
+    }
 }
 
 // g <- g where a > 0, else 0   (backward of the ReLU between the two convolutions of a ResBlock, drunet.py:403-434)
@@ -171,7 +189,7 @@ static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const 
     a.cs_alloc = (m + 7) / 8 * 8; a.cl_alloc = (n + 7) / 8 * 8;
     a.mt = (m + 31) / 32; a.nt = (n + 31) / 32;
     a.nsplit = split_count(gs, a.mt, a.nt);
-    a.per_split = (ceil_div(gs->np, a.nsplit) + 1) / 2 * 2;
+    a.per_split = (ceil_div(gs->np, a.nsplit) + 7) / 8 * 8;     // whole iterations of 4 k-steps
     a.dm = dm;
     const int64_t units = (int64_t)a.mt * a.nt * a.nsplit;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -180,7 +198,7 @@ static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const 
     else hipLaunchKernelGGL((wgrad_kernel<4, true>), grid, block, 0, st, a);
     DINV_CHECK_LAUNCH();
     const int64_t ne = (int64_t)m * n * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st, a.part, ne, a.nsplit,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ne, 16)), dim3(256), 0, st, a.part, ne, a.nsplit,
                        accumulate, dw);
     DINV_CHECK_LAUNCH();
     return 0;
