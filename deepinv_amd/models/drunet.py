@@ -121,7 +121,9 @@ class DRUNet(Denoiser):
         self.m_down1 = nn.Sequential(*[ResBlock(nc[0], dim) for _ in range(nb)], C(nc[0], nc[1], 2, 2, 0, bias=False))
         self.m_down2 = nn.Sequential(*[ResBlock(nc[1], dim) for _ in range(nb)], C(nc[1], nc[2], 2, 2, 0, bias=False))
         self.m_down3 = nn.Sequential(*[ResBlock(nc[2], dim) for _ in range(nb)], C(nc[2], nc[3], 2, 2, 0, bias=False))
-        self.m_body = nn.Sequential(*[ResBlock(nc[3], dim) for _ in range(nb)])
+        # a single module is not wrapped (the reference's `sequential` helper, drunet.py:279-297): with nb = 1 the body's
+        # state_dict keys are m_body.res.{0,2}.weight
+        self.m_body = ResBlock(nc[3], dim) if nb == 1 else nn.Sequential(*[ResBlock(nc[3], dim) for _ in range(nb)])
         self.m_up3 = nn.Sequential(T(nc[3], nc[2], 2, 2, 0, bias=False), *[ResBlock(nc[2], dim) for _ in range(nb)])
         self.m_up2 = nn.Sequential(T(nc[2], nc[1], 2, 2, 0, bias=False), *[ResBlock(nc[1], dim) for _ in range(nb)])
         self.m_up1 = nn.Sequential(T(nc[1], nc[0], 2, 2, 0, bias=False), *[ResBlock(nc[0], dim) for _ in range(nb)])
@@ -227,7 +229,8 @@ class DRUNet(Denoiser):
             wd = seq[-1].weight.to(device)
             e[name + "_s"] = K.pack_down_weight(wd)
             e[name + "_sb"] = K.pack_down_bf16s_weight(wd) if (wd.shape[0] % 64 == 0 and wd.shape[1] % 16 == 0) else None
-        e["m_body"] = [(c3(b.res[0]), c3(b.res[2])) for b in self.m_body]
+        body = [self.m_body] if isinstance(self.m_body, ResBlock) else list(self.m_body)
+        e["m_body"] = [(c3(b.res[0]), c3(b.res[2])) for b in body]
         for name in ("m_up3", "m_up2", "m_up1"):
             seq = getattr(self, name)
             wu = seq[0].weight.to(device)

@@ -121,6 +121,11 @@ def add(lv, a: Vol, b: Vol) -> Vol:
     return out
 
 
+def _blk(model, prefix, k):
+    """parameter-name prefix of ResBlock k of a stage (with nb = 1 the body is a bare ResBlock: 'm_body', not 'm_body.0')"""
+    return prefix if (prefix == "m_body" and model.nb == 1) else f"{prefix}.{k}"
+
+
 def _flip_t(w5):
     return w5.flip(2, 3, 4).transpose(0, 1).contiguous()
 
@@ -157,8 +162,8 @@ class DRUNet3dFunction(torch.autograd.Function):
 
         def res_chain(l, prefix, first, cur):
             for k in range(first, first + nb):
-                a1 = conv3(l, W[f"{prefix}.{k}.res.0.weight"], cur, relu=True, fp32=f32)
-                out = conv3(l, W[f"{prefix}.{k}.res.2.weight"], a1, res=cur, fp32=f32)
+                a1 = conv3(l, W[f"{_blk(model, prefix, k)}.res.0.weight"], cur, relu=True, fp32=f32)
+                out = conv3(l, W[f"{_blk(model, prefix, k)}.res.2.weight"], a1, res=cur, fp32=f32)
                 if train:
                     saved["res"][f"{prefix}.{k}"] = (cur, a1)
                 cur = out
@@ -204,7 +209,7 @@ class DRUNet3dFunction(torch.autograd.Function):
         def res_back(l, prefix, first, gout):
             for k in range(first + nb - 1, first - 1, -1):
                 x_in, a1 = saved["res"][f"{prefix}.{k}"]
-                n1, n2 = f"{prefix}.{k}.res.0.weight", f"{prefix}.{k}.res.2.weight"
+                n1, n2 = f"{_blk(model, prefix, k)}.res.0.weight", f"{_blk(model, prefix, k)}.res.2.weight"
                 if want_w:
                     keep(n2, wgrad3(l, gout, a1, W[n2].shape[0], W[n2].shape[1]))
                 gt = conv3(l, _flip_t(W[n2]), gout)

@@ -50,6 +50,11 @@ def _pad_w(w, d0, d1):
     return out
 
 
+def _blk(model, prefix, k):
+    """parameter-name prefix of ResBlock k of a stage (with nb = 1 the body is a bare ResBlock: 'm_body', not 'm_body.0')"""
+    return prefix if (prefix == "m_body" and model.nb == 1) else f"{prefix}.{k}"
+
+
 def _flip_t(w):
     """filter of the data-gradient convolution: [Cout,Cin,3,3] -> [Cin,Cout,3,3], taps reversed"""
     return w.flip(2, 3).transpose(0, 1).contiguous()
@@ -127,8 +132,8 @@ class DRUNetFunction(torch.autograd.Function):
 
         def res_chain(gl, prefix, first, cur):
             for k in range(first, first + nb):
-                a1 = _conv3(gl, W[f"{prefix}.{k}.res.0.weight"], cur, relu=True, fp32=f32)
-                out = _conv3(gl, W[f"{prefix}.{k}.res.2.weight"], a1, res1=cur, fp32=f32)
+                a1 = _conv3(gl, W[f"{_blk(model, prefix, k)}.res.0.weight"], cur, relu=True, fp32=f32)
+                out = _conv3(gl, W[f"{_blk(model, prefix, k)}.res.2.weight"], a1, res1=cur, fp32=f32)
                 saved["res"][f"{prefix}.{k}"] = (cur, a1)
                 cur = out
             return cur
@@ -174,11 +179,11 @@ class DRUNetFunction(torch.autograd.Function):
         def res_back(gl, prefix, first, gout):
             for k in range(first + nb - 1, first - 1, -1):
                 x_in, a1 = saved["res"][f"{prefix}.{k}"]
-                w1, w2 = W[f"{prefix}.{k}.res.0.weight"], W[f"{prefix}.{k}.res.2.weight"]
-                wgrad(f"{prefix}.{k}.res.2.weight", gl, gl, gout, a1, 9)
+                w1, w2 = W[f"{_blk(model, prefix, k)}.res.0.weight"], W[f"{_blk(model, prefix, k)}.res.2.weight"]
+                wgrad(f"{_blk(model, prefix, k)}.res.2.weight", gl, gl, gout, a1, 9)
                 gt = _conv3(gl, _flip_t(w2), gout)
                 K.relu_backward(a1, gt)
-                wgrad(f"{prefix}.{k}.res.0.weight", gl, gl, gt, x_in, 9)
+                wgrad(f"{_blk(model, prefix, k)}.res.0.weight", gl, gl, gt, x_in, 9)
                 gout = _conv3(gl, _flip_t(w1), gt, res1=gout)
             return gout
 

@@ -78,3 +78,31 @@ def drunet(sd, x, sigma, nb=4):
         m = torch.full((x.shape[0], 1, *x.shape[2:]), float(sigma), dtype=x.dtype)
     assert all(s % 8 == 0 and s > 31 for s in x.shape[2:]), "oracle restates the shape-safe branch only"
     return forward_unet(sd, torch.cat((x, m), 1), nb)
+
+
+def forward_unet_nd(sd, x0, nb, dim):
+    """forward_unet (drunet.py:200-210) for dim = 2 or 3 (Conv{dim}d / ConvTranspose{dim}d) with the reference's
+    state_dict naming, including its `sequential` rule (drunet.py:279-297): a stage made of ONE module is that module
+    itself, so with nb = 1 the body's keys are m_body.res.{0,2}.weight"""
+    conv = {2: F.conv2d, 3: F.conv3d}[dim]
+    convt = {2: F.conv_transpose2d, 3: F.conv_transpose3d}[dim]
+
+    def res(prefix, x):
+        r = F.relu(conv(x, sd[prefix + ".res.0.weight"], padding=1))
+        return x + conv(r, sd[prefix + ".res.2.weight"], padding=1)
+
+    x1 = conv(x0, sd["m_head.weight"], padding=1)
+    skips = [x1]
+    x = x1
+    for name in ("m_down1", "m_down2", "m_down3"):
+        for b in range(nb):
+            x = res(f"{name}.{b}", x)
+        x = conv(x, sd[f"{name}.{nb}.weight"], stride=2)
+        skips.append(x)
+    for b in range(nb):
+        x = res("m_body" if nb == 1 else f"m_body.{b}", x)
+    for lvl, name in zip((3, 2, 1), ("m_up3", "m_up2", "m_up1")):
+        x = convt(x + skips[lvl], sd[f"{name}.0.weight"], stride=2)
+        for b in range(1, nb + 1):
+            x = res(f"{name}.{b}", x)
+    return conv(x + skips[0], sd["m_tail.weight"], padding=1)
