@@ -349,6 +349,59 @@ __global__ __launch_bounds__(256) void tail3x3_kernel(Geom g, const float* __res
     st4(y + (g.sl + p) * 8, make_float4(o4[0], o4[1], o4[2], o4[3]));
 }
 
+// Row-blocked variant: one lane produces RB = 4 vertically adjacent pixels of one column, so the 3 x 3 neighbourhoods of
+// its pixels share input rows: 6 rows x 3 columns of loads per channel block instead of 4 x 9 (the one-pixel form is
+// bound by the vector cache: 9 taps x 64 channels x 2 tensors per pixel); lanes still run along the row (coalesced).
+template <int COUT>
+__global__ __launch_bounds__(256) void tail3x3_rows_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ x2,
+                                                           const float* __restrict__ w, float* __restrict__ y, int ncb) {
+    constexpr int RB = 4;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);                   // padded column
+    const int rg = blockIdx.y * 4 + (threadIdx.x >> 6);                   // group of RB image rows
+    const int b = blockIdx.z;
+    const int r0 = 1 + rg * RB;                                           // first padded row of the group
+    if (c < 1 || c > g.w || r0 > g.h) return;
+    float acc[RB][COUT];
+#pragma unroll
+    for (int k = 0; k < RB; ++k)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[k][co] = 0.f;
+    const int64_t p0 = (int64_t)b * g.plane + (int64_t)r0 * g.wp + c;       // pixel (r0, c)
+    for (int cb = 0; cb < ncb; ++cb) {
+        const int64_t base = ((int64_t)cb * g.cs + g.sl + p0) * 8;
+#pragma unroll
+        for (int rr = -1; rr <= RB; ++rr) {                               // input rows r0 - 1 .. r0 + RB
+            if (r0 + rr > g.h + 1) continue;                              // below the zero frame: nothing to read
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int64_t o = base + ((int64_t)rr * g.wp + dc) * 8;
+                float4 a = ld4(x + o), bq = ld4(x + o + 4);
+                if (x2) { a = add4(a, ld4(x2 + o)); bq = add4(bq, ld4(x2 + o + 4)); }
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {                            // output row r0 + k uses it as tap dy = rr - k + 1
+                    const int dy = rr - k + 1;
+                    if (dy < 0 || dy > 2) continue;
+                    const int t = dy * 3 + dc + 1;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) {
+                        const float* wv = w + (((int64_t)cb * 9 + t) * COUT + co) * 8;   // uniform: scalar loads
+                        acc[k][co] += a.x * wv[0] + a.y * wv[1] + a.z * wv[2] + a.w * wv[3] + bq.x * wv[4] + bq.y * wv[5] +
+                                      bq.z * wv[6] + bq.w * wv[7];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+        if (r0 + k > g.h) break;
+        float o4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) o4[co] = acc[k][co];
+        st4(y + (g.sl + p0 + (int64_t)k * g.wp) * 8, make_float4(o4[0], o4[1], o4[2], o4[3]));
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // NCHW <-> blocked padded rows.  pack also writes the noise-level map channel (drunet.py:238-251:
 // x = cat(x, sigma map)); one thread per pixel writes the whole first channel block (cin+1 <= 8).
@@ -436,9 +489,21 @@ extern "C" int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const f
     if (int e = check_geom(g)) return e;
     DINV_REQUIRE(x && w_tail && y, "null tensor pointer");
     DINV_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= 1 && cout <= 4, "tail conv needs cin %% 8 == 0 and 1 <= cout <= 4 (got %d,%d)", cin, cout);
-    const dim3 grid((unsigned)ceil_div(g->np, 256)), block(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const Geom gg = make_geom(*g);
+    static const bool one_pixel = getenv("DINV_TAIL_ONE_PIXEL") != nullptr;   // the first form, kept for comparison
+    if (!one_pixel && g->batch <= 65535) {
+        const dim3 rgrid((unsigned)ceil_div(g->wp, 64), (unsigned)ceil_div(ceil_div(g->height, 4), 4), (unsigned)g->batch);
+        switch (cout) {
+            case 1: hipLaunchKernelGGL(tail3x3_rows_kernel<1>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;
+            case 2: hipLaunchKernelGGL(tail3x3_rows_kernel<2>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;
+            case 3: hipLaunchKernelGGL(tail3x3_rows_kernel<3>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;
+            default: hipLaunchKernelGGL(tail3x3_rows_kernel<4>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;
+        }
+        DINV_CHECK_LAUNCH();
+        return 0;
+    }
+    const dim3 grid((unsigned)ceil_div(g->np, 256)), block(256);
     switch (cout) {
         case 1: hipLaunchKernelGGL(tail3x3_kernel<1>, grid, block, 0, st, gg, x, x2, w_tail, y, cin / 8); break;
         case 2: hipLaunchKernelGGL(tail3x3_kernel<2>, grid, block, 0, st, gg, x, x2, w_tail, y, cin / 8); break;
