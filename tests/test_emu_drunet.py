@@ -188,3 +188,117 @@ def test_relu_backward():
     ref = g * (a > 0)
     E.check(E.lib().dinv_relu_backward(ctypes.c_int64(1000), E.p(a), E.p(g), None))
     assert torch.equal(g, ref)
+
+
+# ---- 3-D volumes as stacks of slices (models/drunet3d.py): D + 2 images per volume, zero slices at both ends
+def vol_to_act(t, g):
+    """[B, C, D, H, W] -> activation buffer over B (D + 2) images"""
+    B, C, D, H, W = t.shape
+    t2 = torch.nn.functional.pad(t.permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, 0, 1, 1)).reshape(B * (D + 2), C, H, W)
+    return to_act(t2, g)
+
+
+def act_to_vol(a, g, C, B, D):
+    t2 = from_act(a, g, C)                           # [B (D + 2), C, H, W]
+    return t2.view(B, D + 2, C, g.height, g.width)
+
+
+@pytest.mark.parametrize("B,D,H,W,cin,cout", [(1, 2, 4, 6, 16, 64), (2, 4, 6, 4, 32, 64)])
+def test_down_and_up_2x2x2_with_depth_pairing(B, D, H, W, cin, cout):
+    """dinv_conv_down2x2_bf16s_3d / dinv_conv_up2x2_bf16s_3d (two depth taps, slice pairing z <-> 2 z + dz inside the
+    kernel, zero slices kept zero) against conv3d / conv_transpose3d with 2x2x2 kernels and stride 2"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_down_bf16s_weight, pack_up_bf16s_weight
+
+    gen = torch.Generator().manual_seed(D * H + cin)
+    l = E.lib()
+    # ---- down: [B, cin, 2D, 2H, 2W] -> [B, cout, D, H, W]
+    x = torch.randn(B, cin, 2 * D, 2 * H, 2 * W, generator=gen)
+    w = torch.randn(cout, cin, 2, 2, 2, generator=gen) / (8 * cin) ** 0.5
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), stride=2)
+    gi, go = geom(B * (2 * D + 2), 2 * H, 2 * W), geom(B * (D + 2), H, W)
+    xa = vol_to_act(x, gi)
+    ya = torch.zeros((cout // 8, go.cs, 8))
+    for dz in range(2):
+        wp = pack_down_bf16s_weight(w[:, :, dz].contiguous())
+        E.check(l.dinv_conv_down2x2_bf16s_3d(ctypes.byref(gi), ctypes.byref(go), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin,
+                                             cout, E.p(ya), D, dz, int(dz > 0), None))
+    out = act_to_vol(ya, go, cout, B, D)
+    assert float(out[:, 0].abs().max()) == 0 and float(out[:, D + 1].abs().max()) == 0        # zero slices stay zero
+    got = out[:, 1:-1].permute(0, 2, 1, 3, 4)
+    assert float((got.double() - ref).norm() / ref.norm()) < 2e-5
+    # ---- up: [B, cin, D, H, W] -> [B, cout, 2D, 2H, 2W]
+    x = torch.randn(B, cin, D, H, W, generator=gen)
+    w = torch.randn(cin, cout, 2, 2, 2, generator=gen) / cin ** 0.5
+    ref = torch.nn.functional.conv_transpose3d(x.double(), w.double(), stride=2)
+    xa = vol_to_act(x, go)
+    ya = torch.zeros((cout // 8, gi.cs, 8))
+    for dz in range(2):
+        wp = pack_up_bf16s_weight(w[:, :, dz].contiguous())
+        E.check(l.dinv_conv_up2x2_bf16s_3d(ctypes.byref(go), ctypes.byref(gi), E.p(xa), None, ctypes.c_void_p(wp.data_ptr()), cin,
+                                           cout, E.p(ya), D, dz, None))
+    out = act_to_vol(ya, gi, cout, B, 2 * D)
+    assert float(out[:, 0].abs().max()) == 0 and float(out[:, 2 * D + 1].abs().max()) == 0
+    got = out[:, 1:-1].permute(0, 2, 1, 3, 4)
+    assert float((got.double() - ref).norm() / ref.norm()) < 2e-5
+
+
+@pytest.mark.parametrize("up", [False, True])
+def test_wgrad_2x2x2_depth_tap(up):
+    """dinv_conv_wgrad_3d: weight gradient of one depth tap of the 2x2x2 stride-2 (transposed) convolution vs autograd"""
+    B, D, H, W, cs, cl = 2, 2, 4, 4, 32, 16
+    gen = torch.Generator().manual_seed(int(up) + 5)
+    small = torch.randn(B, cs, D, H, W, generator=gen)
+    big = torch.randn(B, cl, 2 * D, 2 * H, 2 * W, generator=gen)
+    w = torch.zeros(cs, cl, 2, 2, 2, dtype=torch.float64, requires_grad=True)
+    if up:
+        (torch.nn.functional.conv_transpose3d(small.double(), w, stride=2) * big.double()).sum().backward()
+    else:
+        (torch.nn.functional.conv3d(big.double(), w, stride=2) * small.double()).sum().backward()
+    gs, gl = geom(B * (D + 2), H, W), geom(B * (2 * D + 2), 2 * H, 2 * W)
+    sa, la = vol_to_act(small, gs), vol_to_act(big, gl)
+    lib = E.lib()
+    lib.dinv_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    for dz in range(2):
+        dw = torch.full((cs, cl, 2, 2), float("nan"))
+        ws = torch.zeros(lib.dinv_conv_wgrad_workspace_bytes(ctypes.byref(gs), cs, cl, 4), dtype=torch.uint8)
+        E.check(lib.dinv_conv_wgrad_3d(ctypes.byref(gs), ctypes.byref(gl), E.p(sa), cs, E.p(la), cl, E.p(dw), 0, E.p(ws),
+                                       ctypes.c_size_t(ws.numel()), D, dz, None))
+        assert float((dw.double() - w.grad[:, :, dz]).norm() / w.grad[:, :, dz].norm()) < 1e-5
+
+
+def test_relu_inplace():
+    x = torch.randn(1000)
+    ref = x.clamp(min=0)
+    E.check(E.lib().dinv_relu_inplace(ctypes.c_int64(1000), E.p(x), None))
+    assert torch.equal(x, ref)
+
+
+def test_conv3x3x3_as_three_shifted_2d_launches():
+    """the composition models/drunet3d.py uses for a 3x3x3 convolution: three launches of the bf16-split 3x3 kernel on
+    views of the input shifted by -1 / 0 / +1 slices (one guard plane in front of the buffer), accumulated IN PLACE
+    through the residual input (res1 = y), against conv3d"""
+    B, C, D, H, W, cout = 1, 16, 3, 6, 8, 64
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(B, C, D, H, W, generator=gen)
+    w = torch.randn(cout, C, 3, 3, 3, generator=gen) / (27 * C) ** 0.5
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
+    g = geom(B * (D + 2), H, W)
+    guard = g.plane
+    g.cs = (g.cs + 2 * guard + 3) // 4 * 4                   # room for the slice-shifted views
+    xa = torch.zeros(C // 8, g.cs, 8)
+    t2 = torch.nn.functional.pad(x.permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, 0, 1, 1)).reshape(B * (D + 2), C, H, W)
+    frames = xa[:, guard + g.sl: guard + g.sl + g.np].view(-1, B * (D + 2), g.hp, g.wp, 8)
+    frames[:, :, 1:H + 1, 1:W + 1] = t2.view(B * (D + 2), -1, 8, H, W).permute(1, 0, 3, 4, 2)
+    ya = torch.zeros(cout // 8, g.cs, 8)
+    l = E.lib()
+    for dz in range(3):
+        xv = xa[:, guard + (dz - 1) * g.plane:]
+        yv = ya[:, guard:]
+        wp = pack(w[:, :, dz].contiguous())
+        E.check(l.dinv_conv3x3_bf16s(ctypes.byref(g), ctypes.c_void_p(xv.data_ptr()), ctypes.c_void_p(wp.data_ptr()), C, cout,
+                                     ctypes.c_void_p(yv.data_ptr()), ctypes.c_void_p(yv.data_ptr()) if dz else None, 0, None))
+    out = ya[:, guard + g.sl: guard + g.sl + g.np].view(-1, B, D + 2, g.hp, g.wp, 8)[:, :, 1:-1, 1:H + 1, 1:W + 1]
+    got = out.permute(1, 0, 5, 2, 3, 4).reshape(B, cout, D, H, W)
+    assert float((got.double() - ref).norm() / ref.norm()) < 2e-5
