@@ -1,3 +1,7 @@
+"""DRUNet gradients of the two GPU paths (DINV_DRUNET_TRAIN=torch: PyTorch-ROCm graph / MIOpen; hip: models/drunet_train.py)
+against an fp64 CPU run of the same module: image + noise-map gradient and the worst / median weight-gradient error.
+Usage: python scripts/check_drunet_grads.py [resblock gain, e.g. 1.0]   (DINV_DRUNET_TRAIN_PRECISION=bf16s for the
+inference kernels in the forward pass: shows the ReLU-mask flips discussed in models/drunet_train.py)"""
 import copy, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
