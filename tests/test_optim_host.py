@@ -303,3 +303,37 @@ def test_least_squares_solvers_match_reference_golden(solver):
                                          gamma=gamma, solver=solver, max_iter=200, tol=1e-10)
             ref = d[f"{tag}_{solver}_{gname}"]
             assert torch.allclose(x, ref, rtol=1e-7, atol=1e-9), (tag, solver, gname, float((x - ref).abs().max()))
+
+
+def test_fan_beam_host_tables_reproduce_the_reference_grid():
+    """deepinv_amd.hip.radon.fan_tables (pure torch, host side) + the kernels' coordinate formula
+    R(theta) (xm_i, yd_d * sc_i) == fan_beam_grid of the reference (functional/radon.py:16-52, restated and golden-pinned
+    in oracle.physics_cpu.fan_grid), for the default and a custom geometry"""
+    import torch
+    from deepinv_amd.hip.radon import fan_tables
+    from oracle import physics_cpu as O
+
+    for W, G, fan in ((16, 23, None), (40, 57, {"pixel_spacing": 0.05, "source_radius": 3.0, "detector_radius": 5.0,
+                                                "n_detector_pixels": 47, "detector_spacing": 0.11})):
+        fp, xm, sc, yd = fan_tables(G, W, fan)
+        assert fp == O.fan_parameters_filled(W, fan)
+        for deg in (0.0, 33.0, 91.0, 270.5):
+            th = O._deg2rad(torch.tensor(deg))
+            ref = O.fan_grid(th, G, fp)[0]                       # [G (march), n_det, 2]
+            c, s = th.cos(), th.sin()
+            px = xm[:, None].expand(-1, yd.numel())
+            py = yd[None, :] * sc[:, None]
+            mine = torch.stack((c * px + s * py, -s * px + c * py), dim=-1)
+            assert float((mine - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+def test_overlap_tiling_edge_cases():
+    from deepinv_amd.distributed import OverlapTiling
+
+    t = OverlapTiling((1, 1, 10, 50), patch_size=64, overlap=4)          # patch larger than the signal: one window
+    assert len(t) == 1 and t.patch == [10, 50]
+    t = OverlapTiling((2, 3, 40), patch_size=16, overlap=3, tiling_dims=-1)       # 1-D tiling
+    assert len(t) == 3 and [w[0][:1] for w in t.windows] == [(0,), (16,), (24,)]   # last window shifted inwards
+    import pytest
+    with pytest.raises(ValueError):
+        OverlapTiling((1, 1, 32, 32), patch_size=(16, 16, 16), overlap=2, tiling_dims=(-2, -1))
