@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);
+int dinv_version(void);   /* 2 = this header (1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
