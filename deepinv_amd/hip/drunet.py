@@ -36,6 +36,7 @@ def _l():
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_down2x2_bf16s.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2_bf16s.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
+        l.dinv_conv3x3_wbf16.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
         l.dinv_conv_wgrad_workspace_bytes.argtypes = [G, i32, i32, i32]
         l.dinv_conv_wgrad.argtypes = [G, G, vp, i32, vp, i32, i32, vp, i32, vp, ctypes.c_size_t, vp]
@@ -120,6 +121,20 @@ def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
     u = (G @ w.detach().double() @ G.t()).float().reshape(cout // 64, 64, cin // 8, 8, 16)
     return u.permute(0, 2, 3, 1, 4).contiguous()
+
+
+def pack_wbf16_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> U = G g G^T (fp64, rounded to fp32 once) split into hi = bf16(U), lo = bf16(U - hi), packed for
+    csrc/drunet_wbf16.hip: [Cout/64][Cin/16][xi 16][plane 2][cblk 2][co 64][ci 8] (bf16), xi = 4 * row + col"""
+    cout, cin = w.shape[:2]
+    if cin % 16 or cout % 64:
+        raise ValueError(f"Winograd bf16-split packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
+    u = (G @ w.detach().double() @ G.t()).float().reshape(cout, cin, 16)
+    hi = u.bfloat16()
+    lo = (u - hi.float()).bfloat16()
+    planes = torch.stack((hi, lo)).reshape(2, cout // 64, 64, cin // 16, 2, 8, 16)      # pl, ct, co, s, cblk, ci, xi
+    return planes.permute(1, 3, 6, 0, 4, 2, 5).contiguous()                             # ct, s, xi, pl, cblk, co, ci
 
 
 def pack_down_weight(w: torch.Tensor) -> torch.Tensor:
@@ -257,6 +272,21 @@ def conv3x3_bf16s(g, x, wsplit, cin, cout, y, res1=None, relu=False):
         e1.record()
         fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
         _prof.append((e0, e1, "conv3x3_bf16s_kernel", fl, 3.0 * fl))
+
+
+def conv3x3_wbf16(g, x, usplit, cin, cout, y, res1=None, relu=False):
+    """OPT-IN, not yet measured on hardware: y = [relu](conv3x3(x)) (+res1) as Winograd F(2x2,3x3) on the bf16 matrix cores
+    with the two-part operand split (csrc/drunet_wbf16.hip); usplit from pack_wbf16_weight"""
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_l().dinv_conv3x3_wbf16(ctypes.byref(g), ptr(x), ptr(usplit), cin, cout, ptr(y), ptr(res1), int(relu),
+                                  stream_ptr(y.device)))
+    if _prof is not None:
+        e1.record()
+        fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
+        tiles = g.batch * ((g.height + 1) // 2) * ((g.width + 1) // 2)
+        _prof.append((e0, e1, "conv3x3_wbf16_kernel", fl, 3.0 * 2.0 * 16 * cin * cout * tiles))
 
 
 def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):

@@ -44,10 +44,12 @@ DEFAULT_RESBLOCK_CONV = "bf16s"
 def _resblock_conv() -> str:
     """which kernel runs the 56 ResBlock convolutions: 'bf16s' = two-part bf16 operand split on the bf16 matrix cores,
     pipelined (csrc/drunet_bf16s.hip); 'wino' = fp32 Winograd F(2x2,3x3) on the fp32 matrix cores; 'direct' = fp32
-    implicit GEMM.  DINV_DRUNET_CONV overrides the default."""
+    implicit GEMM; 'wbf16' = OPT-IN Winograd F(2x2,3x3) on the bf16 matrix cores with the operand split
+    (csrc/drunet_wbf16.hip: validated on the host emulation, not yet measured on hardware).  DINV_DRUNET_CONV overrides
+    the default."""
     v = os.environ.get("DINV_DRUNET_CONV", DEFAULT_RESBLOCK_CONV)
-    if v not in ("bf16s", "wino", "direct"):
-        raise ValueError(f"DINV_DRUNET_CONV must be bf16s, wino or direct, got {v}")
+    if v not in ("bf16s", "wino", "direct", "wbf16"):
+        raise ValueError(f"DINV_DRUNET_CONV must be bf16s, wino, direct or wbf16, got {v}")
     return v
 
 
@@ -204,7 +206,7 @@ class DRUNet(Denoiser):
                 + tuple(p.data_ptr() for p in self.parameters()))
 
     def _prepare(self, device):
-        ver = self._weights_version()
+        ver = (self._weights_version(), _resblock_conv())     # the packs depend on the selected ResBlock kernel
         if self._engine is not None and self._engine["ver"] == ver and self._engine["device"] == device:
             return self._engine
         e = {"ver": ver, "device": device, "ws": {}}
@@ -217,7 +219,8 @@ class DRUNet(Denoiser):
             wino = K.pack_winograd_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0 and w.shape[1] >= 32) else None
             split = K.pack_bf16x3_weight(w) if (_bf16_split_mode() and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0) else None
             bf16s = K.pack_bf16s_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0) else None
-            return (p64, p32, wino, split, bf16s)
+            wbf16 = K.pack_wbf16_weight(w) if (_resblock_conv() == "wbf16" and bf16s is not None) else None
+            return (p64, p32, wino, split, bf16s, wbf16)
 
         e["head"] = c3(self.m_head)
         e["tail"] = c3(self.m_tail)
@@ -275,6 +278,9 @@ class DRUNet(Denoiser):
             K.conv3x3_bf16x3(g, x, pk[3], pk[0][1], pk[0][2], y, res1=res1, relu=relu, planes=_bf16_split_mode())
             return
         mode = _resblock_conv()
+        if mode == "wbf16" and len(pk) > 5 and pk[5] is not None:
+            K.conv3x3_wbf16(g, x, pk[5], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
+            return
         if mode == "bf16s" and len(pk) > 4 and pk[4] is not None:
             # 512-pixel x 64-cout workgroups: keep it only where they fill the chip (small per-GPU batches at the
             # coarse U-Net levels fall through to the Winograd kernel)

@@ -169,6 +169,12 @@ int dinv_conv3x3_bf16x3(const dinv_act_geom* g, const float* x, const void* w_sp
 int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin, int32_t cout,
                        float* y, const float* res1, int32_t relu, dinv_stream_t stream);
 
+/* OPT-IN, validated on the host emulation only (no MI355X measurement yet): the same 3x3 convolution as Winograd
+ * F(2x2,3x3) on the bf16 matrix cores with the two-part operand split: 2.25x fewer MFMAs than dinv_conv3x3_bf16s.
+ * u_split: U = G g G^T (fp64 -> fp32) as hi / lo bf16, [Cout/64][Cin/16][xi 16][plane 2][cblk 2][co 64][ci 8]. */
+int dinv_conv3x3_wbf16(const dinv_act_geom* g, const float* x, const void* u_split, int32_t cin, int32_t cout,
+                       float* y, const float* res1, int32_t relu, dinv_stream_t stream);
+
 /* 2x2 stride-2 convolution (downsample_strideconv, drunet.py:524-552) on the bf16 matrix cores with the same exact
  * two-part operand split; w_split: [tap = dy*2+dx][Cin/16][plane hi/lo][cblk 2][Cout][ci 8] bf16.  Same operator as
  * dinv_conv_down2x2 (fp32 pipe). */
