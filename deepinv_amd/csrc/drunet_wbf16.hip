@@ -1,9 +1,14 @@
 // DRUNet ResBlock 3x3 convolution: Winograd F(2x2, 3x3) on the BF16 matrix cores with the exact two-part operand split
-// (gfx950).  OPT-IN (DINV_DRUNET_CONV=wbf16): written and validated on the host emulation at the end of round 2; ONE
-// hardware run so far (scripts/bench_wbf16.py, profiles/r02_wbf16_first.jsonl; B = 32): correct at first launch (6e-6
-// relative to the direct bf16-split kernel) and 0.99 / 0.77 / 0.67 / 0.79 ms at the four DRUNet levels against
-// 0.94 / 0.73 / 0.73 / 0.76 ms - on par although it issues 2.25x fewer MFMAs, i.e. untuned and bound by the transform /
-// LDS / barrier side, not by the matrix pipe.  The default stays the direct bf16-split kernel (drunet_bf16s.hip).
+// (gfx950).  OPT-IN (DINV_DRUNET_CONV=wbf16): written at the end of round 2 and validated on the host emulation; three
+// short hardware runs (scripts/bench_wbf16.py, profiles/r02_wbf16_first.jsonl; B = 32, ms per conv at the four DRUNet
+// levels, direct bf16-split kernel in brackets): correct at first launch (6e-6 relative to the direct kernel);
+//   first form                                              0.99 / 0.77 / 0.67 / 0.79   (0.94 / 0.73 / 0.73 / 0.76)
+//   + packed transform, waves w / w+4 staggered             0.90 / 0.69 / 0.60 / 0.70   (0.92 / 0.73 / 0.71 / 0.74)
+//   + epilogue in two chunks of 32 couts                    0.90 / 0.70 / 0.60 / 0.68   (no change)
+// A fit over the levels gives ~2.4 us per 16-channel block and ~8.5 us fixed per workgroup against ~0.8 us of MFMA issue
+// per block: with 2.25x fewer MFMAs the kernel is bound by everything else (two barriers per block with all 8 waves, one
+// workgroup per CU because of its 157 KB of LDS, so every fill / write-back is exposed).  Not profiled with counters
+// (the GPU budget of the round was spent); the default stays the direct bf16-split kernel (drunet_bf16s.hip).
 //
 // Operator: y = [relu](conv3x3(x)) (+ res1), stride 1, zero padding 1, no bias (deepinv/models/drunet.py:403-434), on the
 // padded channel-blocked activation layout of drunet.hip.
@@ -22,7 +27,7 @@
 //     bytes of the 16 bf16 operand units V[xi][plane][cblk][pos] (four adjacent lanes complete a 16-byte unit);
 //   * the MFMAs of block s read V[s & 1] while block s + 1 is transformed into V[(s + 1) & 1]; the pre-split U of a wave's
 //     two points comes straight from global / L2 into registers (8 x 16 bytes per lane, re-loaded under the transform).
-// Epilogue: the accumulators are exchanged through LDS in four chunks of 16 couts ([xi][pos][16 co], padded), a thread
+// Epilogue: the accumulators are exchanged through LDS in two chunks of 32 couts ([xi][pos][32 co], padded), a thread
 // then owns (position, 4 couts), applies A^T . A, ReLU / residual, and stores float4 to the interior pixels only.
 // Budget per block and CU at full MFMA issue (1536 cycles): LDS 212 KB (raw 20 + 64, V 64 + 64) = 138 B/clk - above the
 // 128 B/clk of the LDS, but the bf16 pipe sustains only ~55 % of its issue rate on this chip (see drunet_bf16s.hip), at
@@ -40,10 +45,10 @@ constexpr int RS = 2 * TPS + 2;                // raw region side (18 pixels)
 constexpr int RPITCH = 20;                     // floats per raw pixel in LDS: 16 channels + 4 pad (16-byte aligned rows)
 constexpr int RAWF = RS * RS * RPITCH;         // 6480 floats
 constexpr int VUNITS = 16 * 2 * 2 * 64;        // 16-byte units of one V stage: [xi][plane][cblk][pos]
-constexpr int MPITCH = 20;                     // floats per (xi, pos) row of the epilogue exchange: 16 couts + 4 pad
+constexpr int MPITCH = 36;                     // floats per (xi, pos) row of the epilogue exchange: 32 couts + 4 pad
 constexpr size_t LDS_BYTES = (size_t)RAWF * 4 + (size_t)2 * VUNITS * 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert((size_t)16 * 64 * MPITCH * 4 <= (size_t)2 * VUNITS * 16, "epilogue exchange must fit the V stages");
+static_assert((size_t)16 * 64 * MPITCH * 4 <= LDS_BYTES, "epilogue exchange must fit the raw tile + the V stages");
 
 struct WArgs {
     Geom g;
@@ -82,12 +87,31 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, cons
 }
 #endif
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> packed bf16 high parts and packed bf16 low parts (value 0 in the low half-word)
+__device__ __forceinline__ void split2(const f2& v, unsigned& hi, unsigned& lo) {
+#ifdef DINV_EMU
+    const unsigned h0 = f2bf(v.x), h1 = f2bf(v.y);
+    hi = h0 | (h1 << 16);
+    lo = f2bf(v.x - bf2f(h0)) | (f2bf(v.y - bf2f(h1)) << 16);
+#else
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 h = __builtin_convertvector(v, bf2);                 // v_cvt_pk_bf16_f32
+    hi = __builtin_bit_cast(unsigned, h);
+    f2 hf;
+    hf.x = __uint_as_float(hi << 16);
+    hf.y = __uint_as_float(hi & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf2));
+#endif
+}
+
 template <bool RELU, int NRES>
 __global__ __launch_bounds__(NTHR) void conv3x3_wbf16_kernel(WArgs a) {
     DINV_DYN_LDS(float, lds);
     float* raw = lds;                                              // [18][18][RPITCH]
     uint4* vst = reinterpret_cast<uint4*>(lds + RAWF);             // [2][VUNITS]
-    float* mex = lds + RAWF;                                       // epilogue exchange, over the V stages
+    float* mex = lds;                                              // epilogue exchange, over the raw tile and the V stages
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     // XCD-aware order as in drunet_bf16s.hip: the cout tiles of one pixel tile and neighbouring pixel tiles share an L2
@@ -138,33 +162,33 @@ __global__ __launch_bounds__(NTHR) void conv3x3_wbf16_kernel(WArgs a) {
     const int tpos = (wv >> 1) * 16 + (lane >> 2);
     const int traw = ((2 * (tpos >> 3)) * RS + 2 * (tpos & 7)) * RPITCH + tcb * 8 + 2 * cp;    // patch element (0, 0)
     auto transform = [&](int stage) {
-        float2 t[4][4];     // B^T d, one patch column at a time (keeps 8 instead of 32 raw values live)
+        f2 t[4][4];     // B^T d, one patch column at a time (keeps 8 instead of 32 raw values live); packed fp32 adds
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float2 d[4];
+            f2 d[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const float2*>(raw + traw + (i * RS + j) * RPITCH);
-            t[0][j] = make_float2(d[0].x - d[2].x, d[0].y - d[2].y);
-            t[1][j] = make_float2(d[1].x + d[2].x, d[1].y + d[2].y);
-            t[2][j] = make_float2(d[2].x - d[1].x, d[2].y - d[1].y);
-            t[3][j] = make_float2(d[1].x - d[3].x, d[1].y - d[3].y);
+            for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const f2*>(raw + traw + (i * RS + j) * RPITCH);
+            t[0][j] = d[0] - d[2];
+            t[1][j] = d[1] + d[2];
+            t[2][j] = d[2] - d[1];
+            t[3][j] = d[1] - d[3];
         }
         unsigned* vw = reinterpret_cast<unsigned*>(vst + (size_t)stage * VUNITS);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float2 v[4];    // (B^T d) B
-            v[0] = make_float2(t[r][0].x - t[r][2].x, t[r][0].y - t[r][2].y);
-            v[1] = make_float2(t[r][1].x + t[r][2].x, t[r][1].y + t[r][2].y);
-            v[2] = make_float2(t[r][2].x - t[r][1].x, t[r][2].y - t[r][1].y);
-            v[3] = make_float2(t[r][1].x - t[r][3].x, t[r][1].y - t[r][3].y);
+            f2 v[4];    // (B^T d) B
+            v[0] = t[r][0] - t[r][2];
+            v[1] = t[r][1] + t[r][2];
+            v[2] = t[r][2] - t[r][1];
+            v[3] = t[r][1] - t[r][3];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int xi = 4 * r + c;
-                const unsigned h0 = f2bf(v[c].x), h1 = f2bf(v[c].y);
-                const unsigned l0 = f2bf(v[c].x - bf2f(h0)), l1 = f2bf(v[c].y - bf2f(h1));
+                unsigned hi, lo;
+                split2(v[c], hi, lo);
                 // unit (xi, plane, cblk, pos), dword cp of its 8 channels
-                vw[((((xi * 2 + 0) * 2 + tcb) * 64 + tpos) << 2) + cp] = h0 | (h1 << 16);
-                vw[((((xi * 2 + 1) * 2 + tcb) * 64 + tpos) << 2) + cp] = l0 | (l1 << 16);
+                vw[((((xi * 2 + 0) * 2 + tcb) * 64 + tpos) << 2) + cp] = hi;
+                vw[((((xi * 2 + 1) * 2 + tcb) * 64 + tpos) << 2) + cp] = lo;
             }
         }
     };
@@ -221,45 +245,47 @@ __global__ __launch_bounds__(NTHR) void conv3x3_wbf16_kernel(WArgs a) {
     transform(0);
     if (S > 1) load_raw(1);
     __syncthreads();                 // V[0] complete; the raw tile may be overwritten
+    // waves w and w + 4 share a SIMD (drunet_bf16s.hip): one of them transforms before its MFMAs, the other after, so that
+    // on every SIMD vector work (transform, split) and matrix work overlap instead of alternating in lockstep
+    const bool early = (wv & 4) != 0;
     for (int s = 0; s < S; ++s) {
         if (s + 1 < S) write_raw();  // raw tile of block s + 1
         lds_barrier();
         if (s + 2 < S) load_raw(s + 2);
+        if (early && s + 1 < S) transform((s + 1) & 1);
         mma(s & 1);
         if (s + 1 < S) {
             load_u(s + 1);
-            transform((s + 1) & 1);
+            if (!early) transform((s + 1) & 1);
         }
         lds_barrier();               // V[(s+1)&1] complete, V[s&1] and the raw tile consumed
     }
 
-    // ---- epilogue: four chunks of 16 couts through LDS, then (position, 4 couts) per thread
-    const int epos = tid & 63, eq = (tid >> 6) & 3;                        // threads 0..255 produce outputs
+    // ---- epilogue: two chunks of 32 couts through LDS ([xi][pos][32 co], padded), then (position, 4 couts) per thread
+    const int epos = tid & 63, eq = tid >> 6;                              // eq: cout quad 0..7 of the chunk
     const int tyt = TPS * tyb + (epos >> 3), txt = TPS * txb + (epos & 7);     // tile coordinates in the image
     const int R0 = 1 + 2 * tyt, C0 = 1 + 2 * txt;                          // padded coordinates of output (0, 0)
     const int64_t p00 = (int64_t)b * a.g.plane + (int64_t)R0 * a.g.wp + C0;
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-        const int m = ch >> 1, rb = 2 * (ch & 1);                          // register quads rb, rb + 1 of accumulator m
+    for (int m = 0; m < 2; ++m) {                                          // chunk m = accumulator row tile m (32 couts)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int rq = rb + k;                                 // couts 8 k + 4 lhi .. + 3 of the chunk
+                for (int rq = 0; rq < 4; ++rq) {                           // couts 8 rq + 4 lhi .. + 3 of the chunk
                     const float4 v = make_float4(acc[p][m][n][4 * rq], acc[p][m][n][4 * rq + 1], acc[p][m][n][4 * rq + 2],
                                                  acc[p][m][n][4 * rq + 3]);
-                    *reinterpret_cast<float4*>(mex + (((2 * wv + p) * 64 + n * 32 + l31) * MPITCH + 8 * k + 4 * lhi)) = v;
+                    *reinterpret_cast<float4*>(mex + (((2 * wv + p) * 64 + n * 32 + l31) * MPITCH + 8 * rq + 4 * lhi)) = v;
                 }
         __syncthreads();
-        if (tid < 256) {
+        {
             float4 M[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) M[r][c] = *reinterpret_cast<const float4*>(mex + (((4 * r + c) * 64 + epos) * MPITCH + 4 * eq));
-            const int cbo = ty * 8 + ch * 2 + (eq >> 1);                   // output channel block
+            const int cbo = ty * 8 + m * 4 + (eq >> 1);                    // output channel block
             if (cbo < a.cblocks_valid) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -285,7 +311,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_wbf16_kernel(WArgs a) {
                 }
             }
         }
-        __syncthreads();
+        if (m == 0) __syncthreads();
     }
 }
 
