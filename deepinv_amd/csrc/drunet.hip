@@ -445,7 +445,9 @@ extern "C" int dinv_act_geom_init(int32_t batch, int32_t height, int32_t width, 
     g->plane = (int64_t)g->hp * g->wp;
     g->np = g->plane * batch;
     g->sl = g->wp + 4;
-    g->cs = g->sl + ceil_div(g->np, 2 * NT) * 2 * NT + g->wp + 4;   // whole 512-pixel tiles (drunet_bf16s.hip)
+    // trailing slack: whole 512-pixel tiles (flattened 1-D kernels) and, for the 2-D tiles of drunet_split2d.hip, the halo
+    // rows of the last row tile (up to 33 rows past the last frame) plus a partial column tile's overhang
+    g->cs = g->sl + std::max<int64_t>(ceil_div(g->np, 2 * NT) * 2 * NT + g->wp + 4, g->np + (int64_t)34 * g->wp + 64);
     g->cs = (g->cs + 3) / 4 * 4;
     return 0;
 }

@@ -1,0 +1,381 @@
+// DRUNet ResBlock 3x3 convolution on the BF16 matrix cores, two-part exact operand split, 2-D pixel tiles (gfx950).
+//
+// Operator: y = [relu](conv3x3(x)) (+ res1), stride 1, zero padding 1, no bias (deepinv/models/drunet.py:403-434), on the
+// padded channel-blocked activation layout of drunet.hip.  Arithmetic as in round 2: every fp32 operand is x = xh + xl with
+// xh = bf16(x), xl = bf16(x - xh) (both RNE, x - xh exact), a product is ah*bl + al*bh + ah*bh with fp32 accumulation in
+// v_mfma_f32_32x32x16_bf16; the dropped al*bl term and the rounding of xl are <= 2^-16 |x| per operand (worst case,
+// tests/test_emu_drunet.py::test_split_worst_case), 2-4e-6 per layer against an fp64 convolution on random data.
+//
+// What differs from the round-2 kernel (which staged one 258-pixel ROW segment per kernel row dy, i.e. loaded and split
+// every input element 3 x Cout/64 times: 4.4-5 VALU instructions per MFMA, matrix pipe 55 % busy, profiles/pmc/r03_*):
+//   * a workgroup owns a 2-D tile of TR x TC interior pixels (8x32, 16x16, 32x8 = 256 pixels, or half of that) of the image
+//     stack (rows of all images are one flattened axis: the zero frame rows between images are ordinary rows whose results
+//     are not stored), so ONE staged (TR+2) x (TC+2) halo region serves all nine taps of a 16-channel step: 1.3 staged
+//     pixels per output pixel instead of 3.0, and no padded-frame columns are computed (level 3: 5 % wasted MFMAs, was 15 %);
+//   * activations may arrive PRE-SPLIT (each pixel's 8-channel block as 8 bf16 high parts + 8 bf16 low parts in the same
+//     32 bytes): the producer's epilogue splits once per element, the consumer stages by plain copies.  ResBlock conv1
+//     writes its ReLU output t that way (t is consumed only by conv2, which would split it into exactly these parts: same
+//     bits as before); conv2 reads it, adds the fp32 residual and writes fp32;
+//   * the weight rows of a 32-cout MFMA tile are permuted (host pack) so that a lane's 16 accumulator registers are two
+//     complete 8-channel blocks of one pixel: every epilogue access is 32 contiguous bytes per lane.
+// Pipeline: K loop over sub-steps (16 channels x one kernel row dy): weights of a sub-step (3 taps x 16 channels x 64
+// couts, pre-split: 12 KB) double-buffered; the activation stage of the NEXT 16-channel step (21-26 KB) is filled one
+// third per sub-step; global loads run one sub-step ahead in registers; ONE LDS-only barrier per sub-step; two
+// workgroups per CU (<= 77 KB of LDS each).
+#include "drunet_common.hpp"
+
+using namespace dinv;
+using namespace dinv_drunet;
+
+namespace {
+
+constexpr int WUNITS = 2 * 3 * 2 * 64;   // 16-byte units of a sub-step's weights: [plane][dx][cblk][row 64]
+
+template <int TC_, int NREP_> struct Tile2 {
+    static constexpr int TC = TC_, NREP = NREP_;
+    static constexpr int TP = 4 * 32 * NREP;             // pixels per workgroup (4 waves x NREP n-tiles of 32)
+    static constexpr int TR = TP / TC;
+    static constexpr int AR = TR + 2, CW = TC + 2;        // staged rows / columns (one halo pixel on each side)
+    static constexpr int AW = TC == 8 ? 12 : TC + 2;      // LDS row pitch in units: conflict-free ds_read_b128 (see rot())
+    static constexpr int APL = AR * AW;                   // units per (plane, channel block)
+    static constexpr int ASTAGE = 4 * APL;                // [plane 2][cblk 2][AR][AW]
+    static constexpr int NCH = 2 * AR * CW;               // 32-byte chunks (pixel x channel block) of a stage
+    static constexpr int CPS = (NCH + 3 * 256 - 1) / (3 * 256);   // chunks per thread per sub-step
+    static constexpr int LDS_UNITS = 2 * ASTAGE + 2 * WUNITS;
+    static_assert(32 % TC == 0 && TP % TC == 0, "tile width must divide an MFMA n-tile");
+    // lane -> pixel inside a 32-pixel n-tile: row l/TC, column (l%TC + rot) % TC.  The rotation makes the 16 lanes that
+    // one ds_read_b128 cycle serves ({0-3,12-15,20-27}, {4-11,16-19,28-31}) hit 16 distinct 16-byte bank slots for the
+    // pitches above (searched exhaustively: 32 -> none needed, 16 -> (0,14), 8 -> (0,4,4,0) with pitch 12).
+    static __device__ __forceinline__ int rot(int row_in_ntile) {
+        if constexpr (TC == 16) return row_in_ntile ? 14 : 0;
+        else if constexpr (TC == 8) return (row_in_ntile == 1 || row_in_ntile == 2) ? 4 : 0;
+        else return 0;
+    }
+};
+
+struct S2Args {
+    Geom g;
+    const float* x;      // fp32 [cin/8][cs][8]  or pre-split [cin/8][cs][hi 8 bf16 | lo 8 bf16]
+    const uint4* w;      // [cout/64][cin/16][dy 3][plane 2][dx 3][cblk 2][row 64] x (8 bf16), rows permuted (pack_split2d_weight)
+    float* y;
+    const float* res1;
+    int32_t cin;
+    int32_t ntc, ytiles, ntiles, tiles_per_xcd;
+    int32_t rows;        // batch * hp flattened image rows
+};
+
+__device__ __forceinline__ unsigned f2bf(float f) {   // round to nearest even, as v_cvt_pk_bf16_f32
+#ifdef DINV_EMU
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+#else
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
+}
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+
+// 8 fp32 -> 8 bf16 high parts + 8 bf16 low parts (each 16 bytes)
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = f2bf(v[e]);
+        l[e] = f2bf(v[e] - bf2f(h[e]));
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+#ifdef DINV_EMU
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16& c) {
+    emu_bf16x8 av, bv;
+    std::memcpy(&av, &a, 16);
+    std::memcpy(&bv, &b, 16);
+    return emu_mfma_f32_32x32x16_bf16(av, bv, c);
+}
+#else
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+#endif
+
+__device__ __forceinline__ uint4 ldu4(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ float4 as_f4(const uint4& u) {
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+
+template <bool IN_SPLIT, bool OUT_SPLIT, bool RELU, int NRES, int TC, int NREP>
+__global__ __launch_bounds__(256) void conv3x3_split2d_kernel(S2Args a) {
+    using T = Tile2<TC, NREP>;
+    constexpr int TR = T::TR, AR = T::AR, CW = T::CW, AW = T::AW, APL = T::APL, ASTAGE = T::ASTAGE, NCH = T::NCH, CPS = T::CPS;
+    DINV_DYN_LDS(uint4, lds);   // [2][ASTAGE] activations, then [2][WUNITS] weights
+    uint4* const lds_w = lds + 2 * ASTAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // XCD-aware order: consecutive pixel tiles (shared halos) and the cout tiles of one pixel tile stay on one XCD
+    // (observed placement: block b runs on XCD b % 8; speed only)
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int ty = jx % a.ytiles, tl = jx / a.ytiles;
+    const int tile = xcd * a.tiles_per_xcd + tl;
+    if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;
+    const int tr_i = tile / a.ntc, tc_i = tile - tr_i * a.ntc;
+    const int r0 = tr_i * TR, c0 = 1 + tc_i * TC;      // first interior row (flattened over images) / column of the tile
+    const int nstep = a.cin / 16, nsub = 3 * nstep;
+
+    f32x16 acc[2][NREP];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // ---- staging slots of this thread (the same in every step): chunk q = (cblk, row, col) of the halo region
+    int xoff[3], loff[3];     // global offset in floats (channel step 0), LDS unit of the high part
+    bool own[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int q = k * 256 + tid;
+        own[k] = q < NCH;
+        if (!own[k]) q = NCH - 1;         // clamped redundant load, no write: straight-line code
+        const int cb = q / (AR * CW), rem = q - cb * (AR * CW);
+        const int row = rem / CW, col = rem - row * CW;
+        xoff[k] = (int)(((int64_t)cb * a.g.cs + a.g.sl + (int64_t)(r0 - 1 + row) * a.g.wp + (c0 - 1 + col)) * 8);
+        loff[k] = cb * APL + row * AW + col;
+    }
+    const uint4* wsrc0 = a.w + (int64_t)ty * nsub * WUNITS;
+    const int64_t step_stride = (int64_t)2 * a.g.cs * 8;      // floats per 16-channel step
+
+    // staging registers: plain scalars, never arrays indexed inside lambdas (hipcc leaves such arrays in scratch memory,
+    // which turns every staged load into load -> wait -> scratch store: measured 58 % of the wave time parked)
+    static_assert(CPS == 1, "one chunk per thread per sub-step");
+    uint4 rxa, rxb, rw0, rw1, rw2;
+    auto issue_x = [&](int s, int rd) {   // loads of round rd of step s
+        const float* p = a.x + (int64_t)s * step_stride + xoff[rd];
+        rxa = ldu4(p);
+        rxb = ldu4(p + 4);
+    };
+    auto commit_x = [&](int s, int rd) {
+        uint4* st = lds + (s & 1) * ASTAGE;
+        uint4 hi, lo;
+        if constexpr (IN_SPLIT) { hi = rxa; lo = rxb; }
+        else split8(as_f4(rxa), as_f4(rxb), hi, lo);
+        if (own[rd]) {
+            st[loff[rd]] = hi;
+            st[2 * APL + loff[rd]] = lo;
+        }
+    };
+    auto issue_w = [&](int t) {
+        const uint4* ws = wsrc0 + (int64_t)t * WUNITS;
+        rw0 = ws[tid];
+        rw1 = ws[256 + tid];
+        rw2 = ws[512 + tid];
+    };
+    auto commit_w = [&](int t) {
+        uint4* st = lds_w + (t & 1) * WUNITS;
+        st[tid] = rw0;
+        st[256 + tid] = rw1;
+        st[512 + tid] = rw2;
+    };
+
+    // operand slots of this lane: A = weights (row l31 of m-tile, k half = channel block lhi),
+    //                             B = pixels (pixel l31 of n-tile, k half = channel block lhi)
+    const int aslot = lhi * 64 + l31;                       // + (plane*3 + dx)*128 + m*32
+    int bslot[NREP], prow[NREP], pcol[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int q = (wv * NREP + n) * 32 + l31;
+        const int tr = q / TC, j = q - tr * TC;
+        int tc = j + T::rot(l31 / TC);
+        if (tc >= TC) tc -= TC;
+        prow[n] = tr; pcol[n] = tc;
+        bslot[n] = lhi * APL + tr * AW + tc;                // + plane*2*APL + dy*AW + dx
+    }
+
+    // ---- prologue: the whole activation stage of step 0, weights of sub-step 0 in LDS; sub-step 1's weights and round 0 of
+    // step 1 in registers
+    {
+        // one HBM round trip for the whole first stage: all three rounds in flight, then committed
+        const uint4 p0a = ldu4(a.x + xoff[0]), p0b = ldu4(a.x + xoff[0] + 4);
+        const uint4 p1a = ldu4(a.x + xoff[1]), p1b = ldu4(a.x + xoff[1] + 4);
+        const uint4 p2a = ldu4(a.x + xoff[2]), p2b = ldu4(a.x + xoff[2] + 4);
+        issue_w(0);
+        rxa = p0a; rxb = p0b; commit_x(0, 0);
+        rxa = p1a; rxb = p1b; commit_x(0, 1);
+        rxa = p2a; rxb = p2b; commit_x(0, 2);
+    }
+    commit_w(0);
+    if (nsub > 1) issue_w(1);
+    if (nstep > 1) issue_x(1, 0);
+    __syncthreads();
+
+    for (int s = 0; s < nstep; ++s) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {   // compile-time dy: the staging slot arrays are indexed by it
+            const int t = 3 * s + dy;
+            const uint4* xs = lds + (s & 1) * ASTAGE + dy * AW;
+            const uint4* ws = lds_w + (t & 1) * WUNITS;
+            uint4 A[2][2][2], B[2][NREP][2];   // [buffer][tile][plane]
+            auto rd = [&](int buf, int dx) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) A[buf][m][pl] = ws[(pl * 3 + dx) * 128 + aslot + m * 32];
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) B[buf][n][pl] = xs[pl * 2 * APL + bslot[n] + dx];
+                }
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int cur = dx & 1;
+                if (dx < 2) rd(cur ^ 1, dx + 1);
+                // smallest terms first (ah*bl, al*bh, ah*bh), product-major: consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const int pa = e == 1 ? 1 : 0, pb = e == 0 ? 1 : 0;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_bf16(A[cur][m][pa], B[cur][n][pb], acc[m][n]);
+                }
+            }
+            // staging after the MFMAs of this sub-step are issued: registers hold loads issued one sub-step ago
+            if (t + 1 < nsub) commit_w(t + 1);
+            if (t + 2 < nsub) issue_w(t + 2);
+            if (s + 1 < nstep) {
+                commit_x(s + 1, dy);
+                if (dy < 2) issue_x(s + 1, dy + 1);
+                else if (s + 2 < nstep) issue_x(s + 2, 0);
+            }
+            lds_barrier();   // slot t consumed; weights of t+1 and (after dy = 2) the activation stage of step s+1 complete
+        }
+    }
+
+    // ---- epilogue: register quads 2k, 2k+1 of acc[m][n] are channels 0..7 of block cb0 + 4m + 2k + lhi (row permutation of
+    // pack_split2d_weight): 32 contiguous bytes per lane
+    const int cb0 = ty * 8;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int RR = r0 + prow[n], cc = c0 + pcol[n];
+        if (RR >= a.rows || cc > a.g.w) continue;
+        const int rr = RR % a.g.hp;
+        const bool in = rr >= 1 && rr <= a.g.h;     // frame rows between images stay zero
+        const int64_t opix = a.g.sl + (int64_t)RR * a.g.wp + cc;
+        float4 rs[NRES >= 1 ? 8 : 1];
+        if (NRES >= 1) {      // all residual loads of this pixel first: 8 independent 16-byte loads in flight
+#pragma unroll
+            for (int mk = 0; mk < 4; ++mk) {
+                const float* rp = a.res1 + ((int64_t)(cb0 + 4 * (mk >> 1) + 2 * (mk & 1) + lhi) * a.g.cs + opix) * 8;
+                rs[2 * mk] = ld4(rp);
+                rs[2 * mk + 1] = ld4(rp + 4);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int64_t o = ((int64_t)(cb0 + 4 * m + 2 * k + lhi) * a.g.cs + opix) * 8;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[m][n][8 * k + e];
+                if (RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (NRES >= 1) {
+                    const float4 ra = rs[2 * (2 * m + k)], rb = rs[2 * (2 * m + k) + 1];
+                    v[0] += ra.x; v[1] += ra.y; v[2] += ra.z; v[3] += ra.w;
+                    v[4] += rb.x; v[5] += rb.y; v[6] += rb.z; v[7] += rb.w;
+                }
+                if (!in) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                }
+                if constexpr (OUT_SPLIT) {
+                    uint4 hi, lo;
+                    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+                    *reinterpret_cast<uint4*>(a.y + o) = hi;
+                    *reinterpret_cast<uint4*>(a.y + o + 4) = lo;
+                } else {
+                    st4(a.y + o, make_float4(v[0], v[1], v[2], v[3]));
+                    st4(a.y + o + 4, make_float4(v[4], v[5], v[6], v[7]));
+                }
+            }
+    }
+}
+
+template <bool IN_SPLIT, bool OUT_SPLIT, bool RELU, int NRES, int TC, int NREP>
+int launch_s2(S2Args a, hipStream_t st) {
+    using T = Tile2<TC, NREP>;
+    constexpr size_t lds = (size_t)T::LDS_UNITS * sizeof(uint4);
+    static_assert(2 * lds <= 160 * 1024, "two workgroups must fit one CU");
+    const int ntr = (int)ceil_div(a.rows, T::TR);
+    a.ntc = (int)ceil_div(a.g.w, TC);
+    a.ntiles = ntr * a.ntc;
+    a.tiles_per_xcd = (int32_t)ceil_div(a.ntiles, 8);
+    const dim3 grid((unsigned)(a.tiles_per_xcd * a.ytiles * 8)), block(256);
+    auto kern = conv3x3_split2d_kernel<IN_SPLIT, OUT_SPLIT, RELU, NRES, TC, NREP>;
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e_ != hipSuccess) return fail(100 + (int)e_, "hipFuncSetAttribute: %s", hipGetErrorString(e_));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool IN_SPLIT, bool OUT_SPLIT, bool RELU, int NRES>
+int dispatch_tile(const S2Args& a, int tc, int nrep, hipStream_t st) {
+#define DINV_S2(TCV, NR) return launch_s2<IN_SPLIT, OUT_SPLIT, RELU, NRES, TCV, NR>(a, st)
+    if (nrep == 2) {
+        if (tc == 32) DINV_S2(32, 2);
+        if (tc == 16) DINV_S2(16, 2);
+        DINV_S2(8, 2);
+    }
+    if (tc == 32) DINV_S2(32, 1);
+    if (tc == 16) DINV_S2(16, 1);
+    DINV_S2(8, 1);
+#undef DINV_S2
+}
+
+}  // namespace
+
+// flags: bit 0 = x is pre-split, bit 1 = write y pre-split, bit 2 = relu; bits 8-9 = pixels per workgroup (0: chosen from the
+// grid size, 1: 128, 2: 256)
+extern "C" int dinv_conv3x3_split(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout,
+                                  void* y, const float* res1, int32_t flags, dinv_stream_t stream) {
+    if (int e = check_geom(g)) return e;
+    DINV_REQUIRE(x && w_split && y, "null tensor pointer");
+    DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0,
+                 "bf16-split conv needs cin %% 16 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
+    const bool in_split = flags & 1, out_split = flags & 2, relu = flags & 4;
+    DINV_REQUIRE((flags & ~0x307) == 0 && ((flags >> 8) & 3) != 3, "unknown flags %d", flags);
+    DINV_REQUIRE(!(relu && res1), "relu and residual are not combined in DRUNet");
+    DINV_REQUIRE(!(out_split && res1), "a pre-split output carries no residual");
+    // halo rows of the last row tile and the column overhang of a partial column tile must stay inside a channel block
+    DINV_REQUIRE(g->cs >= g->sl + g->np + (int64_t)34 * g->wp + 64, "channel-block stride too small for 2-D tiles (rebuild the geometry)");
+    DINV_REQUIRE(g->cs * 16 < ((int64_t)1 << 31), "activation row too long for 32-bit staging offsets");
+    S2Args a{make_geom(*g), reinterpret_cast<const float*>(x), reinterpret_cast<const uint4*>(w_split),
+             reinterpret_cast<float*>(y), res1, cin, 0, cout / 64, 0, 0, g->batch * g->hp};
+    // tile width: the widest of 32 / 16 / 8 that divides the image width (DRUNet levels: 320 -> 32, 160 -> 32, 80 -> 16,
+    // 40 -> 8); tiles of 128 pixels when 256-pixel tiles would leave the 512 resident workgroup slots under-filled
+    const int tc = g->width % 32 == 0 ? 32 : (g->width % 16 == 0 ? 16 : 8);
+    const int64_t n256 = ceil_div((int64_t)g->batch * g->hp, 256 / tc) * ceil_div(g->width, tc) * (cout / 64);
+    const int nrep = ((flags >> 8) & 3) ? ((flags >> 8) & 3) : (n256 >= 768 ? 2 : 1);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (in_split) {
+        if (relu) return dispatch_tile<true, false, true, 0>(a, tc, nrep, st);
+        if (res1) return dispatch_tile<true, false, false, 1>(a, tc, nrep, st);
+        return dispatch_tile<true, false, false, 0>(a, tc, nrep, st);
+    }
+    if (out_split) {
+        if (relu) return dispatch_tile<false, true, true, 0>(a, tc, nrep, st);
+        return dispatch_tile<false, true, false, 0>(a, tc, nrep, st);
+    }
+    if (relu) return dispatch_tile<false, false, true, 0>(a, tc, nrep, st);
+    if (res1) return dispatch_tile<false, false, false, 1>(a, tc, nrep, st);
+    return dispatch_tile<false, false, false, 0>(a, tc, nrep, st);
+}

@@ -72,7 +72,7 @@ _tls = threading.local()
 
 
 class _DeviceGuardedLib:
-    """The ctypes library with every call issued on the device of the operands last checked by `require_hip`.
+    """The ctypes library with every call issued on the device of that call's operands (`ptr` / `stream_ptr` note it).
     A kernel launch goes to the CURRENT HIP device whatever stream it is given, so operands on cuda:1 while cuda:0 is
     current would fail (or use cuda:0's configuration caches); PyTorch ops guard against that, and so do these."""
 
@@ -89,7 +89,10 @@ class _DeviceGuardedLib:
                 __slots__ = ()
 
                 def __call__(_, *args):
+                    # the device of THIS call's operands: recorded by ptr() / stream_ptr() while the arguments were
+                    # built (every launching entry point takes at least a stream), dropped once the call is issued
                     dev = getattr(_tls, "dev", None)
+                    _tls.dev = None
                     if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
                         with torch.cuda.device(dev):
                             return fn(*args)
@@ -149,10 +152,15 @@ def require_hip(*tensors: torch.Tensor):
 
 
 def ptr(t: torch.Tensor | None):
+    if t is not None and t.is_cuda:
+        _tls.dev = t.device
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
 def stream_ptr(device) -> ctypes.c_void_p:
+    device = torch.device(device)
+    if device.type == "cuda":
+        _tls.dev = device if device.index is not None else torch.device("cuda", torch.cuda.current_device())
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -33,6 +33,7 @@ def _l():
         l.dinv_conv3x3_bf16x3.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
         l.dinv_conv3x3_bf16s.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
+        l.dinv_conv3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_down2x2_bf16s.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2_bf16s.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
@@ -109,6 +110,25 @@ def pack_bf16s_weight(w: torch.Tensor) -> torch.Tensor:
     planes = torch.stack((hi, lo))                                            # [2, Cout, Cin, 3, 3]
     planes = planes.reshape(2, cout // 64, 64, cin // 16, 2, 8, 3, 3)         # pl, ct, co, s, cblk, ci, dy, dx
     return planes.permute(1, 3, 6, 0, 7, 4, 2, 5).contiguous()               # ct, s, dy, pl, dx, cblk, co, ci
+
+
+def split2d_row_perm() -> torch.Tensor:
+    """MFMA A-row -> cout permutation inside a 32-row tile for csrc/drunet_split2d.hip: row 8g + 4h + e carries cout
+    16 (g >> 1) + 8 h + 4 (g & 1) + e, so that the 16 accumulator registers of lane half h are the complete 8-channel blocks
+    2k + h (k = 0, 1) of its pixel."""
+    i = torch.arange(32)
+    g, h, e = i >> 3, (i >> 2) & 1, i & 3
+    return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + e
+
+
+def pack_split2d_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> two-part bf16 split (hi = bf16(w), lo = bf16(w - hi)), packed for csrc/drunet_split2d.hip:
+    [Cout/64][Cin/16][dy 3][plane 2][dx 3][cblk 2][row 64][ci 8] (bf16), rows of each 32-row tile permuted by
+    `split2d_row_perm`"""
+    packed = pack_bf16s_weight(w)                      # ct, s, dy, pl, dx, cblk, co 64, ci 8
+    perm = split2d_row_perm().to(packed.device)
+    idx = torch.cat((perm, 32 + perm))
+    return packed.index_select(6, idx).contiguous()
 
 
 def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
@@ -272,6 +292,22 @@ def conv3x3_bf16s(g, x, wsplit, cin, cout, y, res1=None, relu=False):
         e1.record()
         fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
         _prof.append((e0, e1, "conv3x3_bf16s_kernel", fl, 3.0 * fl))
+
+
+def conv3x3_split(g, x, wsplit, cin, cout, y, res1=None, relu=False, x_presplit=False, y_presplit=False):
+    """y = [relu](conv3x3(x)) (+res1) on the bf16 matrix cores, two-part exact operand split, 2-D pixel tiles
+    (csrc/drunet_split2d.hip); wsplit from pack_split2d_weight.  `x_presplit` / `y_presplit`: the activation buffer holds
+    (8 bf16 high parts | 8 bf16 low parts) per pixel and channel block instead of 8 fp32 values (same 32 bytes)."""
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    flags = (1 if x_presplit else 0) | (2 if y_presplit else 0) | (4 if relu else 0)
+    check(_l().dinv_conv3x3_split(ctypes.byref(g), ptr(x), ptr(wsplit), cin, cout, ptr(y), ptr(res1), flags,
+                                  stream_ptr(y.device)))
+    if _prof is not None:
+        e1.record()
+        fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
+        _prof.append((e0, e1, "conv3x3_split2d_kernel", fl, 3.0 * fl))
 
 
 def conv3x3_wbf16(g, x, usplit, cin, cout, y, res1=None, relu=False):

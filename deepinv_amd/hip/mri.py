@@ -198,11 +198,14 @@ class _MriNormal(torch.autograd.Function):
         return _MriNormal.apply(g, maps, mask, ctx.coil_dim), None, None, None
 
 
+ENABLE_FUSED_NORMAL = True    # test hook: False evaluates A^T A as adjoint(forward(x))
+
+
 def mri_normal(x, coil_maps=None, mask=None, coil_dim=True):
     """``A^T A x = sum_n conj(S_n) F^H(mask^2 F(S_n x))`` in one kernel chain that never writes k-space.  Falls back to
     adjoint(forward(x)) for sizes without a static FFT plan, or when the mask / coil maps themselves need gradients."""
     needs_param_grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in (coil_maps, mask))
-    if not needs_param_grad and os.environ.get("DINV_MRI_NORMAL", "1") != "0":
+    if not needs_param_grad and ENABLE_FUSED_NORMAL:
         B, vol = x.shape[0], tuple(x.shape[2:])
         if all(_static_ok(n) for n in vol) and vol[-1] >= 64:
             return _MriNormal.apply(x, coil_maps, mask, bool(coil_dim))

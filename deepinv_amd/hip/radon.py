@@ -61,8 +61,14 @@ def _l():
     return l
 
 
+# test hooks (module attributes, patched by tests/test_tomography_gpu.py to compare kernel generations; not configuration)
+ENABLE_TILED = True        # False: the first-generation gather kernels everywhere
+FORCE_TILED = False        # True: the LDS-tiled forward even for angle lists with fewer than 4 angles per workgroup
+ENABLE_RAMP_FFT = True     # False: the direct-convolution ramp filter
+
+
 def _use_tiled(grid: int) -> bool:
-    return grid <= TILED_MAX_GRID and os.environ.get("DINV_RADON_TILED", "1") != "0"
+    return grid <= TILED_MAX_GRID and ENABLE_TILED
 
 
 class RadonGeometry:
@@ -116,8 +122,8 @@ def _fwd(x, geo: RadonGeometry, norm, scale=1.0):
     B, C, H, W = x.shape
     sino = torch.empty((B, C, geo.G, geo.A), device=dev, dtype=torch.float32)
     # few angles per workgroup (coarse or irregular angle lists) leave the LDS-tiled forward kernel under-occupied:
-    # below 4 the gather kernel is the faster one (measured at 512^2: 60 angles, kw = 2); DINV_RADON_TILED=2 forces
-    if _use_tiled(geo.G) and geo.plan is not None and (geo.plan.kw >= 4 or os.environ.get("DINV_RADON_TILED") == "2"):
+    # below 4 the gather kernel is the faster one (measured at 512^2: 60 angles, kw = 2)
+    if _use_tiled(geo.G) and geo.plan is not None and (geo.plan.kw >= 4 or FORCE_TILED):
         d = geo.desc(B * C, scale)
         ws = torch.empty(_l().dinv_radon_tiled_workspace_bytes(ctypes.byref(d), 0), device=dev, dtype=torch.uint8)
         check(_l().dinv_radon_forward_tiled(ctypes.byref(d), ctypes.byref(geo.plan), ptr(geo.plan_dev), ptr(x), ptr(geo.xn),
@@ -342,7 +348,7 @@ class _Ramp(torch.autograd.Function):
         out = torch.empty_like(y)
         n = B * C
         P = int(_l().dinv_radon_ramp_padded_size(int(N)))
-        use_fft = P <= RAMP_FFT_MAX_P and os.environ.get("DINV_RAMP_FFT", "1") != "0"
+        use_fft = P <= RAMP_FFT_MAX_P and ENABLE_RAMP_FFT
         if use_fft:
             P, plan, table, filt = _ramp_tables(N, dev)
         step = 65535

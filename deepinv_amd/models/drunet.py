@@ -12,7 +12,6 @@ so reference ``state_dict``s / ``.pth`` checkpoints load unchanged.
 """
 from __future__ import annotations
 
-import os
 from itertools import chain
 
 import numpy as np
@@ -25,32 +24,14 @@ from . import drunet3d, drunet_train
 from .base import Denoiser
 
 
-def _use_winograd(g, pk) -> bool:
-    """Winograd F(2x2,3x3) ResBlock kernel (1.4-1.6x faster than the direct MFMA kernel at every DRUNet level,
-    measured B=4 and B=32); DINV_WINOGRAD=0 selects the direct kernel."""
-    return os.environ.get("DINV_WINOGRAD", "1") != "0"
-
-
-def _bf16_split_mode() -> int:
-    """opt-in: DINV_CONV_BF16X3=3 (six products, fp32-class accuracy) or =2 (three products, ~5e-6 per layer) runs the
-    ResBlock convolutions on the first-generation bf16 kernel (csrc/drunet_bf16.hip)."""
-    v = os.environ.get("DINV_CONV_BF16X3", "")
-    return int(v) if v in ("2", "3") else 0
-
-
-DEFAULT_RESBLOCK_CONV = "bf16s"
-
-
-def _resblock_conv() -> str:
-    """which kernel runs the 56 ResBlock convolutions: 'bf16s' = two-part bf16 operand split on the bf16 matrix cores,
-    pipelined (csrc/drunet_bf16s.hip); 'wino' = fp32 Winograd F(2x2,3x3) on the fp32 matrix cores; 'direct' = fp32
-    implicit GEMM; 'wbf16' = OPT-IN Winograd F(2x2,3x3) on the bf16 matrix cores with the operand split
-    (csrc/drunet_wbf16.hip: validated on the host emulation, not yet measured on hardware).  DINV_DRUNET_CONV overrides
-    the default."""
-    v = os.environ.get("DINV_DRUNET_CONV", DEFAULT_RESBLOCK_CONV)
-    if v not in ("bf16s", "wino", "direct", "wbf16"):
-        raise ValueError(f"DINV_DRUNET_CONV must be bf16s, wino, direct or wbf16, got {v}")
-    return v
+# The ONE precision switch of the denoiser: how the 56 ResBlock 3x3 convolutions multiply.
+#   "bf16split": every fp32 operand as two bf16 parts, three products on the bf16 matrix cores, fp32 accumulation
+#                (csrc/drunet_split2d.hip; <= 2^-16 per operand, 2-4e-6 per layer, DRUNet output within 1e-4 of the fp32 path)
+#   "fp32":      fp32 multiplies on the fp32 matrix cores (Winograd F(2x2,3x3) kernel, direct kernel for the shapes it does
+#                not take) - the reference's arithmetic type
+# Default for new models: `deepinv_amd.models.drunet.DEFAULT_CONV_PRECISION`; per model: `model.conv_precision = "fp32"`.
+CONV_PRECISIONS = ("bf16split", "fp32")
+DEFAULT_CONV_PRECISION = "bf16split"
 
 
 def _conv_nd(dim):
@@ -131,6 +112,13 @@ class DRUNet(Denoiser):
         self.m_up1 = nn.Sequential(T(nc[1], nc[0], 2, 2, 0, bias=False), *[ResBlock(nc[0], dim) for _ in range(nb)])
         self.m_tail = C(nc[0], out_channels, 3, 1, 1, bias=False)
         self.dim = dim
+        self.conv_precision = DEFAULT_CONV_PRECISION
+        # "hip": the hand-written kernels (inference, training, dim = 3); "torch": the same module through PyTorch-ROCm ops
+        # (used by the tests as an independent GPU reference; never the default)
+        self.backend = "hip"
+        # forward pass of the TRAINING node: "fp32" keeps the ReLU masks identical to an fp32 reference,
+        # "bf16split" runs the inference kernels
+        self.train_forward_precision = "fp32"
         if pretrained is not None:
             if pretrained in ("download", "download_2d"):
                 raise RuntimeError("no network access: pass pretrained=<path to .pth> or None")
@@ -171,19 +159,23 @@ class DRUNet(Denoiser):
 
     def _use_hip(self, x):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return self.dim == 2 and not needs_grad
+        return self.dim == 2 and not needs_grad and self.backend == "hip"
 
     def _use_hip_train(self):
-        """gradients requested: the hand-written backward (models/drunet_train.py) for the 2-D architectures it covers;
-        DINV_DRUNET_TRAIN=torch selects the PyTorch-ROCm graph (always used for dim=3)"""
-        return drunet_train.supported(self) and os.environ.get("DINV_DRUNET_TRAIN", "hip") != "torch"
+        """gradients requested: the hand-written backward (models/drunet_train.py) for the 2-D architectures it covers"""
+        return drunet_train.supported(self) and self.backend == "hip"
+
+    def _precision(self):
+        if self.conv_precision not in CONV_PRECISIONS:
+            raise ValueError(f"conv_precision must be one of {CONV_PRECISIONS}, got {self.conv_precision!r}")
+        return self.conv_precision
 
     def forward(self, x, sigma):
         if not x.is_cuda:
             raise HipExtensionError("deepinv_amd.models.DRUNet runs only on a HIP device; there is no CPU fallback")
         if self._use_hip(x):
             run = lambda inp: self._hip_forward(inp[:, :-1], inp[:, -1:])
-        elif drunet3d.supported(self):
+        elif drunet3d.supported(self) and self.backend == "hip":
             run = lambda inp: drunet3d.forward3d(self, inp)             # volumes as stacks of slices on the 2-D kernels
         elif self._use_hip_train():
             run = lambda inp: drunet_train.forward_train(self, inp)     # forward AND backward on the HIP kernels
@@ -206,21 +198,22 @@ class DRUNet(Denoiser):
                 + tuple(p.data_ptr() for p in self.parameters()))
 
     def _prepare(self, device):
-        ver = (self._weights_version(), _resblock_conv())     # the packs depend on the selected ResBlock kernel
+        ver = (self._weights_version(), self._precision())     # the packs depend on the precision
         if self._engine is not None and self._engine["ver"] == ver and self._engine["device"] == device:
             return self._engine
-        e = {"ver": ver, "device": device, "ws": {}}
+        e = {"ver": ver, "device": device, "ws": {}, "split": self._precision() == "bf16split"}
+        split = e["split"]
 
         def c3(m):
-            # both cout-tile widths are kept; _pick() chooses per launch geometry
+            """packs of one 3x3 conv: direct fp32 (64- and 32-wide cout tiles; _pick() chooses per launch geometry) and, per
+            precision, the bf16-split pack or the fp32 Winograd pack"""
             w = m.weight.to(device)
             p64 = K.pack_conv3x3_weight(w)
             p32 = K.pack_conv3x3_weight(w, mt=32) if p64[0].shape[3] == 64 else p64
-            wino = K.pack_winograd_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0 and w.shape[1] >= 32) else None
-            split = K.pack_bf16x3_weight(w) if (_bf16_split_mode() and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0) else None
-            bf16s = K.pack_bf16s_weight(w) if (w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0) else None
-            wbf16 = K.pack_wbf16_weight(w) if (_resblock_conv() == "wbf16" and bf16s is not None) else None
-            return (p64, p32, wino, split, bf16s, wbf16)
+            ok = w.shape[0] % 64 == 0 and w.shape[1] % 16 == 0
+            s2d = K.pack_split2d_weight(w) if (split and ok) else None
+            wino = K.pack_winograd_weight(w) if (not split and ok and w.shape[1] >= 32) else None
+            return (p64, p32, wino, s2d)
 
         e["head"] = c3(self.m_head)
         e["tail"] = c3(self.m_tail)
@@ -231,14 +224,14 @@ class DRUNet(Denoiser):
             e[name] = [(c3(b.res[0]), c3(b.res[2])) for b in list(seq)[:-1]]
             wd = seq[-1].weight.to(device)
             e[name + "_s"] = K.pack_down_weight(wd)
-            e[name + "_sb"] = K.pack_down_bf16s_weight(wd) if (wd.shape[0] % 64 == 0 and wd.shape[1] % 16 == 0) else None
+            e[name + "_sb"] = K.pack_down_bf16s_weight(wd) if (split and wd.shape[0] % 64 == 0 and wd.shape[1] % 16 == 0) else None
         body = [self.m_body] if isinstance(self.m_body, ResBlock) else list(self.m_body)
         e["m_body"] = [(c3(b.res[0]), c3(b.res[2])) for b in body]
         for name in ("m_up3", "m_up2", "m_up1"):
             seq = getattr(self, name)
             wu = seq[0].weight.to(device)
             e[name + "_s"] = K.pack_up_weight(wu)
-            e[name + "_sb"] = K.pack_up_bf16s_weight(wu) if (wu.shape[0] % 16 == 0 and wu.shape[1] % 64 == 0) else None
+            e[name + "_sb"] = K.pack_up_bf16s_weight(wu) if (split and wu.shape[0] % 16 == 0 and wu.shape[1] % 64 == 0) else None
             e[name] = [(c3(b.res[0]), c3(b.res[2])) for b in list(seq)[1:]]
         self._engine = e
         return e
@@ -264,49 +257,35 @@ class DRUNet(Denoiser):
         """64-wide cout tiles unless that grid would leave the chip under-filled (< 3 rounds of the 512 resident
         workgroup slots): then 32-wide tiles double the number of workgroups (small per-GPU batches)."""
         p64, p32 = packs[:2]
-        if p64[0].shape[3] == 64:
-            n64 = ((g.np + 255) // 256) * (p64[2] // 64)
-            if n64 < 1536 and os.environ.get("DINV_CONV_TILE", "") != "64":
-                return p32
-            if os.environ.get("DINV_CONV_TILE", "") == "32":
-                return p32
+        if p64[0].shape[3] == 64 and ((g.np + 255) // 256) * (p64[2] // 64) < 1536:
+            return p32
         return p64
 
-    def _conv_res(self, g, pk, x, y, relu=False, res1=None):
-        """one ResBlock convolution: Winograd F(2x2,3x3) kernel when selected, else the direct MFMA kernel"""
-        if len(pk) > 3 and pk[3] is not None and _bf16_split_mode():
-            K.conv3x3_bf16x3(g, x, pk[3], pk[0][1], pk[0][2], y, res1=res1, relu=relu, planes=_bf16_split_mode())
-            return
-        mode = _resblock_conv()
-        if mode == "wbf16" and len(pk) > 5 and pk[5] is not None:
-            K.conv3x3_wbf16(g, x, pk[5], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
-            return
-        if mode == "bf16s" and len(pk) > 4 and pk[4] is not None:
-            # 512-pixel x 64-cout workgroups: keep it only where they fill the chip (small per-GPU batches at the
-            # coarse U-Net levels fall through to the Winograd kernel)
-            if ((g.np + 511) // 512) * (pk[0][2] // 64) >= 192 or os.environ.get("DINV_DRUNET_CONV_FORCE"):
-                K.conv3x3_bf16s(g, x, pk[4], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
-                return
-        if pk[2] is not None and mode != "direct" and _use_winograd(g, pk):
+    def _conv_fp32(self, g, pk, x, y, relu=False, res1=None):
+        """one ResBlock convolution in fp32 arithmetic: Winograd F(2x2,3x3) kernel, else the direct MFMA kernel"""
+        if pk[2] is not None:
             K.conv3x3_winograd(g, x, pk[2], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
             return
         (w, ci, co) = self._pick(g, pk)
         K.conv3x3(g, x, w, ci, co, y, relu=relu, res1=res1)
 
-    def _res_chain(self, g, blocks, c, x, a, b, t, last_extra=None):
+    def _res_block(self, g, pk1, pk2, x, t, y):
+        """y = x + conv2(relu(conv1(x))) (drunet.py:403-434); `t` is scratch.  bf16-split precision: conv1 writes its ReLU
+        output pre-split (the parts conv2 would form anyway), conv2 stages it by plain copies and adds the fp32 residual"""
+        if pk1[3] is not None and pk2[3] is not None:
+            K.conv3x3_split(g, x, pk1[3], pk1[0][1], pk1[0][2], t, relu=True, y_presplit=True)
+            K.conv3x3_split(g, t, pk2[3], pk2[0][1], pk2[0][2], y, res1=x, x_presplit=True)
+        else:
+            self._conv_fp32(g, pk1, x, t, relu=True)
+            self._conv_fp32(g, pk2, t, y, res1=x)
+
+    def _res_chain(self, g, blocks, c, x, a, b, t):
         """run ResBlocks: returns the buffer holding the result (never `x` itself is overwritten)"""
         cur = x
         bufs = [a, b]
         for i, (pk1, pk2) in enumerate(blocks):
             dst = bufs[i % 2]
-            extra = last_extra if i == len(blocks) - 1 else None
-            if extra is None:
-                self._conv_res(g, pk1, cur, t, relu=True)
-                self._conv_res(g, pk2, t, dst, res1=cur)
-            else:
-                (w1, ci, co), (w2, _, _) = self._pick(g, pk1), self._pick(g, pk2)
-                K.conv3x3(g, cur, w1, ci, co, t, relu=True)
-                K.conv3x3(g, t, w2, ci, co, dst, res1=cur, res2=extra)
+            self._res_block(g, pk1, pk2, cur, t, dst)
             cur = dst
         return cur
 
@@ -326,7 +305,7 @@ class DRUNet(Denoiser):
         downs = ("m_down1", "m_down2", "m_down3")
         for i, name in enumerate(downs):
             r = self._res_chain(g[i], e[name], nc[i], cur, ws[f"a{i}"], ws[f"b{i}"], ws[f"t{i}"])
-            if e[name + "_sb"] is not None and _resblock_conv() == "bf16s":   # same arithmetic as the ResBlock convs
+            if e[name + "_sb"] is not None:   # same arithmetic as the ResBlock convs
                 K.down2x2_bf16s(g[i], g[i + 1], r, e[name + "_sb"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])   # x2, x3, x4
             else:
                 K.down2x2(g[i], g[i + 1], r, e[name + "_s"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])
@@ -334,7 +313,7 @@ class DRUNet(Denoiser):
         r = self._res_chain(g[3], e["m_body"], nc[3], cur, ws["a3"], ws["b3"], ws["t3"])
         skip_add = ws["skip3"]  # x + x4 is fused into the up-conv's operand load
         for i, name in zip((2, 1, 0), ("m_up3", "m_up2", "m_up1")):
-            if e[name + "_sb"] is not None and _resblock_conv() == "bf16s":
+            if e[name + "_sb"] is not None:
                 K.up2x2_bf16s(g[i + 1], g[i], r, skip_add, e[name + "_sb"], nc[i + 1], nc[i], ws[f"t{i}"])
             else:
                 K.up2x2(g[i + 1], g[i], r, skip_add, e[name + "_s"], nc[i + 1], nc[i], ws[f"t{i}"])
@@ -354,7 +333,6 @@ class DRUNet(Denoiser):
         """ResBlocks whose input lives in the `t` buffer: rotate roles so nothing is clobbered."""
         cur, tmp, other = t_in, a, b
         for (pk1, pk2) in blocks:
-            self._conv_res(g, pk1, cur, tmp, relu=True)
-            self._conv_res(g, pk2, tmp, other, res1=cur)
+            self._res_block(g, pk1, pk2, cur, tmp, other)
             cur, other = other, cur
         return cur

@@ -29,7 +29,7 @@ from ..hip import elementwise as ew
 
 
 def supported(model) -> bool:
-    return model.dim == 3 and len(model.nc) == 4 and os.environ.get("DINV_DRUNET3D", "hip") != "torch"
+    return model.dim == 3 and len(model.nc) == 4
 
 
 def _r64(c):
@@ -76,7 +76,7 @@ def _pad_w(w, d0, d1):
 def _conv2d(g, w, x, y, res1, fp32):
     cout, cin = w.shape[:2]
     if cin >= 16 and cout >= 16 and not fp32:
-        K.conv3x3_bf16s(g, x, K.pack_bf16s_weight(_pad_w(w, _r64(cout), _r16(cin))), _r16(cin), _r64(cout), y, res1=res1)
+        K.conv3x3_split(g, x, K.pack_split2d_weight(_pad_w(w, _r64(cout), _r16(cin))), _r16(cin), _r64(cout), y, res1=res1)
     else:           # thin head / tail layers, and the mask-exact forward of the training path
         wpk, ci_p, co_p = K.pack_conv3x3_weight(w)
         K.conv3x3(g, x, wpk, ci_p, co_p, y, cout_valid=cout, res1=res1)
@@ -150,7 +150,7 @@ class DRUNet3dFunction(torch.autograd.Function):
         if D % 8 or H % 8 or Wd % 8:
             raise ValueError("3-D DRUNet on the HIP kernels needs depth, height and width to be multiples of 8")
         train = any(ctx.needs_input_grad[1:])
-        f32 = train and os.environ.get("DINV_DRUNET_TRAIN_PRECISION", "fp32") == "fp32"
+        f32 = train and getattr(model, "train_forward_precision", "fp32") == "fp32"
         lv = [Level(B, D >> i, H >> i, Wd >> i) for i in range(4)]
         W = {n: p.detach().float() for n, p in zip(names, params)}      # true shapes; each kernel pads what it needs
         # pack the input volume: [B, C, D, H, W] -> slices [B (D+2), C, H, W] with zero end slices

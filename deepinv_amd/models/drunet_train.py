@@ -60,10 +60,10 @@ def _flip_t(w):
     return w.flip(2, 3).transpose(0, 1).contiguous()
 
 
-def _fp32_forward() -> bool:
-    v = os.environ.get("DINV_DRUNET_TRAIN_PRECISION", "fp32")
-    if v not in ("fp32", "bf16s"):
-        raise ValueError(f"DINV_DRUNET_TRAIN_PRECISION must be fp32 or bf16s, got {v}")
+def _fp32_forward(model) -> bool:
+    v = getattr(model, "train_forward_precision", "fp32")
+    if v not in ("fp32", "bf16split"):
+        raise ValueError(f"train_forward_precision must be fp32 or bf16split, got {v}")
     return v == "fp32"
 
 
@@ -72,7 +72,7 @@ def _conv3(g, w, x, relu=False, res1=None, fp32=False):
     cout, cin = w.shape[:2]
     y = K.alloc(g, cout, x.device)
     if cout % 64 == 0 and cin % 16 == 0 and not fp32:
-        K.conv3x3_bf16s(g, x, K.pack_bf16s_weight(w), cin, cout, y, res1=res1, relu=relu)
+        K.conv3x3_split(g, x, K.pack_split2d_weight(w), cin, cout, y, res1=res1, relu=relu)
     else:
         wpk, ci_p, co_p = K.pack_conv3x3_weight(w)
         K.conv3x3(g, x, wpk, ci_p, co_p, y, cout_valid=cout, res1=res1, relu=relu)
@@ -128,7 +128,7 @@ class DRUNetFunction(torch.autograd.Function):
         x_act = K.alloc(g[0], C, dev)
         K.pack_input(g[0], xin[:, :-1].contiguous(), xin[:, -1:].contiguous(), x_act)
         saved = {"x_act": x_act, "res": {}, "down_in": {}, "up_in": {}}
-        f32 = _fp32_forward()
+        f32 = _fp32_forward(model)
 
         def res_chain(gl, prefix, first, cur):
             for k in range(first, first + nb):

@@ -40,6 +40,14 @@ class BaseOptim(Reconstructor):
                  unfold=False, trainable_params=None, verbose=False,
                  show_progress_bar=False, **kwargs):
         super().__init__()
+        # the reference's BaseOptim also takes DEQ= and anderson_acceleration= (optimizers.py:295-296); neither is on the
+        # accelerated path - refuse them loudly instead of running a plain loop under their name
+        for k in ("DEQ", "anderson_acceleration"):
+            if kwargs.pop(k, None) not in (None, False):
+                raise NotImplementedError(f"deepinv_amd.optim: {k} is not implemented (only the plain fixed-point loop, "
+                                          "optionally unfolded, is on the accelerated path)")
+        if kwargs:
+            raise TypeError(f"BaseOptim got unexpected keyword arguments {sorted(kwargs)}")
         self.early_stop, self.crit_conv, self.verbose = early_stop, crit_conv, verbose
         self.show_progress_bar, self.max_iter = show_progress_bar, max_iter
         if isinstance(backtracking, bool):
@@ -95,7 +103,8 @@ class BaseOptim(Reconstructor):
             init_metrics_fn=self.init_metrics_fn, init_iterate_fn=self.init_iterate_fn,
             update_metrics_fn=self.update_metrics_fn, max_iter=max_iter, early_stop=early_stop,
             backtracking_config=self.backtracking_config, verbose=verbose,
-            show_progress_bar=show_progress_bar)
+            show_progress_bar=show_progress_bar, conv_crit_fn=self.conv_crit, thres_conv=thres_conv,
+            on_converged=self._set_converged)
 
     # ---- per-iteration lookups (optimizers.py:464-500)
     def update_params_fn(self, it):
@@ -175,19 +184,39 @@ class BaseOptim(Reconstructor):
             return False
         return True
 
-    def check_conv_fn(self, it, X_prev, X):
+    def conv_crit(self, X_prev, X):
+        """the convergence criterion as a tensor (a device scalar on the HIP path; optimizers.py:703-739)"""
         if self.crit_conv == "residual":
             x_prev = self.get_output(X_prev).reshape(self.get_output(X_prev).shape[0], -1)
             x = self.get_output(X).reshape(x_prev.shape[0], -1)
-            crit = ((x_prev - x).norm(p=2, dim=-1) / (x.norm(p=2, dim=-1) + 1e-6)).mean()
-        elif self.crit_conv == "cost":
-            crit = ((X_prev["cost"] - X["cost"]).norm(dim=-1) / (X["cost"].norm(dim=-1) + 1e-6)).mean()
-        else:
-            raise ValueError("convergence criteria not implemented")
-        if crit < self.thres_conv:
+            return ((x_prev - x).norm(p=2, dim=-1) / (x.norm(p=2, dim=-1) + 1e-6)).mean()
+        if self.crit_conv == "cost":
+            return ((X_prev["cost"] - X["cost"]).norm(dim=-1) / (X["cost"].norm(dim=-1) + 1e-6)).mean()
+        raise ValueError("convergence criteria not implemented")
+
+    def check_conv_fn(self, it, X_prev, X):
+        """host-side decision (one sync): used with metrics / backtracking / CPU tensors; on the HIP path without them
+        FixedPoint decides on the device from `conv_crit` and never reads the criterion back per iteration"""
+        if self.conv_crit(X_prev, X) < self.thres_conv:
             self.has_converged = True
             return True
         return False
+
+    def _set_converged(self, flag):
+        self._converged_flag = flag          # device tensor: read (one sync) only when `has_converged` is looked at
+
+    @property
+    def has_converged(self):
+        f = self.__dict__.get("_converged_flag")
+        if f is not None:
+            self.__dict__["_has_converged"] = bool(f)
+            self.__dict__["_converged_flag"] = None
+        return self.__dict__.get("_has_converged", False)
+
+    @has_converged.setter
+    def has_converged(self, v):
+        self.__dict__["_converged_flag"] = None
+        self.__dict__["_has_converged"] = bool(v)
 
     def forward(self, y, physics, init=None, x_gt=None, compute_metrics=False, **kwargs):
         """no_grad unless unfolding (optimizers.py:826-881)"""
@@ -212,7 +241,11 @@ def create_iterator(iteration, prior=None, cost_fn=None, g_first=False, bregman_
     else:
         has_cost = False
     if isinstance(iteration, str):
-        return getattr(_its, iteration + "Iteration")(g_first=g_first, cost_fn=cost_fn, has_cost=has_cost)
+        cls = getattr(_its, iteration + "Iteration", None)
+        if cls is None:
+            raise NotImplementedError(f"iteration '{iteration}' is not implemented by deepinv_amd.optim (available: PGD, HQS); "
+                                      "pass an OptimIterator instance for anything else")
+        return cls(g_first=g_first, cost_fn=cost_fn, has_cost=has_cost)
     return iteration
 
 

@@ -300,7 +300,7 @@ def conv_transpose2d(y, filter, padding, H, W):
     """exact transpose of conv2d: obtained by autograd, which is what the reference's own adjointness tests
     (test_physics_functional.py:158-246) pin conv_transpose2d + _apply_transpose_padding against."""
     B, C = y.shape[:2]
-    x = torch.zeros(B, C, H, W, requires_grad=True)
+    x = torch.zeros(B, C, H, W, dtype=y.dtype, requires_grad=True)
     _, vjp = torch.func.vjp(lambda v: conv2d(v, filter, padding), x)
     return vjp(y)[0]
 
@@ -372,6 +372,24 @@ def downsampling_prox_l2(z, y, gamma, filter, factor, img_size):
     below = torch.mean(splits(Fh2, factor), dim=-1) + 1 / gamma
     rc = Fhc * (top / below).repeat(1, 1, factor, factor)
     return (z_hat - torch.real(torch.fft.ifft2(rc))) * gamma
+
+
+def downsampling_prox_l2_residual(z, y, gamma, filter, factor, img_size):
+    """The same minimiser as `downsampling_prox_l2` (blur.py:331-363) written as z + A^T (A A^T + I/gamma)^-1 (y - A z):
+    A A^T is diagonalised by the low-resolution DFT with symbol mean_blocks(|K|^2).  Algebraically identical (Woodbury),
+    without the gamma-fold cancellation of the reference's form; used to QUANTIFY that cancellation (the product
+    evaluates this form, deepinv_amd/physics/blur.py: Downsampling.prox_l2)."""
+    Fh = filter_fft(filter, img_size, real_fft=False)
+    Fh2 = (torch.conj(Fh) * Fh).real
+
+    def splits(a, sf):
+        b = torch.stack(torch.chunk(a, sf, dim=2), dim=4)
+        return torch.cat(torch.chunk(b, sf, dim=3), dim=4)
+
+    below = torch.mean(splits(Fh2, factor), dim=-1) + 1 / gamma
+    r = y - downsampling_A(z, filter, factor)
+    s = torch.fft.ifft2(torch.fft.fft2(r) / below).real
+    return z + downsampling_AT(s, filter, factor, img_size)
 
 
 def iradon_backproject(y, angles_deg, W, circle=False):

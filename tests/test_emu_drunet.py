@@ -23,7 +23,7 @@ def geom(B, H, W):
     g.plane = g.hp * g.wp
     g.np = g.plane * B
     g.sl = g.wp + 4
-    g.cs = g.sl + (g.np + 511) // 512 * 512 + g.wp + 4
+    g.cs = g.sl + max((g.np + 511) // 512 * 512 + g.wp + 4, g.np + 34 * g.wp + 64)
     g.cs = (g.cs + 3) // 4 * 4
     return g
 
@@ -50,6 +50,110 @@ def pack(w):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from deepinv_amd.hip.drunet import pack_bf16s_weight   # pure torch host code
     return pack_bf16s_weight(w)
+
+
+def split_to_act(t, g):
+    """pre-split activation buffer: per pixel and 8-channel block, 8 bf16 high parts then 8 bf16 low parts (32 bytes)"""
+    a = to_act(t, g)
+    hi = a.bfloat16()
+    lo = (a - hi.float()).bfloat16()
+    return torch.cat((hi, lo), dim=-1).view(torch.float32).contiguous()      # [C/8, cs, 8] fp32 words holding 16 bf16
+
+
+def split_from_act(a, g, C):
+    h = a.view(torch.bfloat16).view(a.shape[0], a.shape[1], 16)
+    return from_act((h[..., :8].float() + h[..., 8:].float()).contiguous(), g, C)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 12, 20, 16, 64, "plain"), (2, 9, 14, 32, 64, "relu"),
+                                                 (1, 17, 33, 32, 128, "res"), (3, 16, 16, 64, 64, "plain"),
+                                                 (1, 8, 32, 16, 64, "relu"), (2, 40, 48, 16, 128, "res"),
+                                                 (2, 40, 64, 32, 64, "res")])
+@pytest.mark.parametrize("fmt", ["f32", "in_split", "out_split"])
+@pytest.mark.parametrize("tile", [1, 2])     # 128- / 256-pixel workgroups
+def test_split2d_conv_matches_fp64(B, H, W, cin, cout, mode, fmt, tile):
+    """csrc/drunet_split2d.hip (2-D tiles, optional pre-split activations) against an fp64 convolution; tile widths 32 /
+    16 / 8 incl. partial column tiles (W = 20, 14, 33) and row tiles that straddle images"""
+    if fmt == "out_split" and mode == "res":
+        pytest.skip("a pre-split output carries no residual")
+    gen = torch.Generator().manual_seed(H * W + cin)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / (3.0 * cin ** 0.5)
+    r = torch.randn(B, cout, H, W, generator=gen)
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_split2d_weight
+    g = geom(B, H, W)
+    if fmt == "in_split":
+        xa = split_to_act(x, g)
+        x = split_from_act(xa, g, cin)              # the operand the kernel really sees
+    else:
+        xa = to_act(x, g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+    ra = to_act(r, g)
+    ya = torch.full((cout // 8, g.cs, 8), float("nan"))
+    ya[:, :g.sl] = 0
+    ya[:, g.sl + g.np:] = 0
+    ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, :, 0] = 0        # frame columns are never written: must stay zero
+    ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, :, W + 1:] = 0
+    wp = pack_split2d_weight(w)
+    flags = (1 if fmt == "in_split" else 0) | (2 if fmt == "out_split" else 0) | (4 if mode == "relu" else 0) | (tile << 8)
+    l = E.lib()
+    E.check(l.dinv_conv3x3_split(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya),
+                                 E.p(ra) if mode == "res" else None, flags, None))
+    assert not torch.isnan(ya).any()
+    out = split_from_act(ya, g, cout) if fmt == "out_split" else from_act(ya, g, cout)
+    err = float((out.double() - ref).norm() / ref.norm())
+    assert err < 2e-5, err
+    # the zero frame survives (rows between images are written as zeros, frame columns untouched)
+    full = ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
+    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, H + 1].abs().max()) == 0
+    assert float(full[:, :, :, 0].abs().max()) == 0 and float(full[:, :, :, W + 1:].abs().max()) == 0
+
+
+def wide_range(shape, lo_exp, hi_exp, gen):
+    """random signs and mantissas, exponents uniform in [lo_exp, hi_exp]: operands spanning many binades"""
+    e = torch.randint(lo_exp, hi_exp + 1, shape, generator=gen).float()
+    return (1 + torch.rand(shape, generator=gen)) * torch.exp2(e) * (torch.randint(0, 2, shape, generator=gen) * 2 - 1).float()
+
+
+@pytest.mark.parametrize("case", ["wide", "he_scale"])
+def test_split_worst_case(case):
+    """The operand split's WORST-CASE bound, checked element by element: x = xh + xl + e with |e| <= 2^-16 |x| (xl is the
+    bf16 rounding of an exact remainder of at most 2^-8 |x|), the dropped al*bl product is at most 2^-16 |a||b|, so every
+    output obeys |y - y_exact| <= 3 * 2^-16 * (|w| conv |x|) + fp32 accumulation (bounded here by 2^-20 of the same sum).
+    `wide`: activations spanning 2^-20 .. 2^8 and weights 2^-12 .. 2^2 (no subnormal low parts: bf16 keeps the fp32
+    exponent range); `he_scale`: O(1)-gain weights (std sqrt(2 / fan_in)) like a trained ResBlock, N(0,1) data, where the
+    typical error must stay at the few-1e-6 level."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_split2d_weight
+    gen = torch.Generator().manual_seed(11)
+    B, H, W, cin, cout = 2, 16, 32, 64, 64
+    if case == "wide":
+        x, w = wide_range((B, cin, H, W), -20, 8, gen), wide_range((cout, cin, 3, 3), -12, 2, gen)
+    else:
+        x, w = torch.randn(B, cin, H, W, generator=gen), torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    mag = torch.nn.functional.conv2d(x.double().abs(), w.double().abs(), padding=1)
+    g = geom(B, H, W)
+    xa = to_act(x, g)
+    ya = torch.zeros(cout // 8, g.cs, 8)
+    l = E.lib()
+    wp = pack_split2d_weight(w)        # keep the packed tensor alive across the call
+    E.check(l.dinv_conv3x3_split(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya), None, 0, None))
+    out = from_act(ya, g, cout).double()
+    bound = (3 * 2.0 ** -16 + 2.0 ** -20) * mag
+    assert bool(((out - ref).abs() <= bound).all()), float(((out - ref).abs() / mag).max())
+    # the bound is not vacuous: the observed worst element uses a visible part of it, the typical one far less
+    worst = float(((out - ref).abs() / mag).max())
+    assert worst < 3 * 2.0 ** -16
+    if case == "he_scale":
+        assert float((out - ref).norm() / ref.norm()) < 5e-6
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 12, 20, 16, 64, "plain"), (2, 9, 14, 32, 64, "relu"),

@@ -171,7 +171,7 @@ def test_back_to_back_reconstructions_use_their_own_adjoint(dev):
 
 
 def test_graph_replay_of_the_loop_matches_eager(dev, monkeypatch):
-    """DINV_LOOP_GRAPH=1: iteration 0 eager, iteration 1 captured into a HIP graph, the rest replayed - same kernels,
+    """`model.fixed_point.use_graph = True`: iteration 0 eager, iteration 1 captured into a HIP graph, the rest replayed - same kernels,
     same arithmetic, so the reconstruction is identical (PnP-PGD on multi-coil MRI; PnP-HQS whose prox is a CG solve
     with the device-side convergence flag recorded into the graph)."""
     import deepinv_amd as dinv
@@ -185,9 +185,8 @@ def test_graph_replay_of_the_loop_matches_eager(dev, monkeypatch):
     y = phys.A(torch.rand(2, 2, H, W, generator=g).to(dev))
     for algo, kw in ((dinv.optim.PGD, dict(stepsize=1.0)), (dinv.optim.HQS, dict(stepsize=2.0))):
         model = algo(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), g_param=0.05, max_iter=6, early_stop=False, **kw)
-        monkeypatch.setenv("DINV_LOOP_GRAPH", "0")
         ref = model(y, phys)
-        monkeypatch.setenv("DINV_LOOP_GRAPH", "1")
+        model.fixed_point.use_graph = True
         out = model(y, phys)
         out2 = model(y, phys)      # a second call re-captures: nothing stale survives the first
         assert rel_err(out, ref) < 1e-6 and torch.equal(out, out2), algo.__name__
@@ -213,7 +212,7 @@ def test_unfolded_pgd_2d_drunet_prior_hip_backward(dev, monkeypatch):
                                            trainable_params=["stepsize", "g_param"], device=dev).to(dev)
 
     def run(mode):
-        monkeypatch.setenv("DINV_DRUNET_TRAIN", mode)
+        den.backend = mode
         model.zero_grad()
         loss = (model(y, phys) - x).pow(2).mean()
         loss.backward()
@@ -226,3 +225,44 @@ def test_unfolded_pgd_2d_drunet_prior_hip_backward(dev, monkeypatch):
     errs = {n: rel_err(gh[n], gt[n]) for n in gt}
     worst = max(errs.items(), key=lambda t: t[1])
     assert worst[1] < 1e-3, worst            # three chained DRUNet calls; measured ~1e-5
+
+
+def test_early_stop_is_decided_on_the_device(dev):
+    """early_stop=True (optimizers.py:703-739) without a per-iteration host sync: the convergence flag lives on the device,
+    later iterates are frozen copies, the host polls a pinned copy every 4 iterations.  Same reconstruction and same
+    `has_converged` as the host-decided loop (forced here by asking for metrics), eager and under HIP-graph replay; and a
+    threshold that is never met runs all iterations."""
+    import deepinv_amd as dinv
+
+    H = W = 64
+    g = torch.Generator().manual_seed(8)
+    maps = (torch.randn(1, 4, H, W, dtype=torch.complex64, generator=g) / 2).to(dev)
+    mask = dinv.utils.radial_mask(H, W, 16).to(dev)
+    phys = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, H, W), device=dev)
+    y = phys.A(torch.rand(3, 2, H, W, generator=g).to(dev))
+
+    class Shrink(torch.nn.Module):          # a contraction: the iteration converges geometrically
+        def forward(self, u, s):
+            return 0.5 * u
+
+    def build(thres):
+        return dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(Shrink()), stepsize=1.0, g_param=0.05,
+                              max_iter=40, early_stop=True, thres_conv=thres)
+
+    host = build(1e-4)
+    ref, metrics = host(y, phys, compute_metrics=True)          # metrics force the host-side decision
+    n_host = len(metrics["residual"][0])
+    assert host.has_converged and 3 < n_host < 40
+    devm = build(1e-4)
+    calls = []
+    it0 = devm.fixed_point.iterator.forward
+    devm.fixed_point.iterator.forward = lambda *a, **k: (calls.append(1), it0(*a, **k))[1]
+    out = devm(y, phys)
+    assert torch.equal(out, ref) and devm.has_converged
+    assert n_host <= len(calls) <= n_host + 2 * devm.fixed_point.poll_every     # stops within two polls of the flag
+    gm = build(1e-4)
+    gm.fixed_point.use_graph = True
+    assert torch.equal(gm(y, phys), ref) and gm.has_converged
+    never = build(0.0)
+    full = never(y, phys)
+    assert not never.has_converged and torch.isfinite(full).all()

@@ -229,6 +229,23 @@ def test_diffpir_matches_reference_sample_path():
     assert close(out, d["out"], 1e-4)
 
 
+def test_downsampling_prox_forms():
+    """Downsampling.prox_l2 (blur.py:331-363): the reference's closed form and the residual form the product evaluates
+    are the same minimiser (fp64: 1e-11), but in fp32 the reference's form loses digits in proportion to gamma: at
+    DiffPIR's first-step gamma = 1/(2 rho) = 7e5 it is ~5e-3 off the exact result, the residual form ~3e-7.  This is the
+    measured replacement for the prose that used to justify a 1e-3 DiffPIR tolerance."""
+    d = load("diffpir")
+    img, f = (3, 32, 32), 4
+    z = torch.rand(2, *img, generator=torch.Generator().manual_seed(0))
+    for gam, ref_lo, ref_hi in ((0.7, 0.0, 1e-6), (7e5, 1e-4, 1e-1)):
+        exact = O.downsampling_prox_l2(z.double(), d["y"].double(), gam, d["k"].double(), f, img)
+        assert close(O.downsampling_prox_l2_residual(z.double(), d["y"].double(), gam, d["k"].double(), f, img), exact, 1e-9)
+        e_ref = float((O.downsampling_prox_l2(z, d["y"], gam, d["k"], f, img).double() - exact).norm() / exact.norm())
+        e_res = float((O.downsampling_prox_l2_residual(z, d["y"], gam, d["k"], f, img).double() - exact).norm() / exact.norm())
+        assert ref_lo <= e_ref <= ref_hi, (gam, e_ref)
+        assert e_res < 2e-6, (gam, e_res)
+
+
 def test_tomography_fan_beam():
     """fan_beam_grid / Radon(fan_beam=True) / Tomography.fbp with the fan branch (radon.py:16-52, tomography.py:229-350)"""
     import numpy as np

@@ -113,7 +113,7 @@ def test_iradon_branch_adjoint_via_backprop_false(dev, W, nang, circle):
 @pytest.mark.parametrize("W,angles,B", [(97, [0., 44.9, 45., 45.1, 89.9, 90., 90.1, 134.9, 135., 135.1, 179.9], 5),
                                         (50, [-30., 200., 359., 720.5, 17., 93., -91.], 1), (192, 120, 8)])
 def test_tiled_and_gather_kernels_agree(dev, W, angles, B, monkeypatch):
-    """The LDS-tiled kernels (default) against the round-1 gather kernels (DINV_RADON_TILED=0): same samples, same
+    """The LDS-tiled kernels (default) against the round-1 gather kernels (hip.radon.ENABLE_TILED = False): same samples, same
     weights - only the summation order may differ; class borders, arbitrary angle lists, a full 8-image group."""
     import deepinv_amd as dinv
 
@@ -125,12 +125,13 @@ def test_tiled_and_gather_kernels_agree(dev, W, angles, B, monkeypatch):
     v = torch.randn(y.shape, generator=g).to(dev)
     xa = phys.A_adjoint(v)
     assert dot_test(phys, x, y) < 1e-5
-    monkeypatch.setenv("DINV_RADON_TILED", "0")
+    from deepinv_amd.hip import radon as HR
+    monkeypatch.setattr(HR, "ENABLE_TILED", False)
     assert rel_err(y, phys.A(x)) < 1e-5
     assert rel_err(xa, phys.A_adjoint(v)) < 1e-5
-    monkeypatch.setenv("DINV_RAMP_FFT", "0")
+    monkeypatch.setattr(HR, "ENABLE_RAMP_FFT", False)
     r_direct = phys.filter(y)
-    monkeypatch.delenv("DINV_RAMP_FFT")
+    monkeypatch.setattr(HR, "ENABLE_RAMP_FFT", True)
     assert rel_err(phys.filter(y), r_direct) < 1e-5
 
 
