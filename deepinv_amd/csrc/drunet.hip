@@ -493,8 +493,7 @@ extern "C" int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const f
     DINV_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= 1 && cout <= 4, "tail conv needs cin %% 8 == 0 and 1 <= cout <= 4 (got %d,%d)", cin, cout);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const Geom gg = make_geom(*g);
-    static const bool one_pixel = getenv("DINV_TAIL_ONE_PIXEL") != nullptr;   // the first form, kept for comparison
-    if (!one_pixel && g->batch <= 65535) {
+    if (g->batch <= 65535) {
         const dim3 rgrid((unsigned)ceil_div(g->wp, 64), (unsigned)ceil_div(ceil_div(g->height, 4), 4), (unsigned)g->batch);
         switch (cout) {
             case 1: hipLaunchKernelGGL(tail3x3_rows_kernel<1>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;

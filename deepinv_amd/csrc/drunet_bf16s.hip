@@ -1,63 +1,12 @@
-// DRUNet ResBlock 3x3 convolution on the BF16 matrix cores with a two-part exact operand split (gfx950).
-//
-// Operator: y = [relu](conv3x3(x)) (+ res1), stride 1, zero padding 1, no bias (deepinv/models/drunet.py:403-434),
-// on the padded channel-blocked activation layout of drunet.hip.
-//
-// Arithmetic: every fp32 operand is written as x = xh + xl with bf16 parts (xh = bf16(x), xl = bf16(x - xh), both
-// round-to-nearest-even; x - xh is exact), and a product a*b is evaluated as ah*bl + al*bh + ah*bh with fp32
-// accumulation in v_mfma_f32_32x32x16_bf16: the dropped al*bl term and the rounding of the low parts are ~2^-17
-// relative per operand, 2-4e-6 per layer against an fp64 convolution and 1.7e-6 on the DRUNet output with O(1)-gain
-// ResBlock weights (tests/test_drunet_gpu.py, tests/test_golden_gpu.py).  The bf16 matrix pipe is 16x the fp32 one and
-// co-issues with the vector ALU, so three products leave a 5.3x higher ceiling than the fp32 MFMA path.
-//
-// Structure (what differs from the first bf16 kernel, drunet_bf16.hip):
-//   * K = 16 per MFMA = 2 channel blocks of 8 x ONE tap (lane half h supplies channel block 2s + h): no padding tap,
-//     9 MFMAs per tile and 16 channels instead of 10;
-//   * workgroup = 8 waves = 512 consecutive padded pixels x 64 couts, each wave a 64 x 64 tile (2 x 2 accumulators);
-//   * the K loop runs over sub-steps (16 channels, one kernel row dy): a sub-step needs one 514-pixel row segment of
-//     the input (split into hi / lo bf16 planes while it is staged) and 3 taps x 16 channels x 64 couts of pre-split
-//     weights = 45 KB of LDS; two such stages alternate: the global loads of sub-step t+2 (into registers) and the
-//     split + LDS write of sub-step t+1 run underneath the 36 MFMAs per wave of sub-step t; ONE barrier per sub-step.
-//     Waves 4-7 stage before their MFMAs, waves 0-3 after them, so that on a SIMD (which holds waves w and w+4) one
-//     wave's vector work overlaps the other wave's matrix work.
-//
-// Measured on MI355X (level 1: 128 channels, 160x160, B = 32; random data, so the matrix pipe runs at its power-limited
-// ~2.0 GHz): this kernel 0.73-0.85 ms = 1.0 PFLOP/s executed (the best plain-HIP bf16 GEMMs reach 1.25-1.34 PFLOP/s on
-// random operands, cdna_hip_programming.md 5); the same loop without staging 0.63 ms, staging without MFMAs 0.40 ms.
-// Variants that were built and measured slower: loads two sub-steps ahead in a second register set (0.89 ms), a
-// three-slot ring with the next sub-step's first operands read before the barrier and sched_barrier-pinned phases
-// (0.89 ms: pinning keeps the split's vector work out of the MFMA blocks of the same wave); persistent workgroups that
-// carry the staging pipeline across (pixel tile, cout tile) items, so that only the accumulator write-back separates
-// two items (47.6 ms per DRUNet forward against 45.3 ms: the bookkeeping in the hot loop costs more than the ~9 us of
-// pipeline fill + write-back per 512-pixel tile that a fit of t = tiles x (F + nsub x 2.0 us) shows).
+// DRUNet 2x2 stride-2 down / up convolutions on the BF16 matrix cores with the two-part exact operand split (gfx950):
+// x = xh + xl (xh = bf16(x), xl = bf16(x - xh)), a product is ah*bl + al*bh + ah*bh with fp32 accumulation in
+// v_mfma_f32_32x32x16_bf16 - the same arithmetic as the ResBlock 3x3 convolutions (drunet_split2d.hip).
 #include "drunet_common.hpp"
 
 using namespace dinv;
 using namespace dinv_drunet;
 
 namespace {
-
-constexpr int TPMAX = 512;              // pixels per workgroup of the widest variant (the geometry is padded for it)
-constexpr int WUNITS = 2 * 3 * 2 * 64;  // ... of its weights: [plane][dx][cblk][co 64]
-constexpr int NSTAGE = 2;
-// NW waves per workgroup: 8 -> 512 pixels, one workgroup per CU (2 x 45 KB of LDS); 4 -> 256 pixels, TWO workgroups per
-// CU (2 x 29 KB each) whose phases drift apart, so one's pipeline fill / epilogue runs under the other's MFMAs
-template <int NW> struct Tile {
-    static constexpr int TP = NW * 64;
-    static constexpr int SEGX = TP + 2;            // staged row segment (one halo pixel on each side)
-    static constexpr int XUNITS = 2 * 2 * SEGX;    // 16-byte units of a stage's activations: [plane][cblk][SEGX]
-    static constexpr int STAGE = XUNITS + WUNITS;  // NW = 8: 2824 units = 45,184 bytes
-};
-
-struct SArgs {
-    Geom g;
-    const float* x;
-    const uint4* w;    // [cout/64][cin/16][dy 3][plane 2][dx 3][cblk 2][co 64] x (8 bf16)
-    float* y;
-    const float* res1;
-    int32_t cin, cblocks_valid;
-    int32_t ntiles, ytiles, tiles_per_xcd;
-};
 
 __device__ __forceinline__ unsigned f2bf(float f) {   // round to nearest even, as v_cvt_pk_bf16_f32
 #ifdef DINV_EMU
@@ -97,137 +46,6 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 #endif
-
-struct Staged {   // one sub-step's share of a thread, between its global loads and its LDS writes
-    float4 x0a, x0b, x1a, x1b, x2a, x2b;
-    uint4 w0, w1, w2;
-};
-
-template <bool RELU, int NRES, int NW>
-__global__ __launch_bounds__(NW * 64) void conv3x3_bf16s_kernel(SArgs a) {
-    constexpr int TP = Tile<NW>::TP, SEGX = Tile<NW>::SEGX, XUNITS = Tile<NW>::XUNITS, STAGE = Tile<NW>::STAGE;
-    DINV_DYN_LDS(uint4, lds);   // [NSTAGE][STAGE]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    // XCD-aware order: consecutive pixel tiles (which share their halo rows) and the cout tiles of one pixel tile stay
-    // on one XCD (observed placement: block b runs on XCD b % 8; speed only)
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int ty = jx % a.ytiles, tl = jx / a.ytiles;
-    const int tile = xcd * a.tiles_per_xcd + tl;
-    if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;
-    const int64_t p0 = (int64_t)tile * TP;
-    const int nsub = 3 * (a.cin / 16);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    // ---- this thread's staging slots (the same in every sub-step).  Every thread moves two full chunks (its pixel
-    // tid of both channel blocks) and one weight unit; the 4 chunks of the two tail pixels and the remaining 256
-    // weight units are LOADED by every thread (clamped, redundant addresses) and only WRITTEN by the threads that own
-    // them, so the loads are straight-line code without divergent branches.
-    const int tq = tid & 3;                                  // tail chunk: channel block tq>>1, pixel TP + (tq&1)
-    const int xg0 = tid * 8, xg1 = (int)(a.g.cs * 8) + tid * 8;                      // cs * 16 < 2^31 (launcher)
-    const int xg2 = (int)((int64_t)(tq >> 1) * a.g.cs * 8) + (TP + (tq & 1)) * 8;
-    const int xl0 = tid, xl1 = SEGX + tid, xl2 = (tq >> 1) * SEGX + TP + (tq & 1);    // + plane * 2 * SEGX
-    const int wu1 = NW == 8 ? 512 + (tid & 255) : 256 + tid;    // NW = 4: three weight units per thread
-    const uint4* wsrc0 = a.w + (int64_t)ty * nsub * WUNITS;
-    const float* xsrc0 = a.x + (a.g.sl + p0 - 1) * 8;
-
-    Staged rg;
-    auto issue = [&](int t) {   // global loads of sub-step t into registers
-        const int s = t / 3, dyi = t - 3 * s;
-        const float* xs = xsrc0 + ((int64_t)(2 * s) * a.g.cs + (int64_t)(dyi - 1) * a.g.wp) * 8;
-        rg.x0a = ld4(xs + xg0); rg.x0b = ld4(xs + xg0 + 4);
-        rg.x1a = ld4(xs + xg1); rg.x1b = ld4(xs + xg1 + 4);
-        rg.x2a = ld4(xs + xg2); rg.x2b = ld4(xs + xg2 + 4);
-        const uint4* ws = wsrc0 + (int64_t)t * WUNITS;
-        rg.w0 = ws[tid];
-        rg.w1 = ws[wu1];
-        if constexpr (NW == 4) rg.w2 = ws[512 + tid];
-    };
-    auto commit = [&](int t) {   // split + write the registers of sub-step t into its ring slot
-        uint4* st = lds + (t % NSTAGE) * STAGE;
-        uint4 hi, lo;
-        split8(rg.x0a, rg.x0b, hi, lo);
-        st[xl0] = hi; st[2 * SEGX + xl0] = lo;
-        split8(rg.x1a, rg.x1b, hi, lo);
-        st[xl1] = hi; st[2 * SEGX + xl1] = lo;
-        split8(rg.x2a, rg.x2b, hi, lo);
-        if (tid < 4) { st[xl2] = hi; st[2 * SEGX + xl2] = lo; }
-        st[XUNITS + tid] = rg.w0;
-        if (NW == 4 || tid < 256) st[XUNITS + wu1] = rg.w1;
-        if constexpr (NW == 4) st[XUNITS + 512 + tid] = rg.w2;
-    };
-
-    // operand slots of this lane: A = weights (row = cout l31 of m-tile, k half = channel block lhi),
-    //                             B = pixels  (col = pixel l31 of n-tile, k half = channel block lhi)
-    const int aslot = lhi * 64 + l31;                       // + (plane*3 + dx)*128 + m*32
-    const int bslot = lhi * SEGX + wv * 64 + l31;           // + plane*2*SEGX + n*32 + dx
-
-    issue(0);
-    commit(0);
-    if (nsub > 1) issue(1);
-    __syncthreads();
-    for (int t = 0; t < nsub; ++t) {
-        // registers hold sub-step t+1 (loaded one iteration ago); its slot was last read in iteration t-1, before
-        // the barrier that ended that iteration
-        // waves w and w+4 share a SIMD (dispatch order 0,2,1,3): one of each kind per SIMD; with four waves per
-        // workgroup the SIMD partner belongs to the other resident workgroup, whose phase is unrelated
-        const bool early = NW == 8 && (wv & 4) != 0;
-        if (early) {
-            if (t + 1 < nsub) commit(t + 1);
-            if (t + 2 < nsub) issue(t + 2);
-        }
-        const uint4* st = lds + (t % NSTAGE) * STAGE;
-        const uint4* xs = st;
-        const uint4* ws = st + XUNITS;
-        // operands of tap dx+1 are read while the 12 MFMAs of tap dx run; the three products go product-major, so that
-        // consecutive MFMAs write different accumulators (a dependent 32x32 MFMA would wait for its predecessor)
-        uint4 A[2][2][2], B[2][2][2];   // [buffer][tile][plane]
-        auto rd = [&](int buf, int dx) {
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) A[buf][m][pl] = ws[(pl * 3 + dx) * 128 + aslot + m * 32];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) B[buf][n][pl] = xs[pl * 2 * SEGX + bslot + n * 32 + dx];
-            }
-        };
-        rd(0, 0);
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int cur = dx & 1;
-            if (dx < 2) rd(cur ^ 1, dx + 1);
-            // smallest terms first: ah*bl, al*bh, ah*bh
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const int pa = e == 1 ? 1 : 0, pb = e == 0 ? 1 : 0;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(A[cur][m][pa], B[cur][n][pb], acc[m][n]);
-            }
-        }
-        if (!early) {
-            if (t + 1 < nsub) commit(t + 1);
-            if (t + 2 < nsub) issue(t + 2);
-        }
-        lds_barrier();   // slot t is consumed; slot t+1 is complete (global loads of t+2 stay in flight)
-    }
-    const int cb0 = ty * 8;
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int64_t p = p0 + wv * 64 + n * 32 + l31;
-        if (p >= a.g.np) continue;
-        store_tile<2, RELU, NRES>(acc, n, a.g.sl + p, interior(a.g, p), cb0, a.cblocks_valid, a.g.cs, lhi, a.y, a.res1,
-                                  nullptr);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 2x2 stride-2 convolution (downsample_strideconv, deepinv/models/drunet.py:524-552) with the same operand split.
@@ -467,50 +285,6 @@ __global__ __launch_bounds__(256) void up2x2_bf16s_kernel(UpSArgs a) {
 }
 
 }  // namespace
-
-extern "C" int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin,
-                                  int32_t cout, float* y, const float* res1, int32_t relu, dinv_stream_t stream) {
-    if (int e = check_geom(g)) return e;
-    DINV_REQUIRE(x && w_split && y, "null tensor pointer");
-    DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0,
-                 "bf16-split conv needs cin %% 16 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
-    DINV_REQUIRE(!(relu && res1), "relu and residual are not combined in DRUNet");
-    DINV_REQUIRE(g->cs >= g->sl + ceil_div(g->np, TPMAX) * TPMAX + g->wp + HALO, "channel-block stride too small for 512-pixel tiles");
-    DINV_REQUIRE(g->cs * 16 < ((int64_t)1 << 31), "activation row too long for 32-bit staging offsets");
-    SArgs a{make_geom(*g), x, reinterpret_cast<const uint4*>(w_split), y, res1, cin, cout / 8, 0, 0, 0};
-    // 256-pixel workgroups (two per CU) by default: measured per DRUNet forward (56 ResBlock convs) 44.1 vs 45.3 ms at
-    // B = 32 and 6.5 vs 7.4 ms at B = 4 (the per-GPU batch of the 8-GPU run); DINV_BF16S_WAVES=8 selects the 512-pixel form
-    const char* env_nw = getenv("DINV_BF16S_WAVES");   // read per call: the emulated CPU tests switch it
-    const int nw = env_nw && atoi(env_nw) == 8 ? 8 : 4;
-    const int tp = nw * 64;
-    a.ntiles = (int32_t)ceil_div(g->np, tp);
-    a.ytiles = cout / 64;
-    a.tiles_per_xcd = (int32_t)ceil_div(a.ntiles, 8);
-    const dim3 grid((unsigned)(a.tiles_per_xcd * a.ytiles * 8)), block((unsigned)tp);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static_assert((size_t)NSTAGE * Tile<8>::STAGE * sizeof(uint4) <= 160 * 1024, "ring does not fit the LDS");
-    static_assert((size_t)2 * NSTAGE * Tile<4>::STAGE * sizeof(uint4) <= 160 * 1024, "two 4-wave workgroups must fit one CU");
-#define DINV_S_LAUNCH(R, N, W)                                                                                    \
-    do {                                                                                                          \
-        constexpr size_t lds = (size_t)NSTAGE * Tile<W>::STAGE * sizeof(uint4);                                   \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16s_kernel<R, N, W>),         \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        if (e_ != hipSuccess) return fail(100 + (int)e_, "hipFuncSetAttribute: %s", hipGetErrorString(e_));       \
-        hipLaunchKernelGGL((conv3x3_bf16s_kernel<R, N, W>), grid, block, lds, st, a);                             \
-    } while (0)
-#define DINV_S_LAUNCH_W(R, N)          \
-    do {                               \
-        if (nw == 4) DINV_S_LAUNCH(R, N, 4); \
-        else DINV_S_LAUNCH(R, N, 8);   \
-    } while (0)
-    if (relu) DINV_S_LAUNCH_W(true, 0);
-    else if (res1) DINV_S_LAUNCH_W(false, 1);
-    else DINV_S_LAUNCH_W(false, 0);
-#undef DINV_S_LAUNCH_W
-#undef DINV_S_LAUNCH
-    DINV_CHECK_LAUNCH();
-    return 0;
-}
 
 static int down2x2_bf16s_launch(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const void* w_split,
                                 int32_t cin, int32_t cout, float* y, DepthMap dm, int accumulate, dinv_stream_t stream) {

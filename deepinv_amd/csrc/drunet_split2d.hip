@@ -18,10 +18,19 @@
 //     bits as before); conv2 reads it, adds the fp32 residual and writes fp32;
 //   * the weight rows of a 32-cout MFMA tile are permuted (host pack) so that a lane's 16 accumulator registers are two
 //     complete 8-channel blocks of one pixel: every epilogue access is 32 contiguous bytes per lane.
-// Pipeline: K loop over sub-steps (16 channels x one kernel row dy): weights of a sub-step (3 taps x 16 channels x 64
-// couts, pre-split: 12 KB) double-buffered; the activation stage of the NEXT 16-channel step (21-26 KB) is filled one
-// third per sub-step; global loads run one sub-step ahead in registers; ONE LDS-only barrier per sub-step; two
-// workgroups per CU (<= 77 KB of LDS each).
+// Pipeline: the K loop runs over 16-channel steps.  ONE activation stage (the halo region, pre-split: 21-26 KB) and ONE weight
+// stage (all nine taps x 16 channels x 64 couts, pre-split: 36 KB) live in LDS; the 108 MFMAs of a step run per wave without a
+// barrier while the next step's operands (3 activation chunks + 9 weight units per thread, loaded at the top of the step)
+// wait in registers; at the step boundary: barrier, 15 ds_write_b128 per thread, barrier.  Two workgroups per CU (59-63 KB).
+// Measured (MI355X, B = 32, profiles/r03_split2d_*.jsonl): 0.73 / 0.63 / 0.58 / 0.60 ms per launch at the four DRUNet levels
+// against 0.90 / 0.79 / 0.72 / 0.75 ms for the round-2 kernel.  Two other pipelines were built on the same tile code and
+// measured within 3 % of this one (double-buffered activation stage + per-kernel-row weight stages + a barrier per row, 2
+// workgroups per CU; single activation stage + per-row weight stages, 3 workgroups per CU): the kernel is no longer limited
+// by its structure but by the chip's power budget - on zero-filled activations the same launch runs 1.6-1.7 PFLOP/s
+// executed (0.45 ms at level 1), on random data the clock drops to ~1.9 GHz and it stops at 1.24-1.31 PFLOP/s, which is
+// what plain-HIP bf16 GEMMs reach on this chip (cdna_hip_programming.md 5).  What is left is fewer MFMAs, not better-fed ones.
+// A lesson recorded here: staging registers must be plain scalars - small arrays indexed inside lambdas were left in
+// scratch memory by hipcc, which turned every staged load into load -> wait -> scratch store (58 % of wave time parked).
 #include "drunet_common.hpp"
 
 using namespace dinv;
@@ -41,7 +50,7 @@ template <int TC_, int NREP_> struct Tile2 {
     static constexpr int ASTAGE = 4 * APL;                // [plane 2][cblk 2][AR][AW]
     static constexpr int NCH = 2 * AR * CW;               // 32-byte chunks (pixel x channel block) of a stage
     static constexpr int CPS = (NCH + 3 * 256 - 1) / (3 * 256);   // chunks per thread per sub-step
-    static constexpr int LDS_UNITS = 2 * ASTAGE + 2 * WUNITS;
+    static constexpr int LDS_UNITS = ASTAGE + 3 * WUNITS;       // one activation stage + the nine taps of a step
     static_assert(32 % TC == 0 && TP % TC == 0, "tile width must divide an MFMA n-tile");
     // lane -> pixel inside a 32-pixel n-tile: row l/TC, column (l%TC + rot) % TC.  The rotation makes the 16 lanes that
     // one ds_read_b128 cycle serves ({0-3,12-15,20-27}, {4-11,16-19,28-31}) hit 16 distinct 16-byte bank slots for the
@@ -109,11 +118,12 @@ __device__ __forceinline__ float4 as_f4(const uint4& u) {
 }
 
 template <bool IN_SPLIT, bool OUT_SPLIT, bool RELU, int NRES, int TC, int NREP>
-__global__ __launch_bounds__(256) void conv3x3_split2d_kernel(S2Args a) {
+__global__ __launch_bounds__(256, 2) void conv3x3_split2d_kernel(S2Args a) {
     using T = Tile2<TC, NREP>;
-    constexpr int TR = T::TR, AR = T::AR, CW = T::CW, AW = T::AW, APL = T::APL, ASTAGE = T::ASTAGE, NCH = T::NCH, CPS = T::CPS;
-    DINV_DYN_LDS(uint4, lds);   // [2][ASTAGE] activations, then [2][WUNITS] weights
-    uint4* const lds_w = lds + 2 * ASTAGE;
+    constexpr int TR = T::TR, AR = T::AR, CW = T::CW, AW = T::AW, APL = T::APL, ASTAGE = T::ASTAGE, NCH = T::NCH;
+    static_assert(T::CPS == 1, "one activation chunk per thread per third of the stage");
+    DINV_DYN_LDS(uint4, lds);   // [ASTAGE] activations, then [3][WUNITS] weights
+    uint4* const lds_w = lds + ASTAGE;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     // XCD-aware order: consecutive pixel tiles (shared halos) and the cout tiles of one pixel tile stay on one XCD
@@ -150,38 +160,6 @@ __global__ __launch_bounds__(256) void conv3x3_split2d_kernel(S2Args a) {
     const uint4* wsrc0 = a.w + (int64_t)ty * nsub * WUNITS;
     const int64_t step_stride = (int64_t)2 * a.g.cs * 8;      // floats per 16-channel step
 
-    // staging registers: plain scalars, never arrays indexed inside lambdas (hipcc leaves such arrays in scratch memory,
-    // which turns every staged load into load -> wait -> scratch store: measured 58 % of the wave time parked)
-    static_assert(CPS == 1, "one chunk per thread per sub-step");
-    uint4 rxa, rxb, rw0, rw1, rw2;
-    auto issue_x = [&](int s, int rd) {   // loads of round rd of step s
-        const float* p = a.x + (int64_t)s * step_stride + xoff[rd];
-        rxa = ldu4(p);
-        rxb = ldu4(p + 4);
-    };
-    auto commit_x = [&](int s, int rd) {
-        uint4* st = lds + (s & 1) * ASTAGE;
-        uint4 hi, lo;
-        if constexpr (IN_SPLIT) { hi = rxa; lo = rxb; }
-        else split8(as_f4(rxa), as_f4(rxb), hi, lo);
-        if (own[rd]) {
-            st[loff[rd]] = hi;
-            st[2 * APL + loff[rd]] = lo;
-        }
-    };
-    auto issue_w = [&](int t) {
-        const uint4* ws = wsrc0 + (int64_t)t * WUNITS;
-        rw0 = ws[tid];
-        rw1 = ws[256 + tid];
-        rw2 = ws[512 + tid];
-    };
-    auto commit_w = [&](int t) {
-        uint4* st = lds_w + (t & 1) * WUNITS;
-        st[tid] = rw0;
-        st[256 + tid] = rw1;
-        st[512 + tid] = rw2;
-    };
-
     // operand slots of this lane: A = weights (row l31 of m-tile, k half = channel block lhi),
     //                             B = pixels (pixel l31 of n-tile, k half = channel block lhi)
     const int aslot = lhi * 64 + l31;                       // + (plane*3 + dx)*128 + m*32
@@ -196,63 +174,92 @@ __global__ __launch_bounds__(256) void conv3x3_split2d_kernel(S2Args a) {
         bslot[n] = lhi * APL + tr * AW + tc;                // + plane*2*APL + dy*AW + dx
     }
 
-    // ---- prologue: the whole activation stage of step 0, weights of sub-step 0 in LDS; sub-step 1's weights and round 0 of
-    // step 1 in registers
-    {
-        // one HBM round trip for the whole first stage: all three rounds in flight, then committed
-        const uint4 p0a = ldu4(a.x + xoff[0]), p0b = ldu4(a.x + xoff[0] + 4);
-        const uint4 p1a = ldu4(a.x + xoff[1]), p1b = ldu4(a.x + xoff[1] + 4);
-        const uint4 p2a = ldu4(a.x + xoff[2]), p2b = ldu4(a.x + xoff[2] + 4);
-        issue_w(0);
-        rxa = p0a; rxb = p0b; commit_x(0, 0);
-        rxa = p1a; rxb = p1b; commit_x(0, 1);
-        rxa = p2a; rxb = p2b; commit_x(0, 2);
-    }
-    commit_w(0);
-    if (nsub > 1) issue_w(1);
-    if (nstep > 1) issue_x(1, 0);
+    // one sub-step's 36 MFMAs per wave: operands of tap dx+1 are read while the 12 MFMAs of tap dx run; smallest terms first
+    // (ah*bl, al*bh, ah*bh), product-major, so that consecutive MFMAs hit different accumulators
+    auto mma = [&](const uint4* xs, const uint4* ws) {
+        uint4 A[2][2][2], B[2][NREP][2];   // [buffer][tile][plane]
+        auto rd = [&](int buf, int dx) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) A[buf][m][pl] = ws[(pl * 3 + dx) * 128 + aslot + m * 32];
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) B[buf][n][pl] = xs[pl * 2 * APL + bslot[n] + dx];
+            }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int cur = dx & 1;
+            if (dx < 2) rd(cur ^ 1, dx + 1);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int pa = e == 1 ? 1 : 0, pb = e == 0 ? 1 : 0;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_bf16(A[cur][m][pa], B[cur][n][pb], acc[m][n]);
+            }
+        }
+    };
+
+    // ---- staging registers of this thread: the next step's operands (plain scalars: see the header)
+    uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8;       // weight units tid + 256 k of the step: [dy 3][plane 2][dx 3][cblk 2][row 64]
+    uint4 n0a, n0b, n1a, n1b, n2a, n2b;             // three activation chunks (32 bytes each; hi / lo after the split)
+    auto ldw = [&](int s) {
+        const uint4* ws = wsrc0 + (int64_t)(3 * s) * WUNITS;
+        w0 = ws[tid]; w1 = ws[256 + tid]; w2 = ws[512 + tid];
+        w3 = ws[768 + tid]; w4 = ws[1024 + tid]; w5 = ws[1280 + tid];
+        w6 = ws[1536 + tid]; w7 = ws[1792 + tid]; w8 = ws[2048 + tid];
+    };
+    auto putw = [&]() {
+        lds_w[tid] = w0; lds_w[256 + tid] = w1; lds_w[512 + tid] = w2;
+        lds_w[768 + tid] = w3; lds_w[1024 + tid] = w4; lds_w[1280 + tid] = w5;
+        lds_w[1536 + tid] = w6; lds_w[1792 + tid] = w7; lds_w[2048 + tid] = w8;
+    };
+    auto ld = [&](int s, int rd, uint4& ua, uint4& ub) {
+        const float* p = a.x + (int64_t)s * step_stride + xoff[rd];
+        ua = ldu4(p);
+        ub = ldu4(p + 4);
+    };
+    auto sp = [&](uint4& ua, uint4& ub) {
+        if constexpr (!IN_SPLIT) {
+            uint4 hi, lo;
+            split8(as_f4(ua), as_f4(ub), hi, lo);
+            ua = hi; ub = lo;
+        }
+    };
+    auto put = [&](int rd, const uint4& hi, const uint4& lo) {
+        if (own[rd]) {
+            lds[loff[rd]] = hi;
+            lds[2 * APL + loff[rd]] = lo;
+        }
+    };
+
+    // ---- prologue: both stages of step 0 (one HBM round trip)
+    ld(0, 0, n0a, n0b); ld(0, 1, n1a, n1b); ld(0, 2, n2a, n2b);
+    ldw(0);
+    sp(n0a, n0b); sp(n1a, n1b); sp(n2a, n2b);
+    put(0, n0a, n0b); put(1, n1a, n1b); put(2, n2a, n2b);
+    putw();
     __syncthreads();
 
     for (int s = 0; s < nstep; ++s) {
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {   // compile-time dy: the staging slot arrays are indexed by it
-            const int t = 3 * s + dy;
-            const uint4* xs = lds + (s & 1) * ASTAGE + dy * AW;
-            const uint4* ws = lds_w + (t & 1) * WUNITS;
-            uint4 A[2][2][2], B[2][NREP][2];   // [buffer][tile][plane]
-            auto rd = [&](int buf, int dx) {
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) A[buf][m][pl] = ws[(pl * 3 + dx) * 128 + aslot + m * 32];
-#pragma unroll
-                    for (int n = 0; n < NREP; ++n) B[buf][n][pl] = xs[pl * 2 * APL + bslot[n] + dx];
-                }
-            };
-            rd(0, 0);
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int cur = dx & 1;
-                if (dx < 2) rd(cur ^ 1, dx + 1);
-                // smallest terms first (ah*bl, al*bh, ah*bh), product-major: consecutive MFMAs hit different accumulators
-#pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    const int pa = e == 1 ? 1 : 0, pb = e == 0 ? 1 : 0;
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_bf16(A[cur][m][pa], B[cur][n][pb], acc[m][n]);
-                }
-            }
-            // staging after the MFMAs of this sub-step are issued: registers hold loads issued one sub-step ago
-            if (t + 1 < nsub) commit_w(t + 1);
-            if (t + 2 < nsub) issue_w(t + 2);
-            if (s + 1 < nstep) {
-                commit_x(s + 1, dy);
-                if (dy < 2) issue_x(s + 1, dy + 1);
-                else if (s + 2 < nstep) issue_x(s + 2, 0);
-            }
-            lds_barrier();   // slot t consumed; weights of t+1 and (after dy = 2) the activation stage of step s+1 complete
+        const bool more = s + 1 < nstep;
+        if (more) {    // every load of the next step up front: a whole step of MFMAs to land in
+            ldw(s + 1);
+            ld(s + 1, 0, n0a, n0b); ld(s + 1, 1, n1a, n1b); ld(s + 1, 2, n2a, n2b);
+        }
+        mma(lds, lds_w);
+        mma(lds + AW, lds_w + WUNITS);
+        if (more) { sp(n0a, n0b); sp(n1a, n1b); }
+        mma(lds + 2 * AW, lds_w + 2 * WUNITS);
+        if (more) {
+            sp(n2a, n2b);
+            lds_barrier();   // every read of both stages is done
+            put(0, n0a, n0b); put(1, n1a, n1b); put(2, n2a, n2b);
+            putw();
+            lds_barrier();
         }
     }
 
@@ -266,17 +273,17 @@ __global__ __launch_bounds__(256) void conv3x3_split2d_kernel(S2Args a) {
         const int rr = RR % a.g.hp;
         const bool in = rr >= 1 && rr <= a.g.h;     // frame rows between images stay zero
         const int64_t opix = a.g.sl + (int64_t)RR * a.g.wp + cc;
-        float4 rs[NRES >= 1 ? 8 : 1];
-        if (NRES >= 1) {      // all residual loads of this pixel first: 8 independent 16-byte loads in flight
 #pragma unroll
-            for (int mk = 0; mk < 4; ++mk) {
-                const float* rp = a.res1 + ((int64_t)(cb0 + 4 * (mk >> 1) + 2 * (mk & 1) + lhi) * a.g.cs + opix) * 8;
-                rs[2 * mk] = ld4(rp);
-                rs[2 * mk + 1] = ld4(rp + 4);
+        for (int m = 0; m < 2; ++m) {
+            float4 rs[NRES >= 1 ? 4 : 1];
+            if (NRES >= 1) {      // the four residual loads of this m-tile first: independent 16-byte loads in flight
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float* rp = a.res1 + ((int64_t)(cb0 + 4 * m + 2 * k + lhi) * a.g.cs + opix) * 8;
+                    rs[2 * k] = ld4(rp);
+                    rs[2 * k + 1] = ld4(rp + 4);
+                }
             }
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int64_t o = ((int64_t)(cb0 + 4 * m + 2 * k + lhi) * a.g.cs + opix) * 8;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void conv3x3_split2d_kernel(S2Args a) {
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (NRES >= 1) {
-                    const float4 ra = rs[2 * (2 * m + k)], rb = rs[2 * (2 * m + k) + 1];
+                    const float4 ra = rs[2 * k], rb = rs[2 * k + 1];
                     v[0] += ra.x; v[1] += ra.y; v[2] += ra.z; v[3] += ra.w;
                     v[4] += rb.x; v[5] += rb.y; v[6] += rb.z; v[7] += rb.w;
                 }
@@ -306,6 +313,7 @@ __global__ __launch_bounds__(256) void conv3x3_split2d_kernel(S2Args a) {
                     st4(a.y + o + 4, make_float4(v[4], v[5], v[6], v[7]));
                 }
             }
+        }
     }
 }
 

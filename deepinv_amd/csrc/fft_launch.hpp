@@ -160,12 +160,6 @@ constexpr int kMaxGrid = 256 * 8;  // grid-stride over tiles: enough workgroups 
 template <int N> struct RowsL { static constexpr int value = N >= 512 ? 8 : (N >= 128 ? 16 : 32); };
 template <int N> struct ColsL { static constexpr int value = N == 16 ? 256 : 16; };
 
-// tunable: lines per workgroup of the rows passes (smaller tiles -> more workgroups per CU in flight)
-inline int rows_L_override() {
-    static int v = [] { const char* e = getenv("DINV_ROWS_L"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
 template <class T, class = void> struct io_planar_store : std::false_type {};
 template <class T> struct io_planar_store<T, std::void_t<decltype(T::planar_store)>> : std::bool_constant<T::planar_store> {};
 
@@ -175,9 +169,8 @@ inline int launch_rows_static_L(Io io, int64_t nlines, const void* table, int in
     using P = std::conditional_t<io_planar_store<Io>::value, typename PlanForS<N>::P, typename PlanFor<N>::P>;
     const int64_t ntiles = ceil_div(nlines, L);
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
-    static const bool no_vec = getenv("DINV_NO_VEC4") != nullptr;  // experiment knob
     if constexpr (io_has_vec4<Io>::value && P::STAGES >= 2 && P::M1 % 4 == 0 && (P::N / (P::STAGES == 3 ? P::R3 : P::R2)) % 4 == 0) {
-        if (!no_vec && (centered == 0 || (P::N / 2) % 4 == 0)) {
+        if (centered == 0 || (P::N / 2) % 4 == 0) {
             if (inverse)
                 hipLaunchKernelGGL((fft_rows_static_v4_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, nlines,
                                    ntiles, table, centered, scale);
@@ -201,17 +194,7 @@ inline int launch_rows_static_L(Io io, int64_t nlines, const void* table, int in
 template <int N, class Io>
 inline int launch_rows_static(Io io, int64_t nlines, const void* table, int inverse, int centered, float scale,
                               hipStream_t s) {
-    int L = rows_L_override();
-    if (L == 0) L = RowsL<N>::value;
-    if (N >= 512 && L > 8) L = 8;
-    if (L <= 4) return launch_rows_static_L<N, Io, 4>(io, nlines, table, inverse, centered, scale, s);
-    if (L <= 8) return launch_rows_static_L<N, Io, 8>(io, nlines, table, inverse, centered, scale, s);
-    if constexpr (N < 512) {
-        if (L <= 16) return launch_rows_static_L<N, Io, 16>(io, nlines, table, inverse, centered, scale, s);
-        if constexpr (N < 128) return launch_rows_static_L<N, Io, 32>(io, nlines, table, inverse, centered, scale, s);
-        return launch_rows_static_L<N, Io, 16>(io, nlines, table, inverse, centered, scale, s);
-    }
-    return launch_rows_static_L<N, Io, 8>(io, nlines, table, inverse, centered, scale, s);
+    return launch_rows_static_L<N, Io, RowsL<N>::value>(io, nlines, table, inverse, centered, scale, s);
 }
 
 template <int N, class Io>
@@ -221,7 +204,7 @@ inline int launch_cols_static(Io io, int64_t P_, int64_t Q, const void* table, i
     constexpr int L = ColsL<N>::value;
     const int64_t qtiles = ceil_div(Q, L);
     const int64_t ntiles = P_ * qtiles;
-    if (group > 1 && (P_ % group != 0 || getenv("DINV_NO_XCD_MAP"))) group = 1;
+    if (group > 1 && P_ % group != 0) group = 1;
     const int64_t padded = group > 1 ? ceil_div(ntiles, (int64_t)8 * group) * 8 * group : ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(padded, kMaxGrid);
     if (inverse)

@@ -107,7 +107,8 @@ inline bool has_static_plan(int n) { return n == 16 || n == 32 || n == 64 || n =
 // ROW = false: tile of L columns of one outer index p, lanes run along the columns (LDS [pos][L]);
 //              each thread owns one column (ColCtx in registers).
 // Output is delivered through `emit(item_slot, line, k, value)` so that the coil-combine pass can accumulate.
-template <class P, bool INV, bool ROW, int L>
+// NT: threads of the workgroup (512 halves the per-thread register arrays of the long column transforms)
+template <class P, bool INV, bool ROW, int L, int NT = 256>
 struct TileFft {
     static constexpr int N = P::N;
     static __device__ __forceinline__ int addr(int line, int q1, int rest) {
@@ -115,10 +116,10 @@ struct TileFft {
     }
     static constexpr size_t lds_floats2 = ROW ? (size_t)L * P::LSR : (size_t)L * N;
 
-    static constexpr int NS1 = (L * P::K1 + 255) / 256;                                  // item slots per thread, stage 1
+    static constexpr int NS1 = (L * P::K1 + NT - 1) / NT;                                  // item slots per thread, stage 1
     static constexpr int RL = (P::STAGES == 3) ? P::R3 : (P::STAGES == 2 ? P::R2 : P::R1);  // radix of the last stage
     static constexpr int KL = N / RL;                                                      // last-stage items per line
-    static constexpr int NSL = (L * KL + 255) / 256;                                        // slots per thread, last stage
+    static constexpr int NSL = (L * KL + NT - 1) / NT;                                        // slots per thread, last stage
 
     // item -> (line, index-within-line); lanes run along the index (ROW) or along the lines (COL)
     static __device__ __forceinline__ void split(int w, int K, int& line, int& i) {
@@ -128,6 +129,30 @@ struct TileFft {
     // LDS_IN: the inputs themselves live in `buf` (natural order, whatever addressing `load` uses): every thread first
     // pulls ALL its stage-1 inputs into registers, then the workgroup synchronises, and only then are the stage-1
     // outputs written over the same LDS tile (two transforms back to back on one tile, see mri_cols_normal_kernel).
+    // stage-1 inputs of this thread pulled into registers by the caller (software pipelining across tiles: the loads of
+    // the NEXT tile are in flight while the current one is transformed); feed them back through run_regs()
+    template <class LoadF>
+    static __device__ __forceinline__ void load_inputs(float2 (&vin)[NS1][P::R1], int lines, int c, int tid, LoadF load) {
+#pragma unroll
+        for (int slot = 0; slot < NS1; ++slot) {
+            const int w = tid + NT * slot;
+            int line, u;
+            split(w, P::K1, line, u);
+            const bool ok = w < L * P::K1 && line < lines;
+#pragma unroll
+            for (int j = 0; j < P::R1; ++j) {
+                int n = u + P::M1 * j + c;
+                if (n >= N) n -= N;
+                vin[slot][j] = ok ? load(slot, j, line, n) : make_float2(0.f, 0.f);
+            }
+        }
+    }
+    template <class EmitF>
+    static __device__ __forceinline__ void run_regs(float2* buf, const float2* __restrict__ tw, int lines, int c, float scale,
+                                                    int tid, const float2 (&vin)[NS1][P::R1], EmitF emit) {
+        run<false>(buf, tw, lines, c, scale, tid, [&](int slot, int j, int, int) { return vin[slot][j]; }, emit);
+    }
+
     template <bool LDS_IN = false, class LoadF, class EmitF>
     static __device__ __forceinline__ void run(float2* buf, const float2* __restrict__ tw, int lines, int c,
                                                float scale, int tid, LoadF load, EmitF emit) {
@@ -136,7 +161,7 @@ struct TileFft {
         if constexpr (LDS_IN) {
 #pragma unroll
             for (int slot = 0; slot < NS1; ++slot) {
-                const int w = tid + 256 * slot;
+                const int w = tid + NT * slot;
                 int line, u;
                 split(w, P::K1, line, u);
                 if (w >= L * P::K1 || line >= lines) continue;
@@ -152,7 +177,7 @@ struct TileFft {
         // ---------------- stage 1 : global -> registers -> LDS  (or straight to the output when single-stage)
 #pragma unroll
         for (int slot = 0; slot < NS1; ++slot) {
-            const int w = tid + 256 * slot;
+            const int w = tid + NT * slot;
             int line, u;
             split(w, P::K1, line, u);
             if (w >= L * P::K1 || line >= lines) continue;
@@ -185,10 +210,10 @@ struct TileFft {
         __syncthreads();
         if constexpr (P::STAGES == 3) {
             // ---------------- stage 2 : LDS -> LDS, items (line, q1, u') with u' fastest
-            constexpr int NS2 = (L * P::K2 + 255) / 256;
+            constexpr int NS2 = (L * P::K2 + NT - 1) / NT;
 #pragma unroll
             for (int slot = 0; slot < NS2; ++slot) {
-                const int w = tid + 256 * slot;
+                const int w = tid + NT * slot;
                 int line, i;
                 split(w, P::K2, line, i);
                 if (w >= L * P::K2 || line >= lines) continue;
@@ -207,7 +232,7 @@ struct TileFft {
         constexpr int Q2N = (P::STAGES == 3) ? R2 : 1;  // number of q2 values
 #pragma unroll
         for (int slot = 0; slot < NSL; ++slot) {
-            const int w = tid + 256 * slot;
+            const int w = tid + NT * slot;
             int line, i;
             split(w, KL, line, i);
             if (w >= L * KL || line >= lines) continue;
@@ -235,10 +260,10 @@ struct TileFft {
         constexpr int R1 = P::R1, R2 = P::R2, M1 = P::M1, M2 = P::M2;
         static_assert(M1 % 4 == 0 && KL % 4 == 0 && N % 8 == 0 && P::STAGES >= 2, "vector width 4 needs 4 | M1, KL");
         constexpr int T1 = M1 / 4;                       // threads per line, stage 1
-        constexpr int NSV1 = (L * T1 + 255) / 256;
+        constexpr int NSV1 = (L * T1 + NT - 1) / NT;
 #pragma unroll
         for (int slot = 0; slot < NSV1; ++slot) {
-            const int w = tid + 256 * slot;
+            const int w = tid + NT * slot;
             const int line = w / T1, u0 = (w - line * T1) * 4;
             if (w >= L * T1 || line >= lines) continue;
             float2 x[R1][4];
@@ -261,10 +286,10 @@ struct TileFft {
         }
         __syncthreads();
         if constexpr (P::STAGES == 3) {
-            constexpr int NS2 = (L * P::K2 + 255) / 256;
+            constexpr int NS2 = (L * P::K2 + NT - 1) / NT;
 #pragma unroll
             for (int slot = 0; slot < NS2; ++slot) {
-                const int w = tid + 256 * slot;
+                const int w = tid + NT * slot;
                 int line, i;
                 split(w, P::K2, line, i);
                 if (w >= L * P::K2 || line >= lines) continue;
@@ -281,10 +306,10 @@ struct TileFft {
         }
         constexpr int Q2N = (P::STAGES == 3) ? R2 : 1;
         constexpr int TL = KL / 4;                       // threads per line, last stage
-        constexpr int NSVL = (L * TL + 255) / 256;
+        constexpr int NSVL = (L * TL + NT - 1) / NT;
 #pragma unroll
         for (int slot = 0; slot < NSVL; ++slot) {
-            const int w = tid + 256 * slot;
+            const int w = tid + NT * slot;
             const int line = w / TL, i0 = (w - line * TL) * 4;
             if (w >= L * TL || line >= lines) continue;
             float2 o[RL][4];

@@ -394,68 +394,90 @@ struct ColsCoilLoadIo {
     __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
 };
 
-// cols pass along the first volume axis with a coil loop: t[b,n] = F_axis(S[n] * x[b]); x stays in registers
-template <class P, int L>
-__global__ __launch_bounds__(256) void mri_cols_coil_fwd_kernel(const float* __restrict__ x,
-                                                                const float2* __restrict__ maps,
-                                                                float2* __restrict__ t, int ncoil, int maps_batch,
-                                                                int64_t Q, int64_t qtiles, int64_t ntiles,
-                                                                const void* table, float scale) {
-    using TF = TileFft<P, false, false, L>;
-    constexpr int N = P::N;
-    __shared__ __attribute__((aligned(16))) float2 buf[P::STAGES > 1 ? TF::lds_floats2 : 1];
+// ---- first pass of the forward operator, fused: t[b,n] = F_axis0( S[n] . x[b] ) on tiles of L columns.
+// The planar x tile and the interleaved coil-map tile are fetched with 16-byte-per-lane loads (all of a thread's loads in
+// flight before the first use), multiplied, and written to the LDS tile in natural order; the transform then runs in place
+// (TileFft::run<LDS_IN>) and its last stage stores t.  Replaces the streaming expansion kernel + an in-place column pass:
+// one write of t instead of a write, a read and a write (210 of the 630 MB that A moved per call at cfg2).
+// The coils of one (slice, column tile) run on one XCD at the same time (blocks b and b + 8; observed placement, speed
+// only), so x is read from HBM once and from that XCD's L2 seven times.
+template <class P, int L, int NT>
+__global__ __launch_bounds__(NT) void mri_cols_expand_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ maps,
+                                                                  float2* __restrict__ t, int ncoil, int maps_batch, int64_t Q,
+                                                                  int64_t qtiles, int64_t nsets, const void* table, float scale) {
+    using TF = TileFft<P, false, false, L, NT>;
+    constexpr int N = P::N, QL = L / 4, NI = (N * QL + NT - 1) / NT;
+    static_assert(L % 4 == 0 && P::STAGES > 1, "wide loads need 4 | L; single-stage lengths use the plain column pass");
+    __shared__ __attribute__((aligned(16))) float2 buf[(size_t)N * L];
     const float2* tw = reinterpret_cast<const float2*>(table);
     const int tid = threadIdx.x, line = tid % L;
     const int c = N / 2;
     const int64_t vol = (int64_t)N * Q;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t b = tile / qtiles;
-        const int64_t q0 = (tile - b * qtiles) * L;
+    const int64_t padded = ceil_div_dev(nsets, 8) * 8 * ncoil;
+    for (int64_t T = blockIdx.x; T < padded; T += gridDim.x) {
+        const int64_t chunk = T / (8 * ncoil), within = T - chunk * (8 * ncoil);
+        const int64_t set = chunk * 8 + within % 8;
+        const int n = (int)(within / 8);
+        if (set >= nsets) continue;
+        const int64_t b = set / qtiles, q0 = (set - b * qtiles) * L;
         const int cols = (int)min((int64_t)L, Q - q0);
-        const int64_t q = q0 + (line < cols ? line : 0);
-        const float* xre = x + (b * 2) * vol + q;
-        const float* xim = xre + vol;
-        // cache this thread's stage-1 inputs of x (same item decomposition as TileFft::run stage 1)
-        float2 xc[TF::NS1][P::R1];
+        const float* xre = x + (b * 2) * vol + q0;
+        const float2* sp = maps ? maps + ((maps_batch > 1 ? b : 0) * ncoil + n) * vol + q0 : nullptr;
+        float4 xr[NI], xi[NI], sa[NI], sb[NI];
 #pragma unroll
-        for (int slot = 0; slot < TF::NS1; ++slot) {
-            const int w = tid + 256 * slot;
-            const int u = w / L;
-#pragma unroll
-            for (int j = 0; j < P::R1; ++j) {
-                int n = u + P::M1 * j + c;
-                if (n >= N) n -= N;
-                const bool ok = w < L * P::K1 && line < cols;
-                xc[slot][j] = ok ? make_float2(xre[(int64_t)n * Q], xim[(int64_t)n * Q]) : make_float2(0.f, 0.f);
+        for (int i = 0; i < NI; ++i) {
+            const int item = tid + NT * i, row = item / QL, quad = item - row * QL;
+            const bool ok = item < N * QL && 4 * quad < cols;
+            const int64_t o = ok ? (int64_t)row * Q + 4 * quad : 0;
+            xr[i] = ld_f4(xre + o);
+            xi[i] = ld_f4(xre + vol + o);
+            if (sp) {
+                sa[i] = reinterpret_cast<const float4*>(sp + o)[0];
+                sb[i] = reinterpret_cast<const float4*>(sp + o)[1];
             }
         }
-        for (int coil = 0; coil < ncoil; ++coil) {
-            const float2* s = maps ? maps + (((maps_batch > 1 ? b : 0) * ncoil + coil) * vol + q) : nullptr;
-            float2* o = t + ((b * ncoil + coil) * vol + q);
-            if (P::STAGES > 1) __syncthreads();
-            TF::run(buf, tw, cols, c, scale, tid,
-                    [&](int slot, int j, int, int n) {
-                        return s ? cmul(s[(int64_t)n * Q], xc[slot][j]) : xc[slot][j];
-                    },
-                    [&](int, int, int k, int, float2 v) { o[(int64_t)k * Q] = v; });
+        __syncthreads();   // the previous tile's last stage has left the LDS tile
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int item = tid + NT * i, row = item / QL, quad = item - row * QL;
+            if (item >= N * QL) continue;
+            float2 v[4] = {make_float2(xr[i].x, xi[i].x), make_float2(xr[i].y, xi[i].y), make_float2(xr[i].z, xi[i].z),
+                           make_float2(xr[i].w, xi[i].w)};
+            if (sp) {
+                v[0] = cmul(make_float2(sa[i].x, sa[i].y), v[0]);
+                v[1] = cmul(make_float2(sa[i].z, sa[i].w), v[1]);
+                v[2] = cmul(make_float2(sb[i].x, sb[i].y), v[2]);
+                v[3] = cmul(make_float2(sb[i].z, sb[i].w), v[3]);
+            }
+            st_c4(buf + row * L + 4 * quad, v);
         }
+        __syncthreads();
+        float2* o = t + (b * ncoil + n) * vol + q0 + (line < cols ? line : 0);
+        TF::template run<true>(buf, tw, cols, c, scale, tid,
+                               [&](int, int, int, int nn) { return buf[nn * L + line]; },
+                               [&](int, int, int k, int, float2 v) { o[(int64_t)k * Q] = v; });
     }
 }
 
-// cols pass along the first volume axis + coil combine: x[b] = sum_n conj(S[n]) * F^H_axis(t[b,n])
-template <class P, int L>
-__global__ __launch_bounds__(256) void mri_cols_combine_inv_kernel(const float2* __restrict__ t,
-                                                                   const float2* __restrict__ maps,
-                                                                   float* __restrict__ x, int ncoil, int maps_batch,
-                                                                   int64_t Q, int64_t qtiles, int64_t ntiles,
-                                                                   const void* table, float scale) {
-    using TF = TileFft<P, true, false, L>;
+// ---- last pass of the adjoint, fused: x[b] = sum_n conj(S[n]) . F^H_axis0( t[b,n] ) on tiles of L columns.  One workgroup
+// owns a (slice, column tile) and walks the coils; the stage-1 inputs AND the coil-map values of the NEXT coil are loaded
+// into registers before the current coil is transformed, so the HBM stream never waits for a transform; the coil sum is
+// accumulated in registers by the thread that owns an output position (fixed order n = 0..N-1: deterministic).
+// Replaces an in-place column pass + the streaming combination kernel: one read of t instead of a read, a write and a read.
+template <class P, int L, int NT>
+__global__ __launch_bounds__(NT) void mri_cols_combine_inv_kernel(const float2* __restrict__ t,
+                                                                  const float2* __restrict__ maps,
+                                                                  float* __restrict__ x, int ncoil, int maps_batch,
+                                                                  int64_t Q, int64_t qtiles, int64_t ntiles,
+                                                                  const void* table, float scale) {
+    using TF = TileFft<P, true, false, L, NT>;
     constexpr int N = P::N;
     __shared__ __attribute__((aligned(16))) float2 buf[P::STAGES > 1 ? TF::lds_floats2 : 1];
     const float2* tw = reinterpret_cast<const float2*>(table);
     const int tid = threadIdx.x, line = tid % L;
     const int c = N / 2;
     const int64_t vol = (int64_t)N * Q;
+    constexpr int Q2N = (P::STAGES == 3) ? P::R2 : 1;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t b = tile / qtiles;
         const int64_t q0 = (tile - b * qtiles) * L;
@@ -466,31 +488,47 @@ __global__ __launch_bounds__(256) void mri_cols_combine_inv_kernel(const float2*
         for (int a = 0; a < TF::NSL; ++a)
 #pragma unroll
             for (int r = 0; r < TF::RL; ++r) acc[a][r] = make_float2(0.f, 0.f);
-        for (int coil = 0; coil < ncoil; ++coil) {
-            const float2* in = t + ((b * ncoil + coil) * vol + q);
-            const float2* s = maps ? maps + (((maps_batch > 1 ? b : 0) * ncoil + coil) * vol + q) : nullptr;
-            if (P::STAGES > 1) __syncthreads();
-            TF::run(buf, tw, cols, c, scale, tid,
-                    [&](int, int, int, int n) { return in[(int64_t)n * Q]; },
-                    [&](int slot, int, int k, int r, float2 v) {
-                        if (s) v = cmulc(v, s[(int64_t)k * Q]);  // conj(S) * v
-                        acc[slot][r] = cadd(acc[slot][r], v);
-                    });
+        // output position k of (slot, r): the last-stage item decomposition of TileFft::run
+        auto out_k = [&](int slot, int r) {
+            const int w = tid + NT * slot, i = w / L;
+            int k = (P::STAGES == 1 ? r : (i % P::R1) + P::R1 * (i / P::R1) + P::R1 * Q2N * r) + c;
+            return k >= N ? k - N : k;
+        };
+        // two register sets (A, B) alternate: the loads of coil n + 1 are in flight while coil n is transformed
+        float2 va[TF::NS1][P::R1], vb[TF::NS1][P::R1];
+#define DINV_FETCH(coil, V)                                                                                           \
+        do {                                                                                                          \
+            const float2* in_ = t + ((b * ncoil + (coil)) * vol + q);                                                 \
+            TF::load_inputs(V, cols, c, tid, [&](int, int, int, int n) { return in_[(int64_t)n * Q]; });              \
+        } while (0)
+#define DINV_XFORM(coil, V)                                                                                           \
+        do {                                                                                                          \
+            const float2* s_ = maps ? maps + (((maps_batch > 1 ? b : 0) * ncoil + (coil)) * vol + q) : nullptr;       \
+            if (P::STAGES > 1) __syncthreads(); /* the previous transform has left the LDS tile */                    \
+            TF::run_regs(buf, tw, cols, c, scale, tid, V, [&](int slot, int, int k, int r, float2 v) {                \
+                if (s_) v = cmulc(v, s_[(int64_t)k * Q]); /* conj(S) * v */                                           \
+                acc[slot][r] = cadd(acc[slot][r], v);                                                                 \
+            });                                                                                                       \
+        } while (0)
+        DINV_FETCH(0, va);
+        for (int coil = 0; coil < ncoil; coil += 2) {
+            if (coil + 1 < ncoil) DINV_FETCH(coil + 1, vb);
+            DINV_XFORM(coil, va);
+            if (coil + 1 < ncoil) {
+                if (coil + 2 < ncoil) DINV_FETCH(coil + 2, va);
+                DINV_XFORM(coil + 1, vb);
+            }
         }
-        // store with the last-stage item decomposition of TileFft::run
+#undef DINV_FETCH
+#undef DINV_XFORM
         float* xre = x + (b * 2) * vol + q;
         float* xim = xre + vol;
-        constexpr int Q2N = (P::STAGES == 3) ? P::R2 : 1;
 #pragma unroll
         for (int slot = 0; slot < TF::NSL; ++slot) {
-            const int w = tid + 256 * slot;
-            const int i = w / L;
-            if (w >= L * TF::KL || line >= cols) continue;
-            const int q1 = P::STAGES == 1 ? 0 : i % P::R1, q2 = P::STAGES == 1 ? 0 : i / P::R1;
+            if (tid + NT * slot >= L * TF::KL || line >= cols) continue;
 #pragma unroll
             for (int r = 0; r < TF::RL; ++r) {
-                int k = (P::STAGES == 1 ? r : q1 + P::R1 * q2 + P::R1 * Q2N * r) + c;
-                if (k >= N) k -= N;
+                const int k = out_k(slot, r);
                 xre[(int64_t)k * Q] = acc[slot][r].x;
                 xim[(int64_t)k * Q] = acc[slot][r].y;
             }
@@ -588,16 +626,22 @@ __global__ __launch_bounds__(256) void mri_coil_expand_kernel(const float* __res
 }
 
 template <int N>
-int launch_cols_coil_fwd(const float* x, const float2* maps, float2* t, int64_t B, int ncoil, int maps_batch, int64_t Q,
-                         const void* table, float scale, hipStream_t s) {
+int launch_cols_expand_fwd(const float* x, const float2* maps, float2* t, int64_t B, int ncoil, int maps_batch, int64_t Q,
+                           const void* table, float scale, hipStream_t s) {
     using P = typename PlanFor<N>::P;
-    constexpr int L = ColsL<N>::value;
-    const int64_t qtiles = ceil_div(Q, L), ntiles = B * qtiles;
-    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
-    hipLaunchKernelGGL((mri_cols_coil_fwd_kernel<P, L>), dim3(grid), dim3(256), 0, s, x, maps, t, ncoil, maps_batch, Q,
-                       qtiles, ntiles, table, scale);
-    DINV_CHECK_LAUNCH();
-    return 0;
+    if constexpr (P::STAGES > 1) {
+        constexpr int L = ColsL<N>::value;
+        const int64_t qtiles = ceil_div(Q, L), nsets = B * qtiles;
+        const int64_t padded = ceil_div(nsets, 8) * 8 * ncoil;
+        const unsigned grid = (unsigned)std::min<int64_t>(padded, 4 * kMaxGrid);
+        constexpr int NT = N >= 256 ? 512 : 256;
+        hipLaunchKernelGGL((mri_cols_expand_fwd_kernel<P, L, NT>), dim3(grid), dim3(NT), 0, s, x, maps, t, ncoil, maps_batch, Q,
+                           qtiles, nsets, table, scale);
+        DINV_CHECK_LAUNCH();
+        return 0;
+    } else {
+        return fail(2, "no fused expand pass for length %d", N);
+    }
 }
 
 template <int N>
@@ -606,75 +650,15 @@ int launch_cols_combine_inv(const float2* t, const float2* maps, float* x, int64
     using P = typename PlanFor<N>::P;
     constexpr int L = ColsL<N>::value;
     const int64_t qtiles = ceil_div(Q, L), ntiles = B * qtiles;
-    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
-    hipLaunchKernelGGL((mri_cols_combine_inv_kernel<P, L>), dim3(grid), dim3(256), 0, s, t, maps, x, ncoil, maps_batch, Q,
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 4 * kMaxGrid);
+    constexpr int NT = N >= 256 ? 512 : 256;
+    hipLaunchKernelGGL((mri_cols_combine_inv_kernel<P, L, NT>), dim3(grid), dim3(NT), 0, s, t, maps, x, ncoil, maps_batch, Q,
                        qtiles, ntiles, table, scale);
     DINV_CHECK_LAUNCH();
     return 0;
 }
 
-// ---- normal operator, middle pass: t <- F^H_axis( M^2 . F_axis t ) along the first volume axis, in place, ONE round trip
-// of t: forward transform of an N x L column tile (outputs kept in registers), masked write back into the same LDS
-// tile in natural order, inverse transform out of the tile (TileFft::run<LDS_IN>), store.  y = M F S x is never formed.
-// The mask multiplies each real channel twice, exactly as A followed by A_adjoint does (mri.py:271, :300).
-template <class P, int L>
-__global__ __launch_bounds__(256) void mri_cols_normal_kernel(float2* __restrict__ t, const float* __restrict__ mask,
-                                                              int ncoil, int mask_batch, int64_t Q, int64_t qtiles,
-                                                              int64_t ntiles, const void* table, float scale) {
-    using TF = TileFft<P, false, false, L>;
-    using TI = TileFft<P, true, false, L>;
-    constexpr int N = P::N;
-    __shared__ __attribute__((aligned(16))) float2 buf[(size_t)N * L];
-    const float2* tw = reinterpret_cast<const float2*>(table);
-    const int tid = threadIdx.x;
-    const int c = N / 2;
-    const int line = tid % L;
-    const int64_t vol = (int64_t)N * Q;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t p = tile / qtiles;
-        const int64_t q0 = (tile - p * qtiles) * L;
-        const int cols = (int)min((int64_t)L, Q - q0);
-        const int64_t q = q0 + (line < cols ? line : 0);
-        float2* tp = t + p * vol + q;
-        const float* mre = mask ? mask + ((mask_batch > 1 ? p / ncoil : 0) * 2) * vol + q : nullptr;
-        __syncthreads();   // previous tile's inverse transform has left the LDS tile
-        float2 out[TF::NSL][TF::RL];
-        TF::run(buf, tw, cols, c, scale, tid,
-                [&](int, int, int, int n) { return tp[(int64_t)n * Q]; },
-                [&](int slot, int, int k, int qq, float2 v) {
-                    if (mre) {
-                        const float m0 = mre[(int64_t)k * Q], m1 = mre[vol + (int64_t)k * Q];
-                        v.x = m0 * (m0 * v.x);
-                        v.y = m1 * (m1 * v.y);
-                    }
-                    out[slot][qq] = v;
-                });
-        __syncthreads();   // every last-stage read of the tile is done: overwrite it with k-space in natural order
-        {
-            constexpr int Q2N = (P::STAGES == 3) ? P::R2 : 1;
-#pragma unroll
-            for (int slot = 0; slot < TF::NSL; ++slot) {
-                const int w = tid + 256 * slot;
-                const int i = w / L;                 // cols mode: item -> (i, line) with the line fastest
-                if (w >= L * TF::KL || line >= cols) continue;
-#pragma unroll
-                for (int qq = 0; qq < TF::RL; ++qq) {
-                    int k;
-                    if constexpr (P::STAGES == 1) k = qq + c;
-                    else k = (i % P::R1) + P::R1 * (i / P::R1) + P::R1 * Q2N * qq + c;
-                    if (k >= N) k -= N;
-                    buf[k * L + line] = out[slot][qq];
-                }
-            }
-        }
-        __syncthreads();
-        TI::template run<true>(buf, tw, cols, c, scale, tid,
-                               [&](int, int, int, int n) { return buf[n * L + line]; },
-                               [&](int, int, int k, int, float2 v) { tp[(int64_t)k * Q] = v; });
-    }
-}
-
-// ---- the same middle pass along the LAST (contiguous) axis: t <- F^H_W( M^2 . F_W t ) on tiles of L rows; the forward
+// ---- normal operator, middle pass along the LAST (contiguous) axis: t <- F^H_W( M^2 . F_W t ) on tiles of L rows; the forward
 // transform emits masked k-space rows into a second LDS tile in natural order, the inverse transform reads them from
 // there.  This is the variant the normal operator uses.
 // Measured at cfg2 (B = 32, 8 coils, 320 x 320; us per pass): expand 52-60 + cols 78 + THIS ~145 + cols^-1 71 + combine 38
@@ -739,19 +723,6 @@ int launch_rows_normal(float2* t, const float* mask, int64_t nlines, int64_t R, 
     return 0;
 }
 
-template <int N>
-int launch_cols_normal(float2* t, const float* mask, int64_t P_, int ncoil, int mask_batch, int64_t Q, const void* table,
-                       float scale, hipStream_t s) {
-    using P = typename PlanFor<N>::P;
-    constexpr int L = ColsL<N>::value;
-    const int64_t qtiles = ceil_div(Q, L), ntiles = P_ * qtiles;
-    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
-    hipLaunchKernelGGL((mri_cols_normal_kernel<P, L>), dim3(grid), dim3(256), 0, s, t, mask, ncoil, mask_batch, Q, qtiles,
-                       ntiles, table, scale);
-    DINV_CHECK_LAUNCH();
-    return 0;
-}
-
 #define DINV_ALL_STATIC(X) X(16) X(32) X(64) X(128) X(256) X(320) X(512)
 
 bool all_static(const dinv_mri_desc* d) {
@@ -783,17 +754,8 @@ inline int64_t volume(const dinv_mri_desc* d) {
     return v;
 }
 
-// Sub-batching of the static pipeline (DINV_MRI_CHUNK = slices per chunk, 0 / unset = whole batch): the three passes of
-// a chunk run back to back over the SAME chunk of the coil scratch t, so that t is produced and consumed while it may
-// still sit in the 256 MB Infinity Cache.  MEASURED (r02, cfg2, B = 32: A / A^T in ms): whole batch 0.259 /
-// 0.279; chunks of 16: 0.267 / 0.283; of 8: 0.303 / 0.340; of 4: 0.412 / 0.441 - each pass already streams at
-// 4.1-4.8 TB/s, and smaller launches only add ramp-up/tail; 3-D cfg4 per volume: A 0.283 vs 0.303, A^T 0.392 vs 0.300.
-// Hence OFF by default; the knob stays for other shapes.
-int mri_chunk(const dinv_mri_desc* d) {
-    static const int forced = [] { const char* e = getenv("DINV_MRI_CHUNK"); return e ? atoi(e) : 0; }();
-    (void)d;
-    return forced > 0 ? forced : 0;
-}
+// TEMPORARY (round-3 A/B on hardware): 1 = the round-2 three-pass forms (streaming expand / combine + in-place column pass)
+int g_mri_variant = 0;
 
 }  // namespace
 
@@ -820,34 +782,18 @@ extern "C" int dinv_mri_forward(const dinv_mri_desc* d, const float* x, const fl
     const int64_t P = (int64_t)d->batch * d->coils;
 
     if (all_static(d)) {
-        const int chunk = mri_chunk(d);
-        if (chunk > 0 && d->batch > chunk) {   // cache-resident sub-batches, all through the first chunk of t
-            for (int b0 = 0; b0 < d->batch; b0 += chunk) {
-                dinv_mri_desc dd = *d;
-                dd.batch = std::min(chunk, d->batch - b0);
-                if (d->mask_batch > 1) dd.mask_batch = dd.batch;
-                if (d->maps_batch > 1) dd.maps_batch = dd.batch;
-                const float* mk = mask ? mask + (d->mask_batch > 1 ? (int64_t)b0 * 2 * vol : 0) : nullptr;
-                const float* mpc = maps ? maps + (d->maps_batch > 1 ? (int64_t)b0 * d->coils * vol * 2 : 0) : nullptr;
-                if (int e = dinv_mri_forward(&dd, x + (int64_t)b0 * 2 * vol, mpc, mk, y + (int64_t)b0 * 2 * d->coils * vol,
-                                             workspace, ws_bytes, stream))
-                    return e;
-            }
-            return 0;
-        }
         const float2* mp = reinterpret_cast<const float2*>(maps);
         const int64_t N0 = d->dims[0], Q0 = vol / N0;
         const float sc0 = 1.0f / sqrtf((float)N0);
         int e = 0;
-        static const bool coil_loop = getenv("DINV_MRI_COIL_LOOP") != nullptr;  // experiment knob
-        if (coil_loop) {
+        if (Q0 % 4 == 0 && N0 > 16 && g_mri_variant == 0) {
+            // fused first pass: coil expansion + transform along the first axis, t written once
             switch (d->dims[0]) {
-#define DINV_CASE(NN) case NN: e = launch_cols_coil_fwd<NN>(x, mp, t, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s); break;
-                DINV_ALL_STATIC(DINV_CASE)
+#define DINV_CASE(NN) case NN: e = launch_cols_expand_fwd<NN>(x, mp, t, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s); break;
+                DINV_CASE(32) DINV_STATIC_SIZES(DINV_CASE)
 #undef DINV_CASE
             }
-        } else if (vol % 4 == 0 && N0 > 16 && !getenv("DINV_MRI_FUSED_EXPAND")) {
-            // wide streaming coil expansion, then a C2C pass along the first axis in place
+        } else if (vol % 4 == 0 && N0 > 16) {
             const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
             hipLaunchKernelGGL((mri_coil_expand_kernel<8>), grid, dim3(256), 0, s, x, mp, t, vol, d->batch, d->coils,
                                d->maps_batch);
@@ -855,6 +801,7 @@ extern "C" int dinv_mri_forward(const dinv_mri_desc* d, const float* x, const fl
             C2CIo fio{t, t, 0, 0};
             e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s);
         } else {
+            // short first axis (a 3-D volume's depth): single-stage transform straight from x and the maps
             ColsCoilLoadIo cio{x, mp, t, d->coils, d->maps_batch, 0, 0};
             e = launch_cols(cio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s, d->coils);
         }
@@ -896,21 +843,6 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
     const int64_t P = (int64_t)d->batch * d->coils;
 
     if (all_static(d)) {
-        const int chunk = mri_chunk(d);
-        if (chunk > 0 && d->batch > chunk) {
-            for (int b0 = 0; b0 < d->batch; b0 += chunk) {
-                dinv_mri_desc dd = *d;
-                dd.batch = std::min(chunk, d->batch - b0);
-                if (d->mask_batch > 1) dd.mask_batch = dd.batch;
-                if (d->maps_batch > 1) dd.maps_batch = dd.batch;
-                const float* mk = mask ? mask + (d->mask_batch > 1 ? (int64_t)b0 * 2 * vol : 0) : nullptr;
-                const float* mpc = maps ? maps + (d->maps_batch > 1 ? (int64_t)b0 * d->coils * vol * 2 : 0) : nullptr;
-                if (int e = dinv_mri_adjoint(&dd, y + (int64_t)b0 * 2 * d->coils * vol, mpc, mk, x + (int64_t)b0 * 2 * vol,
-                                             workspace, ws_bytes, stream))
-                    return e;
-            }
-            return 0;
-        }
         RowsPlanarMaskLoadIo lio{y, mask, t, d->coils, d->mask_batch, R, W, 0, 0};
         if (int e = launch_rows(lio, P * R, d->plan[nd - 1], d->table[nd - 1], 1, 1, 1.0f / sqrtf((float)W), s)) return e;
         if (nd == 3) {
@@ -920,9 +852,7 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
         const float2* mp = reinterpret_cast<const float2*>(maps);
         const int64_t N0 = d->dims[0], Q0 = vol / N0;
         const float sc0 = 1.0f / sqrtf((float)N0);
-        static const bool fused_combine = getenv("DINV_MRI_FUSED_COMBINE") != nullptr;  // experiment knob
-        if (!fused_combine && vol % 4 == 0 && N0 > 16) {
-            // C2C pass along the first axis in place, then a wide streaming coil combination
+        if ((g_mri_variant == 1 || N0 > 320) && vol % 4 == 0 && N0 > 16) {   // 512: the fused kernel spills (444 B / lane)
             C2CIo fio{t, t, 0, 0};
             if (int e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 1, 1, sc0, s)) return e;
             const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
@@ -931,6 +861,7 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
             DINV_CHECK_LAUNCH();
             return 0;
         }
+        // fused last pass: inverse transform along the first axis + conj(S) + coil sum, t read once
         switch (d->dims[0]) {
 #define DINV_CASE(NN) case NN: return launch_cols_combine_inv<NN>(t, mp, x, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s);
             DINV_ALL_STATIC(DINV_CASE)
@@ -977,13 +908,28 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
 //   rows(W) [x, S -> t] ; (cols(H) in place) ; cols(first axis): F, M^2, F^H in one LDS tile ; (cols(H)^-1) ;
 //   rows(W)^-1 + coil combine [t, S -> out]
 // 2-D: 4 passes over t instead of the 10 of dinv_mri_forward + dinv_mri_adjoint (which also write and re-read y).
-extern "C" int dinv_mri_normal_supported(const dinv_mri_desc* d) { return d && validate(d) == 0 && all_static(d) ? 1 : 0; }
+static bool normal_ok(const dinv_mri_desc* d) {
+    if (!all_static(d)) return false;
+    const int64_t vol = volume(d), N0 = d->dims[0], W = d->dims[d->ndim - 1];
+    bool wok = false;
+    switch ((int)W) {
+#define DINV_CASE(NN) case NN: wok = true; break;
+        DINV_STATIC_SIZES(DINV_CASE)
+#undef DINV_CASE
+        default: break;
+    }
+    return wok && N0 > 16 && (vol / N0) % 4 == 0;
+}
+
+extern "C" int dinv_mri_debug_variant(int v) { g_mri_variant = v; return 0; }
+
+extern "C" int dinv_mri_normal_supported(const dinv_mri_desc* d) { return d && validate(d) == 0 && normal_ok(d) ? 1 : 0; }
 
 extern "C" int dinv_mri_normal(const dinv_mri_desc* d, const float* x, const float* maps, const float* mask, float* out,
                                void* workspace, size_t ws_bytes, dinv_stream_t stream) {
     if (int e = validate(d)) return e;
     if (d->batch == 0) return 0;
-    DINV_REQUIRE(all_static(d), "dinv_mri_normal needs statically planned sizes (see dinv_mri_normal_supported)");
+    DINV_REQUIRE(normal_ok(d), "dinv_mri_normal: unsupported sizes (see dinv_mri_normal_supported)");
     DINV_REQUIRE(x && out && workspace, "null tensor pointer");
     DINV_REQUIRE(ws_bytes >= dinv_mri_workspace_bytes(d), "workspace too small: %zu < %zu", ws_bytes,
                  dinv_mri_workspace_bytes(d));
@@ -998,57 +944,45 @@ extern "C" int dinv_mri_normal(const dinv_mri_desc* d, const float* x, const flo
     const int64_t P = (int64_t)d->batch * d->coils;
     const float2* mp = reinterpret_cast<const float2*>(maps);
     const float scw = 1.0f / sqrtf((float)W);
-
     const int64_t N0v = d->dims[0], Q0 = vol / N0v;
-    static const bool cols_order = [] { const char* e = getenv("DINV_MRI_NORMAL_ORDER"); return e && e[0] == 'c'; }();
-    if (!cols_order && vol % 4 == 0 && N0v > 16) {
-        // expand -> cols(first axis) -> (cols(H)) -> rows(W): F, M^2, F^H in one tile -> (cols(H)^-1) -> cols^-1 -> combine
-        const float sc0 = 1.0f / sqrtf((float)N0v);
-        const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
+    const float sc0 = 1.0f / sqrtf((float)N0v);
+    // fused expand + cols(first axis) -> (cols(H)) -> rows(W): F, M^2, F^H in one tile -> (cols(H)^-1) -> fused cols^-1 + combine
+    int e = 0;
+    C2CIo fio{t, t, 0, 0};
+    const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
+    if (g_mri_variant == 1) {
         hipLaunchKernelGGL((mri_coil_expand_kernel<8>), grid, dim3(256), 0, s, x, mp, t, vol, d->batch, d->coils, d->maps_batch);
         DINV_CHECK_LAUNCH();
-        C2CIo fio{t, t, 0, 0};
-        if (int e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s)) return e;
-        if (nd == 3)
-            if (int e = launch_cols(fio, P * d->dims[0], W, d->plan[1], d->table[1], 0, 1, 1.0f / sqrtf((float)d->dims[1]), s)) return e;
-        int e = 0;
-        switch ((int)W) {
-#define DINV_CASE(NN) case NN: e = launch_rows_normal<NN>(t, mask, P * R, R, d->coils, d->mask_batch, d->table[nd - 1], scw, s); break;
-            DINV_STATIC_SIZES(DINV_CASE)
+        if ((e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s))) return e;
+    } else {
+        switch (d->dims[0]) {
+#define DINV_CASE(NN) case NN: e = launch_cols_expand_fwd<NN>(x, mp, t, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s); break;
+            DINV_CASE(32) DINV_STATIC_SIZES(DINV_CASE)
 #undef DINV_CASE
         }
         if (e) return e;
-        if (nd == 3)
-            if ((e = launch_cols(fio, P * d->dims[0], W, d->plan[1], d->table[1], 1, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
+    }
+    if (nd == 3)
+        if ((e = launch_cols(fio, P * d->dims[0], W, d->plan[1], d->table[1], 0, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
+    switch ((int)W) {
+#define DINV_CASE(NN) case NN: e = launch_rows_normal<NN>(t, mask, P * R, R, d->coils, d->mask_batch, d->table[nd - 1], scw, s); break;
+        DINV_STATIC_SIZES(DINV_CASE)
+#undef DINV_CASE
+        default: return fail(2, "dinv_mri_normal: no static rows plan for %d", (int)W);
+    }
+    if (e) return e;
+    if (nd == 3)
+        if ((e = launch_cols(fio, P * d->dims[0], W, d->plan[1], d->table[1], 1, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
+    if (g_mri_variant == 1 || N0v > 320) {
         if ((e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 1, 1, sc0, s))) return e;
         hipLaunchKernelGGL((mri_coil_combine_kernel<8>), grid, dim3(256), 0, s, t, mp, out, vol, d->batch, d->coils, d->maps_batch);
         DINV_CHECK_LAUNCH();
         return 0;
     }
-    // column order (DINV_MRI_NORMAL_ORDER=cols, and volumes the streaming expand / combine kernels do not take)
-    RowsCoilLoadIo rio{x, mp, t, d->coils, d->maps_batch, R, W, 0, 0};
-    if (int e = launch_rows(rio, P * R, d->plan[nd - 1], d->table[nd - 1], 0, 1, scw, s)) return e;
-    if (nd == 3) {
-        C2CIo mio{t, t, 0, 0};
-        if (int e = launch_cols(mio, P * d->dims[0], W, d->plan[1], d->table[1], 0, 1, 1.0f / sqrtf((float)d->dims[1]), s)) return e;
-    }
-    const int64_t N0 = d->dims[0];
-    int e = 0;
     switch (d->dims[0]) {
-#define DINV_CASE(NN) case NN: e = launch_cols_normal<NN>(t, mask, P, d->coils, d->mask_batch, vol / N0, d->table[0], 1.0f / sqrtf((float)N0), s); break;
+#define DINV_CASE(NN) case NN: return launch_cols_combine_inv<NN>(t, mp, out, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s);
         DINV_ALL_STATIC(DINV_CASE)
 #undef DINV_CASE
     }
-    if (e) return e;
-    if (nd == 3) {
-        C2CIo mio{t, t, 0, 0};
-        if ((e = launch_cols(mio, P * d->dims[0], W, d->plan[1], d->table[1], 1, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
-    }
-    switch ((int)W) {
-#define DINV_CASE(NN) case NN: return launch_combine_static<NN>(t, mp, out, (int64_t)d->batch * R, R, d->coils, d->maps_batch, d->table[nd - 1], scw, s);
-        DINV_STATIC_SIZES(DINV_CASE)
-#undef DINV_CASE
-        default: break;
-    }
-    return fail(2, "unreachable: no static rows plan for %d", (int)W);
+    return fail(2, "unreachable");
 }

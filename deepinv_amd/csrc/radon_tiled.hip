@@ -40,7 +40,8 @@ namespace {
 
 constexpr int KWMAX = 8;     // most angles per workgroup (one per wave; the plan picks 8, 4, 2 or 1)
 constexpr int BH = 16;       // band height
-constexpr int WWPREF = 136;  // window width (columns) up to which two workgroups of 8 images share a CU's LDS
+constexpr int WWPREF = 128;  // window width (columns) up to which two workgroups of 8 images share a CU's LDS;
+                             // a multiple of 16: see the pitch note in dinv_radon_plan_init
 constexpr int JW = 32;       // sinogram segment length staged per angle in the adjoint
 constexpr int KA = 16;       // angles per staging round in the adjoint
 constexpr int JPAD = 32;     // zero entries before/after each packed sinogram row
@@ -544,8 +545,6 @@ int make_geom(const dinv_radon_desc* d, TiledGeom* g, int* NBsel) {
     g->n_img = d->n_img; g->W = d->width; g->G = d->grid; g->pad = d->pad_before; g->A = d->n_angles;
     g->circle = d->circle; g->scale = d->scale;
     int NB = d->n_img >= 8 ? 8 : d->n_img >= 4 ? 4 : d->n_img >= 2 ? 2 : 1;
-    static const int nb_cap = [] { const char* e = getenv("DINV_RADON_NB"); return e ? atoi(e) : 0; }();   // tuning knob
-    if (nb_cap == 1 || nb_cap == 2 || nb_cap == 4) NB = std::min(NB, nb_cap);
     *NBsel = NB;
     g->groups = d->n_img == 0 ? 0 : (d->n_img + NB - 1) / NB;
     g->njb = (d->grid + 63) / 64;
@@ -683,7 +682,14 @@ int build_plan(const TiledGeom& g, const float* cs_host, int kw, int32_t* blob, 
 
 // Host-side plan.  cs_host: [A][2] fp32 (cos, sin) exactly as the device table holds them.  The number of angles per
 // workgroup is the largest of 8, 4, 2, 1 whose widest window stays within WWPREF columns (angle lists with coarse or
-// irregular spacing get fewer angles per workgroup; one angle always fits).  DINV_RADON_KW overrides (tuning).
+// irregular spacing get fewer angles per workgroup; one angle always fits).  A caller may force the count by passing
+// plan->kw = 1, 2, 4 or 8 on entry (0: automatic; the emulated CPU tests sweep it).
+// Window pitch: a window cell (4 images = 16 bytes) of (row, col) sits in LDS bank slot (row * pitch + col) mod 16.  The 16
+// lanes one ds_read_b128 cycle serves are 16 adjacent rays, i.e. cells (col0 + ~k cos, row0 - ~k sin): with pitch = 0 mod
+// 16 the slot is col mod 16 and only two rays that share a column in different rows collide (shallow angles: none; 45
+// degrees: two-way), every other residue also collides across rows (pitch = 8 mod 16: (col + 8, row + 1) with (col, row),
+// two-way at nearly every angle).  Simulated LDS cycles per tap read averaged over the angles of a class: 1.46 at 0 mod 16,
+// 1.91 at 8 (the round-2 pitch 136), 2.36 at 12 (the pitch 124 that config 3 got): so the pitch is rounded up to 16.
 extern "C" int dinv_radon_plan_init(const dinv_radon_desc* d, const float* cs_host, dinv_radon_plan* plan,
                                     void* host_blob) {
     TiledGeom g;
@@ -691,9 +697,8 @@ extern "C" int dinv_radon_plan_init(const dinv_radon_desc* d, const float* cs_ho
     if (int e = make_geom(d, &g, &NB)) return e;
     DINV_REQUIRE(cs_host && plan && host_blob, "null pointer");
     int32_t* blob = reinterpret_cast<int32_t*>(host_blob);
+    const int forced = plan->kw;
     std::memset(plan, 0, sizeof(*plan));
-    const char* env = getenv("DINV_RADON_KW");
-    const int forced = env ? atoi(env) : 0;
     int kw = KWMAX, worst = 0, nplain = 0, nch = 0;
     for (;; kw >>= 1) {
         if (forced == 1 || forced == 2 || forced == 4 || forced == 8) kw = forced;
@@ -701,7 +706,7 @@ extern "C" int dinv_radon_plan_init(const dinv_radon_desc* d, const float* cs_ho
         if (worst <= WWPREF || kw == 1 || forced) break;
     }
     plan->grid = g.G; plan->n_angles = g.A; plan->kw = kw; plan->band_h = BH;
-    plan->win_w = std::max(8, (worst + 3) & ~3);
+    plan->win_w = std::max(16, (worst + 15) & ~15);
     plan->n_jblocks = g.njb; plan->n_bands = g.nbands; plan->n_chunks_plain = nplain; plan->n_chunks_swap = nch - nplain;
     plan->fits = 1;
     plan->blob_words = (int32_t)plan_layout(g.A, g.njb, g.nbands, kw).words;

@@ -104,9 +104,11 @@ class DistributedStackedLinearPhysics(LinearPhysics):
       sum, then one all-reduce; ``reduce_op=None`` returns the local contribution;
     * ``A_adjoint_A(x)``: sum_i A_i^T A_i x with one all-reduce (what the PGD / CG loops call)."""
 
-    def __init__(self, ctx: BatchParallelContext, num_operators: int, factory, *, factory_kwargs=None, **kwargs):
+    def __init__(self, ctx: BatchParallelContext, num_operators: int, factory, *, factory_kwargs=None, img_shape=None,
+                 **kwargs):
         super().__init__(**kwargs)
         self.ctx, self.num_operators = ctx, int(num_operators)
+        self.img_shape = tuple(img_shape) if img_shape is not None else None
         self.local_indexes = [i for i in range(self.num_operators) if i % ctx.world_size == ctx.rank]
         self.local_physics = torch.nn.ModuleList([factory(i, ctx.device, factory_kwargs) for i in self.local_indexes])
         for p in self.local_physics:
@@ -151,6 +153,17 @@ class DistributedStackedLinearPhysics(LinearPhysics):
                     out[i] = bufs[r]
         return out
 
+    def _empty_contribution(self, like=None):
+        """a rank that owns no operator still has to join the all-reduce (the other ranks are already in it): its share is
+        a zero image.  The image shape is `like`'s when the caller has an image at hand (A_adjoint_A), else the shape given
+        at construction (`img_shape=`)."""
+        if like is not None:
+            return torch.zeros_like(like)
+        if self.img_shape is None:
+            raise RuntimeError("this rank owns no operator and the image shape is unknown: construct the distributed "
+                               "physics with img_shape=(B, C, ...) when num_operators < world_size")
+        return torch.zeros(self.img_shape, device=self.ctx.device, dtype=torch.float32)
+
     def A_adjoint(self, y, reduce_op: str | None = "sum", **kwargs):
         ys = self._local(y)
         acc = None
@@ -158,7 +171,7 @@ class DistributedStackedLinearPhysics(LinearPhysics):
             t = p.A_adjoint(yi, **kwargs)
             acc = t if acc is None else acc + t
         if acc is None:
-            raise RuntimeError("this rank owns no operator: cannot shape its (zero) contribution")
+            acc = self._empty_contribution()
         return self._reduce(acc, reduce_op)
 
     def A_adjoint_A(self, x, reduce_op: str | None = "sum", **kwargs):
@@ -166,6 +179,8 @@ class DistributedStackedLinearPhysics(LinearPhysics):
         for p in self.local_physics:
             t = p.A_adjoint_A(x, **kwargs)
             acc = t if acc is None else acc + t
+        if acc is None:
+            acc = self._empty_contribution(like=x)
         return self._reduce(acc, reduce_op)
 
     def A_vjp(self, x, v, reduce_op: str | None = "sum", **kwargs):
@@ -178,6 +193,8 @@ def coil_parallel_mri(ctx: BatchParallelContext, mask, coil_maps, img_size, thre
     from .physics.mri import MultiCoilMRI
 
     n = coil_maps.shape[1]
+    if n < ctx.world_size:
+        raise ValueError(f"coil-parallel MultiCoilMRI needs at least one coil per rank: {n} coils for {ctx.world_size} ranks")
     q, r = divmod(n, ctx.world_size)
     bounds = [0]
     for k in range(ctx.world_size):
@@ -296,9 +313,126 @@ class DistributedProcessing:
             for i0 in range(0, len(mine), step):
                 group = mine[i0:i0 + step]
                 batch = torch.cat([T.window(xp, k) for k in group], dim=0)       # windows ride the batch axis
-                res = self.processor(batch, *args, **kwargs)
+                rep = lambda a: (a.repeat(len(group), *([1] * (a.ndim - 1)))        # noqa: E731  per-sample arguments
+                                 if isinstance(a, torch.Tensor) and a.ndim >= 1 and a.shape[0] == B and B > 1 else a)
+                if B == 1 and any(isinstance(a, torch.Tensor) and a.ndim >= 1 and a.shape[0] == 1 and a.numel() > 1
+                                  for a in (*args, *kwargs.values())):
+                    pass   # [1, ...] maps broadcast over the windows exactly as they did over the single sample
+                res = self.processor(batch, *[rep(a) for a in args], **{k: rep(v) for k, v in kwargs.items()})
                 for j, k in enumerate(group):
                     T.place(out, k, res[j * B:(j + 1) * B])
         if gather and self.ctx.world_size > 1:
             dist.all_reduce(out, op=dist.ReduceOp.SUM)
         return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Data fidelity over distributed stacked physics and the `distribute()` factory
+# (reference deepinv/distributed/distrib_framework.py:940-1180, distributed/distribute.py:30-420)
+# ----------------------------------------------------------------------------------------------------------------------
+class DistributedDataFidelity:
+    """f(x) = sum_i d(A_i x, y_i) and its gradient sum_i A_i^T grad d(A_i x, y_i) over a `DistributedStackedLinearPhysics`:
+    every rank evaluates its own operators (no communication), then ONE all-reduce (`reduction` 'sum' or 'mean' over the
+    operators).  `data_fidelity`: one DataFidelity shared by all operators, or a factory
+    ``factory(index, device, factory_kwargs) -> DataFidelity`` (then `num_operators` is required)."""
+
+    def __init__(self, ctx: BatchParallelContext, data_fidelity, num_operators: int | None = None, *, factory_kwargs=None,
+                 reduction: str = "sum"):
+        import copy
+
+        from .optim.data_fidelity import DataFidelity
+
+        if reduction not in ("sum", "mean"):
+            raise ValueError("reduction must be 'sum' or 'mean'")
+        self.ctx, self.reduction_mode = ctx, reduction
+        self.local_data_fidelities, self.single_fidelity = [], None
+        if isinstance(data_fidelity, DataFidelity):
+            self.single_fidelity = copy.deepcopy(data_fidelity)
+            self.single_fidelity.to(ctx.device)
+        elif callable(data_fidelity):
+            if num_operators is None:
+                raise ValueError("num_operators must be provided when using a factory.")
+            for i in range(int(num_operators)):
+                if i % ctx.world_size == ctx.rank:
+                    self.local_data_fidelities.append(data_fidelity(i, ctx.device, factory_kwargs))
+        else:
+            raise ValueError("data_fidelity must be a DataFidelity instance or a factory callable.")
+
+    def _get_fidelity(self, i: int):
+        return self.single_fidelity if self.single_fidelity is not None else self.local_data_fidelities[i]
+
+    def _apply_op(self, local_op, x, y, physics, gather=True, **kwargs):
+        if not isinstance(physics, DistributedStackedLinearPhysics):
+            raise ValueError("physics must be a DistributedStackedLinearPhysics instance to be used with DistributedDataFidelity.")
+        y_local = physics._local(y)
+        Ax_local = physics.A(x, gather=False, **kwargs)
+        acc = None
+        for idx, (Ax_i, y_i) in enumerate(zip(Ax_local, y_local)):
+            t = local_op(idx, Ax_i, y_i)
+            acc = t if acc is None else acc + t
+        if acc is None:        # a rank without operators: a zero of the right shape joins the reduction
+            acc = self._zero
+        if self.reduction_mode == "mean":
+            acc = acc / physics.num_operators
+        if gather and self.ctx.world_size > 1:
+            acc = acc.contiguous()
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        return acc
+
+    def fn(self, x, y, physics, gather: bool = True, *args, **kwargs):
+        """sum_i d(A_i x, y_i), one value per batch element"""
+        self._zero = torch.zeros(x.shape[0], device=x.device, dtype=x.dtype)
+        return self._apply_op(lambda idx, Ax_i, y_i: self._get_fidelity(idx).d.fn(Ax_i, y_i, *args), x, y, physics, gather, **kwargs)
+
+    def grad(self, x, y, physics, gather: bool = True, *args, **kwargs):
+        """sum_i A_i^T grad d(A_i x, y_i)"""
+        self._zero = torch.zeros_like(x)
+        return self._apply_op(lambda idx, Ax_i, y_i: physics.local_physics[idx].A_vjp(x, self._get_fidelity(idx).d.grad(Ax_i, y_i, *args)),
+                              x, y, physics, gather, **kwargs)
+
+    def __call__(self, x, y, physics, *args, **kwargs):
+        return self.fn(x, y, physics, *args, **kwargs)
+
+
+def distribute(obj, ctx: BatchParallelContext, *, num_operators: int | None = None, type_object: str | None = "auto",
+               tiling_strategy: str | None = "overlap_tiling", tiling_dims=None, patch_size=256, overlap=64,
+               max_batch_size: int | None = None, **kwargs):
+    """`deepinv.distributed.distribute` (distribute.py:214-420) for the objects on this library's path:
+      * a list of `LinearPhysics` / a factory ``f(index, device, kwargs)`` (+ `num_operators`)  -> `DistributedStackedLinearPhysics`
+      * a `DataFidelity` / a list of them / a factory (+ `num_operators`, `type_object="data_fidelity"`)  -> `DistributedDataFidelity`
+      * a `Denoiser` (any module called as ``model(x, sigma)``)  -> `DistributedProcessing` (overlap tiling)
+    A callable needs an explicit `type_object` ('linear_physics', 'data_fidelity' or 'denoiser'), exactly as in the reference."""
+    from .models.base import Denoiser
+    from .optim.data_fidelity import DataFidelity
+
+    is_list = isinstance(obj, (list, tuple)) and len(obj) > 0
+    if type_object == "auto":
+        if is_list and isinstance(obj[0], LinearPhysics):
+            type_object = "linear_physics"
+        elif isinstance(obj, DataFidelity) or (is_list and isinstance(obj[0], DataFidelity)):
+            type_object = "data_fidelity"
+        elif isinstance(obj, Denoiser):
+            type_object = "denoiser"
+        elif callable(obj):
+            raise ValueError("For callable objects, you must specify type_object parameter")
+        else:
+            raise ValueError(f"Cannot auto-detect type for object: {type(obj)}")
+    if type_object in ("physics", "linear_physics"):
+        if is_list:
+            ops = list(obj)
+            return DistributedStackedLinearPhysics(ctx, len(ops), lambda i, device, _: ops[i].to(device), **kwargs)
+        if not callable(obj) or num_operators is None:
+            raise ValueError("a physics factory needs num_operators")
+        return DistributedStackedLinearPhysics(ctx, num_operators, obj, **kwargs)
+    if type_object == "data_fidelity":
+        if is_list:
+            dfs = list(obj)
+            return DistributedDataFidelity(ctx, lambda i, device, _: dfs[i].to(device), num_operators=len(dfs), **kwargs)
+        return DistributedDataFidelity(ctx, obj, num_operators=num_operators, **kwargs)
+    if type_object == "denoiser":
+        if tiling_strategy not in (None, "overlap_tiling"):
+            raise ValueError("only the 'overlap_tiling' strategy is implemented")
+        return DistributedProcessing(ctx, obj, strategy=tiling_strategy,
+                                     strategy_kwargs={"patch_size": patch_size, "overlap": overlap, "tiling_dims": tiling_dims},
+                                     max_batch_size=max_batch_size)
+    raise ValueError(f"Unsupported type_object: {type_object}")

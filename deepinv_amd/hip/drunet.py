@@ -30,14 +30,11 @@ def _l():
         l.dinv_act_unpack.argtypes = [G, vp, i32, vp, vp]
         l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
         l.dinv_conv3x3_tail.argtypes = [G, vp, vp, vp, i32, i32, vp, vp]
-        l.dinv_conv3x3_bf16x3.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
-        l.dinv_conv3x3_bf16s.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_down2x2_bf16s.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2_bf16s.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
-        l.dinv_conv3x3_wbf16.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
         l.dinv_conv_wgrad_workspace_bytes.argtypes = [G, i32, i32, i32]
         l.dinv_conv_wgrad.argtypes = [G, G, vp, i32, vp, i32, i32, vp, i32, vp, ctypes.c_size_t, vp]
@@ -83,23 +80,8 @@ def pack_tail_weight(w: torch.Tensor) -> torch.Tensor:
     return w.detach().float().reshape(cout, cin // 8, 8, 9).permute(1, 3, 0, 2).contiguous()
 
 
-def pack_bf16x3_weight(w: torch.Tensor) -> torch.Tensor:
-    """OIHW [Cout,Cin,3,3] -> exact 3-way bf16 split, packed [Cout/64][Cin/8][plane 3][tap 9][co 64][8] (bf16)"""
-    cout, cin = w.shape[:2]
-    if cin % 8 or cout % 64:
-        raise ValueError(f"bf16x3 packing needs cin % 8 == 0 and cout % 64 == 0, got {cin},{cout}")
-    w = w.detach().float()
-    p1 = w.bfloat16()
-    r = w - p1.float()
-    p2 = r.bfloat16()
-    p3 = (r - p2.float()).bfloat16()
-    planes = torch.stack((p1, p2, p3))                                   # [3, Cout, Cin, 3, 3]
-    planes = planes.reshape(3, cout // 64, 64, cin // 8, 8, 9)           # pl, ct, co, cb, ci, tap
-    return planes.permute(1, 3, 0, 5, 2, 4).contiguous()                # ct, cb, pl, tap, co, ci
-
-
-def pack_bf16s_weight(w: torch.Tensor) -> torch.Tensor:
-    """OIHW [Cout,Cin,3,3] -> two-part bf16 split (hi = bf16(w), lo = bf16(w - hi)), packed for csrc/drunet_bf16s.hip:
+def _pack_split_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> two-part bf16 split (hi = bf16(w), lo = bf16(w - hi)),
     [Cout/64][Cin/16][dy 3][plane 2][dx 3][cblk 2][co 64][ci 8] (bf16)"""
     cout, cin = w.shape[:2]
     if cin % 16 or cout % 64:
@@ -125,7 +107,7 @@ def pack_split2d_weight(w: torch.Tensor) -> torch.Tensor:
     """OIHW [Cout,Cin,3,3] -> two-part bf16 split (hi = bf16(w), lo = bf16(w - hi)), packed for csrc/drunet_split2d.hip:
     [Cout/64][Cin/16][dy 3][plane 2][dx 3][cblk 2][row 64][ci 8] (bf16), rows of each 32-row tile permuted by
     `split2d_row_perm`"""
-    packed = pack_bf16s_weight(w)                      # ct, s, dy, pl, dx, cblk, co 64, ci 8
+    packed = _pack_split_weight(w)                     # ct, s, dy, pl, dx, cblk, co 64, ci 8
     perm = split2d_row_perm().to(packed.device)
     idx = torch.cat((perm, 32 + perm))
     return packed.index_select(6, idx).contiguous()
@@ -141,20 +123,6 @@ def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
     u = (G @ w.detach().double() @ G.t()).float().reshape(cout // 64, 64, cin // 8, 8, 16)
     return u.permute(0, 2, 3, 1, 4).contiguous()
-
-
-def pack_wbf16_weight(w: torch.Tensor) -> torch.Tensor:
-    """OIHW [Cout,Cin,3,3] -> U = G g G^T (fp64, rounded to fp32 once) split into hi = bf16(U), lo = bf16(U - hi), packed for
-    csrc/drunet_wbf16.hip: [Cout/64][Cin/16][xi 16][plane 2][cblk 2][co 64][ci 8] (bf16), xi = 4 * row + col"""
-    cout, cin = w.shape[:2]
-    if cin % 16 or cout % 64:
-        raise ValueError(f"Winograd bf16-split packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
-    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
-    u = (G @ w.detach().double() @ G.t()).float().reshape(cout, cin, 16)
-    hi = u.bfloat16()
-    lo = (u - hi.float()).bfloat16()
-    planes = torch.stack((hi, lo)).reshape(2, cout // 64, 64, cin // 16, 2, 8, 16)      # pl, ct, co, s, cblk, ci, xi
-    return planes.permute(1, 3, 6, 0, 4, 2, 5).contiguous()                             # ct, s, xi, pl, cblk, co, ci
 
 
 def pack_down_weight(w: torch.Tensor) -> torch.Tensor:
@@ -267,33 +235,6 @@ def conv3x3_tail(g, x, wtail, cin, cout, y, x2=None):
     check(_l().dinv_conv3x3_tail(ctypes.byref(g), ptr(x), ptr(x2), ptr(wtail), cin, cout, ptr(y), stream_ptr(y.device)))
 
 
-def conv3x3_bf16x3(g, x, wsplit, cin, cout, y, res1=None, relu=False, planes=3):
-    """EXPERIMENTAL: y = [relu](conv3x3(x)) (+res1) on the bf16 matrix cores, fp32-accurate 3-way split"""
-    if _prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    check(_l().dinv_conv3x3_bf16x3(ctypes.byref(g), ptr(x), ptr(wsplit), cin, cout, ptr(y), ptr(res1), int(relu),
-                                   int(planes), stream_ptr(y.device)))
-    if _prof is not None:
-        e1.record()
-        fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
-        _prof.append((e0, e1, "conv3x3_bf16x3_kernel", fl, (6.0 if planes == 3 else 3.0) * fl * 10 / 9))
-
-
-def conv3x3_bf16s(g, x, wsplit, cin, cout, y, res1=None, relu=False):
-    """y = [relu](conv3x3(x)) (+res1) on the bf16 matrix cores, two-part exact operand split, three products
-    (csrc/drunet_bf16s.hip); wsplit from pack_bf16s_weight"""
-    if _prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    check(_l().dinv_conv3x3_bf16s(ctypes.byref(g), ptr(x), ptr(wsplit), cin, cout, ptr(y), ptr(res1), int(relu),
-                                  stream_ptr(y.device)))
-    if _prof is not None:
-        e1.record()
-        fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
-        _prof.append((e0, e1, "conv3x3_bf16s_kernel", fl, 3.0 * fl))
-
-
 def conv3x3_split(g, x, wsplit, cin, cout, y, res1=None, relu=False, x_presplit=False, y_presplit=False):
     """y = [relu](conv3x3(x)) (+res1) on the bf16 matrix cores, two-part exact operand split, 2-D pixel tiles
     (csrc/drunet_split2d.hip); wsplit from pack_split2d_weight.  `x_presplit` / `y_presplit`: the activation buffer holds
@@ -308,21 +249,6 @@ def conv3x3_split(g, x, wsplit, cin, cout, y, res1=None, relu=False, x_presplit=
         e1.record()
         fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
         _prof.append((e0, e1, "conv3x3_split2d_kernel", fl, 3.0 * fl))
-
-
-def conv3x3_wbf16(g, x, usplit, cin, cout, y, res1=None, relu=False):
-    """OPT-IN, not yet measured on hardware: y = [relu](conv3x3(x)) (+res1) as Winograd F(2x2,3x3) on the bf16 matrix cores
-    with the two-part operand split (csrc/drunet_wbf16.hip); usplit from pack_wbf16_weight"""
-    if _prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    check(_l().dinv_conv3x3_wbf16(ctypes.byref(g), ptr(x), ptr(usplit), cin, cout, ptr(y), ptr(res1), int(relu),
-                                  stream_ptr(y.device)))
-    if _prof is not None:
-        e1.record()
-        fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
-        tiles = g.batch * ((g.height + 1) // 2) * ((g.width + 1) // 2)
-        _prof.append((e0, e1, "conv3x3_wbf16_kernel", fl, 3.0 * 2.0 * 16 * cin * cout * tiles))
 
 
 def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):

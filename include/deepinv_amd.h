@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 2 = this header (1: the round-1 entry points only) */
+int dinv_version(void);   /* 3 = this header (2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -157,23 +157,22 @@ int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const float* x2, c
  * relu and res1 are mutually exclusive (ResBlock conv1 / conv2, drunet.py:403-434). */
 int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w_wino, int32_t cin, int32_t cout,
                           float* y, const float* res1, int32_t relu, dinv_stream_t stream);
-/* EXPERIMENTAL (opt-in, DINV_CONV_BF16X3=1 in the Python layer): same operator as dinv_conv3x3_winograd on the BF16
- * matrix cores: operands split exactly into bf16 parts, leading products, fp32 accumulate.  planes = 3: three parts,
- * six products, fp32-level accuracy (~3e-7 per layer); planes = 2: two parts, three products (~5e-6 per layer).
- * w_split: [cout/64][cin/8][plane 3][tap 9][co 64][8] bf16; cin % 8 == 0, cout % 64 == 0. */
-int dinv_conv3x3_bf16x3(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin, int32_t cout,
-                        float* y, const float* res1, int32_t relu, int32_t planes, dinv_stream_t stream);
-/* Same operator on the BF16 matrix cores with a two-part exact operand split (x = xh + xl, three products
- * ah*bl + al*bh + ah*bh, fp32 accumulate; 2-4e-6 per layer vs fp64), software-pipelined (csrc/drunet_bf16s.hip).
- * w_split: [cout/64][cin/16][dy 3][plane 2][dx 3][cblk 2][co 64][8] bf16; cin % 16 == 0, cout % 64 == 0. */
-int dinv_conv3x3_bf16s(const dinv_act_geom* g, const float* x, const void* w_split, int32_t cin, int32_t cout,
-                       float* y, const float* res1, int32_t relu, dinv_stream_t stream);
-
-/* OPT-IN, validated on the host emulation only (no MI355X measurement yet): the same 3x3 convolution as Winograd
- * F(2x2,3x3) on the bf16 matrix cores with the two-part operand split: 2.25x fewer MFMAs than dinv_conv3x3_bf16s.
- * u_split: U = G g G^T (fp64 -> fp32) as hi / lo bf16, [Cout/64][Cin/16][xi 16][plane 2][cblk 2][co 64][ci 8]. */
-int dinv_conv3x3_wbf16(const dinv_act_geom* g, const float* x, const void* u_split, int32_t cin, int32_t cout,
-                       float* y, const float* res1, int32_t relu, dinv_stream_t stream);
+/* Same operator on the BF16 matrix cores with a two-part exact operand split (x = xh + xl with xh = bf16(x),
+ * xl = bf16(x - xh); three products ah*bl + al*bh + ah*bh, fp32 accumulate): per output
+ * |y - y_exact| <= 3 * 2^-16 * (|w| conv |x|), 2-4e-6 relative per layer on random data (csrc/drunet_split2d.hip: 2-D pixel
+ * tiles, whole-step LDS stages).  This is the "bf16split" setting of the ONE precision switch of the denoiser; the fp32
+ * setting uses dinv_conv3x3_winograd / dinv_conv3x3.
+ * w_split: [cout/64][cin/16][dy 3][plane hi/lo][dx 3][cblk 2][row 64][8] bf16, the rows of each 32-row tile permuted so
+ *   that row 8g + 4h + e carries cout 16(g>>1) + 8h + 4(g&1) + e (deepinv_amd/hip/drunet.py: pack_split2d_weight);
+ *   cin % 16 == 0, cout % 64 == 0.
+ * flags: bit 0  x is PRE-SPLIT: each pixel's 8-channel block holds 8 bf16 high parts then 8 bf16 low parts in the 32 bytes
+ *               an fp32 block occupies (what this kernel would split an fp32 block into);
+ *        bit 1  write y pre-split (no residual then);  bit 2  ReLU (no residual then);
+ *        bits 8-9  pixels per workgroup: 0 = chosen from the grid size, 1 = 128, 2 = 256.
+ * In a ResBlock (drunet.py:403-434) conv1 runs with flags 2|4 into a scratch buffer that conv2 reads with flag 1 and res1 = x.
+ * The geometry must come from dinv_act_geom_init of this library version (trailing slack for the halo rows of the last tile). */
+int dinv_conv3x3_split(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout, void* y,
+                       const float* res1, int32_t flags, dinv_stream_t stream);
 
 /* 2x2 stride-2 convolution (downsample_strideconv, drunet.py:524-552) on the bf16 matrix cores with the same exact
  * two-part operand split; w_split: [tap = dy*2+dx][Cin/16][plane hi/lo][cblk 2][Cout][ci 8] bf16.  Same operator as
@@ -206,7 +205,7 @@ int dinv_relu_inplace(int64_t n, float* x, dinv_stream_t stream);
 
 /* ---- 3-D volumes (DRUNet with dim = 3, deepinv/models/drunet.py:39-263 with Conv3d / ConvTranspose3d) on the 2-D
  * kernels: a volume of D slices occupies D + 2 consecutive images of the padded layout (a zero slice at each end).
- *   3x3x3 convolution = three 3x3 launches (dinv_conv3x3_bf16s / dinv_conv3x3) on views of x shifted by -1 / 0 / +1
+ *   3x3x3 convolution = three 3x3 launches (dinv_conv3x3_split / dinv_conv3x3) on views of x shifted by -1 / 0 / +1
  *     slices (pointer + dz * plane * 8 floats), accumulated through `res1 = y`; same for its weight gradient
  *     (dinv_conv_wgrad with a shifted L);
  *   2x2x2 stride-2 layers pair slice z of the half grid with slice 2 z + dz of the full grid: the _3d entry points

@@ -92,10 +92,10 @@ def bench_conv_levels(B):
         fl = 2.0 * 9 * c * c * B * H * H
         td = timeit(lambda: K.conv3x3(g, x, wd, ci, co, y, relu=True), iters=20, warmup=3)
         tw = timeit(lambda: K.conv3x3_winograd(g, x, ww, c, c, y, relu=True), iters=20, warmup=3)
-        ws = K.pack_bf16s_weight(w)
-        ts = timeit(lambda: K.conv3x3_bf16s(g, x, ws, c, c, y, relu=True), iters=20, warmup=3)
+        ws = K.pack_split2d_weight(w)
+        ts = timeit(lambda: K.conv3x3_split(g, x, ws, c, c, y, relu=True), iters=20, warmup=3)
         r = K.alloc(g, c, dev)
-        tsr = timeit(lambda: K.conv3x3_bf16s(g, x, ws, c, c, y, res1=r), iters=20, warmup=3)
+        tsr = timeit(lambda: K.conv3x3_split(g, x, ws, c, c, y, res1=r), iters=20, warmup=3)
         print(json.dumps({"op": "conv3x3", "B": B, "hw": H, "c": c, "direct_ms": td * 1e3, "wino_ms": tw * 1e3,
                           "bf16s_ms": ts * 1e3, "bf16s_res_ms": tsr * 1e3, "direct_TF": fl / td / 1e12,
                           "wino_effTF": fl / tw / 1e12, "bf16s_effTF": fl / ts / 1e12,

@@ -34,6 +34,16 @@ for lvl, c in enumerate((64, 128, 256, 512)):
     n1 = timeit(lambda: K.conv3x3_split(g, x, w2, c, c, t, relu=True, y_presplit=True), iters=20, warmup=3)
     n2 = timeit(lambda: K.conv3x3_split(g, t, w2, c, c, y, res1=r, x_presplit=True), iters=20, warmup=3)
     n3 = timeit(lambda: K.conv3x3_split(g, x, w2, c, c, y, res1=r), iters=20, warmup=3)
+    import ctypes
+    from deepinv_amd.hip import check, ptr, stream_ptr
+    def raw(xx, yy, res, flags):
+        check(K._l().dinv_conv3x3_split(ctypes.byref(g), ptr(xx), ptr(w2), c, c, ptr(yy), ptr(res), flags, stream_ptr(dev)))
+    s1 = timeit(lambda: raw(x, t, None, 4 | 2 | 0x400), iters=20, warmup=3)
+    s2 = timeit(lambda: raw(t, y, r, 1 | 0x400), iters=20, warmup=3)
+    row.update(sact_conv1_ms=round(s1 * 1e3, 4), sact_conv2_ms=round(s2 * 1e3, 4))
+    s1 = timeit(lambda: raw(x, t, None, 4 | 2 | 0x800), iters=20, warmup=3)
+    s2 = timeit(lambda: raw(t, y, r, 1 | 0x800), iters=20, warmup=3)
+    row.update(step_conv1_ms=round(s1 * 1e3, 4), step_conv2_ms=round(s2 * 1e3, 4))
     row.update(conv1_ms=round(n1 * 1e3, 4), conv2_ms=round(n2 * 1e3, 4), f32_res_ms=round(n3 * 1e3, 4),
                conv2_direct_TF=round(fl / n2 / 1e12, 1), conv1_direct_TF=round(fl / n1 / 1e12, 1))
     if hasattr(K, "conv3x3_bf16s"):

@@ -89,22 +89,24 @@ class RadonGeom:
     def desc(self, n_img, scale=1.0):
         return RadonDesc(n_img, self.W, self.G, self.pad, self.A, int(self.circle), float(scale), 0)
 
-    def plan(self, n_img):
+    def plan(self, n_img, kw=0):
+        """kw = 1, 2, 4, 8 forces the angles per workgroup (dinv_radon_plan_init reads plan.kw on entry), 0 = automatic"""
         l = lib()
         d = self.desc(n_img)
         nbytes = l.dinv_radon_plan_bytes(ctypes.byref(d))
         blob = np.zeros(nbytes // 4, np.int32)
         pl = RadonPlan()
+        pl.kw = kw
         check(l.dinv_radon_plan_init(ctypes.byref(d), p(self.cs), ctypes.byref(pl), p(blob)))
         return pl, blob
 
 
-def radon_forward_tiled(x, geo, norm=None, scale=1.0):
+def radon_forward_tiled(x, geo, norm=None, scale=1.0, kw=0):
     l = lib()
     B, C, W, _ = x.shape
     x = x.contiguous().float()
     d = geo.desc(B * C, scale)
-    pl, blob = geo.plan(B * C)
+    pl, blob = geo.plan(B * C, kw)
     sino = torch.full((B, C, geo.G, geo.A), float("nan"))
     ws = np.zeros(l.dinv_radon_tiled_workspace_bytes(ctypes.byref(d), 0), np.uint8)
     check(l.dinv_radon_forward_tiled(ctypes.byref(d), ctypes.byref(pl), p(blob), p(x), p(geo.xn), p(geo.cs), p(norm), p(sino),

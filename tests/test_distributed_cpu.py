@@ -209,3 +209,83 @@ def test_tile_parallel_processing_matches_untiled():
     parts = [torch.from_numpy(r[2]) for r in results]
     assert torch.allclose(parts[0] + parts[1], ref, atol=1e-6)
     assert torch.all((parts[0] == 0) | (parts[1] == 0))
+
+
+def _distribute_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import deepinv_amd as dinv
+    from deepinv_amd.distributed import BatchParallelContext, DistributedProcessing, distribute
+
+    g = torch.Generator().manual_seed(0)
+    Ms = [torch.randn(5, 4, generator=g) for _ in range(3)]
+
+    class Mat(dinv.physics.LinearPhysics):
+        def __init__(self, M):
+            super().__init__()
+            self.M = M
+
+        def A(self, x, **k):
+            return x @ self.M.T
+
+        def A_adjoint(self, y, **k):
+            return y @ self.M
+
+    x = torch.randn(2, 4, generator=g)
+    with BatchParallelContext(backend="gloo", device="cpu") as ctx:
+        phys = distribute([Mat(M) for M in Ms], ctx)                       # list of LinearPhysics -> stacked distributed
+        df = distribute(dinv.optim.L2(sigma=0.5), ctx)                      # one fidelity for every operator
+        df_list = distribute([dinv.optim.L2(sigma=0.5) for _ in Ms], ctx)   # ... or one per operator
+        y = phys.A(x + 1.0, gather=True)
+        f, gr = df.fn(x, y, phys), df.grad(x, y, phys)
+        f2, gr2 = df_list.fn(x, y, phys), df_list.grad(x, y, phys)
+        fm = distribute(dinv.optim.L2(sigma=0.5), ctx, reduction="mean").fn(x, y, phys)
+        # ONE operator on two ranks: rank 1 owns nothing and must still join the all-reduce with a zero image
+        single = distribute([Mat(Ms[0])], ctx, img_shape=(2, 4))
+        y1 = single.A(x, gather=False)
+        aty = single.A_adjoint(y1 if y1 else [])
+        ata = single.A_adjoint_A(x)
+        # per-sample arguments follow the windows on the batch axis
+        sig = torch.tensor([0.5, 2.0]).view(2, 1, 1, 1)
+        proc = DistributedProcessing(ctx, lambda z, s: z * s.view(-1, 1, 1, 1), strategy_kwargs={"patch_size": 8, "overlap": 2})
+        img = torch.rand(2, 1, 16, 24, generator=g)
+        scaled = proc(img, sig.view(2))
+        try:
+            distribute(lambda i, d, k: Mat(Ms[i]), ctx)
+            err = ""
+        except ValueError as e:
+            err = str(e)
+        q.put((rank, f.numpy(), gr.numpy(), f2.numpy(), gr2.numpy(), fm.numpy(), aty.numpy(), ata.numpy(), scaled.numpy(),
+               (img * sig).numpy(), err, type(phys).__name__, type(df).__name__))
+
+
+def test_distribute_factory_and_distributed_data_fidelity():
+    """distribute() (distribute.py:214-420) and DistributedDataFidelity (distrib_framework.py:940-1180) on 2 gloo ranks: value
+    and gradient equal the single-process sums; a rank without operators contributes zeros instead of dead-locking the
+    all-reduce; per-sample tensor arguments of a tiled processor are repeated with the windows"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_distribute_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(0)
+    Ms = [torch.randn(5, 4, generator=g) for _ in range(3)]
+    x = torch.randn(2, 4, generator=g)
+    ys = [(x + 1.0) @ M.T for M in Ms]
+    f_ref = sum(0.5 * ((x @ M.T - y) ** 2).sum(1) / 0.25 for M, y in zip(Ms, ys))
+    g_ref = sum(((x @ M.T - y) / 0.25) @ M for M, y in zip(Ms, ys))
+    for r in results:
+        _, f, gr, f2, gr2, fm, aty, ata, scaled, scaled_ref, err, tp, td = r
+        assert tp == "DistributedStackedLinearPhysics" and td == "DistributedDataFidelity"
+        for a, b in ((f, f_ref), (f2, f_ref), (gr, g_ref), (gr2, g_ref), (fm, f_ref / 3)):
+            assert torch.allclose(torch.from_numpy(a), b, atol=1e-5)
+        assert torch.allclose(torch.from_numpy(aty), (x @ Ms[0].T) @ Ms[0], atol=1e-5)
+        assert torch.allclose(torch.from_numpy(ata), (x @ Ms[0].T) @ Ms[0], atol=1e-5)
+        assert torch.allclose(torch.from_numpy(scaled), torch.from_numpy(scaled_ref), atol=1e-6)
+        assert "type_object" in err

@@ -116,65 +116,15 @@ def test_winograd_conv_rejects_unsupported_channel_counts(dev):
         K.conv3x3_winograd(geo, x, torch.zeros(1, 3, 8, 64, 16, device=dev), 24, 64, y)
 
 
-def test_drunet_winograd_matches_oracle(dev, monkeypatch):
+def test_drunet_fp32_precision_matches_oracle(dev):
+    """the ONE precision switch: conv_precision = "fp32" (fp32 multiplies: Winograd F(2x2,3x3) / direct MFMA kernels)"""
     import deepinv_amd as dinv
 
-    monkeypatch.setenv("DINV_WINOGRAD", "1")
-    monkeypatch.setenv("DINV_DRUNET_CONV", "wino")
     sd = OD.init_state_dict(2, 2, seed=1)
     model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
     model.load_state_dict(sd)
     model.eval()
-    x = torch.rand(2, 2, 64, 96, generator=torch.Generator().manual_seed(0))
-    with torch.no_grad():
-        out = model(x.to(dev), 0.05)
-    assert rel_err(out, OD.drunet(sd, x, 0.05)) < 1e-4
-
-
-@pytest.mark.parametrize("planes,tol", [(3, 1e-6), (2, 2e-5)])
-@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(2, 24, 40, 64, 64, "plain"), (1, 17, 33, 32, 128, "relu"),
-                                                 (2, 16, 16, 128, 64, "res"), (3, 5, 7, 8, 64, "plain")])
-def test_bf16_split_conv_matches_fp64_conv(dev, planes, tol, B, H, W, cin, cout, mode):
-    """EXPERIMENTAL bf16-split convolution (opt-in): exact 3-way split / six products is fp32-class (measured 3e-7),
-    the 2-way split / three products stays below 5e-6 per layer."""
-    from deepinv_amd.hip import drunet as K
-
-    g = torch.Generator().manual_seed(B * 100 + H)
-    x = torch.randn(B, cin, H, W, generator=g).to(dev)
-    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)).to(dev)
-    r = torch.randn(B, cout, H, W, generator=g).to(dev)
-    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
-    if mode == "relu":
-        ref = ref.relu()
-    if mode == "res":
-        ref = ref + r.double()
-    geo = K.geom(B, H, W)
-
-    def to_act(t):
-        a = K.alloc(geo, t.shape[1], dev)
-        av = a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
-        av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
-        return a
-
-    xa, ra, ya = to_act(x), to_act(r), K.alloc(geo, cout, dev)
-    K.conv3x3_bf16x3(geo, xa, K.pack_bf16x3_weight(w), cin, cout, ya, res1=ra if mode == "res" else None,
-                     relu=mode == "relu", planes=planes)
-    av = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
-    out = av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W)
-    assert rel_err(out, ref) < tol
-    assert av[:, :, 0].abs().max() == 0 and av[:, :, H + 1:].abs().max() == 0
-    assert av[:, :, :, 0].abs().max() == 0 and av[:, :, :, W + 1:].abs().max() == 0
-
-
-@pytest.mark.parametrize("planes", ["2", "3"])
-def test_drunet_bf16_split_matches_oracle(dev, monkeypatch, planes):
-    import deepinv_amd as dinv
-
-    monkeypatch.setenv("DINV_CONV_BF16X3", planes)
-    sd = OD.init_state_dict(2, 2, seed=1)
-    model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
-    model.load_state_dict(sd)
-    model.eval()
+    model.conv_precision = "fp32"
     x = torch.rand(2, 2, 64, 96, generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
         out = model(x.to(dev), 0.05)
@@ -185,20 +135,19 @@ def test_drunet_bf16_split_matches_oracle(dev, monkeypatch, planes):
                                                  (2, 16, 16, 128, 64, "res"), (3, 5, 7, 16, 64, "plain"),
                                                  (1, 160, 160, 128, 128, "relu"), (2, 20, 20, 512, 512, "res"),
                                                  (70, 4, 6, 32, 128, "plain"), (1, 2, 330, 64, 64, "res")])
-def test_bf16s_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
-    """pipelined two-part bf16 split (csrc/drunet_bf16s.hip): three products, a few 1e-6 per layer against fp64;
-    512-pixel tiles incl. ragged last tile, many tiny images, a single long row"""
+@pytest.mark.parametrize("fmt", ["f32", "in_split", "out_split"])
+def test_split2d_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode, fmt):
+    """two-part bf16 split on 2-D pixel tiles (csrc/drunet_split2d.hip): three products, a few 1e-6 per layer against fp64;
+    tile widths 32 / 16 / 8 incl. partial column tiles, row tiles that straddle images, many tiny images, a single long
+    row; fp32 and pre-split activation buffers (a pre-split input is what the kernel would split an fp32 one into)"""
     from deepinv_amd.hip import drunet as K
 
+    if fmt == "out_split" and mode == "res":
+        pytest.skip("a pre-split output carries no residual")
     g = torch.Generator().manual_seed(B * 100 + H)
     x = torch.randn(B, cin, H, W, generator=g).to(dev)
     w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)).to(dev)
     r = torch.randn(B, cout, H, W, generator=g).to(dev)
-    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
-    if mode == "relu":
-        ref = ref.relu()
-    if mode == "res":
-        ref = ref + r.double()
     geo = K.geom(B, H, W)
 
     def to_act(t):
@@ -207,8 +156,29 @@ def test_bf16s_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
         av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
         return a
 
+    def presplit(a):      # [C/8, cs, 8] fp32 -> the same bytes holding (8 bf16 high parts | 8 bf16 low parts)
+        hi = a.bfloat16()
+        lo = (a - hi.float()).bfloat16()
+        return torch.cat((hi, lo), dim=-1).view(torch.float32).contiguous()
+
+    def unsplit(a):
+        h = a.view(torch.bfloat16).view(a.shape[0], a.shape[1], 16)
+        return (h[..., :8].float() + h[..., 8:].float()).contiguous()
+
     xa, ra, ya = to_act(x), to_act(r), K.alloc(geo, cout, dev)
-    K.conv3x3_bf16s(geo, xa, K.pack_bf16s_weight(w), cin, cout, ya, res1=ra if mode == "res" else None, relu=mode == "relu")
+    if fmt == "in_split":
+        xa = presplit(xa)
+        av = unsplit(xa)[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+        x = av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cin, H, W)     # the operand the kernel sees
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+    K.conv3x3_split(geo, xa, K.pack_split2d_weight(w), cin, cout, ya, res1=ra if mode == "res" else None, relu=mode == "relu",
+                    x_presplit=fmt == "in_split", y_presplit=fmt == "out_split")
+    if fmt == "out_split":
+        ya = unsplit(ya)
     av = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
     out = av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W)
     assert rel_err(out, ref) < 2e-5
@@ -216,19 +186,54 @@ def test_bf16s_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
     assert av[:, :, :, 0].abs().max() == 0 and av[:, :, :, W + 1:].abs().max() == 0
 
 
-def test_drunet_bf16s_matches_oracle(dev, monkeypatch):
+@pytest.mark.parametrize("case", ["wide", "he_scale"])
+def test_split_worst_case_bound(dev, case):
+    """the operand split's worst-case bound element by element on the hardware kernel (the emulated twin of this test,
+    tests/test_emu_drunet.py::test_split_worst_case, explains it): |y - y_exact| <= (3 * 2^-16 + 2^-20) (|w| conv |x|) for
+    activations spanning 2^-20 .. 2^8 and weights 2^-12 .. 2^2; He-scaled weights and N(0,1) data stay at a few 1e-6"""
+    from deepinv_amd.hip import drunet as K
+
+    gen = torch.Generator().manual_seed(11)
+    B, H, W, cin, cout = 2, 64, 96, 128, 128
+
+    def wide(shape, lo, hi):
+        e = torch.randint(lo, hi + 1, shape, generator=gen).float()
+        return (1 + torch.rand(shape, generator=gen)) * torch.exp2(e) * (torch.randint(0, 2, shape, generator=gen) * 2 - 1).float()
+
+    if case == "wide":
+        x, w = wide((B, cin, H, W), -20, 8), wide((cout, cin, 3, 3), -12, 2)
+    else:
+        x, w = torch.randn(B, cin, H, W, generator=gen), torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    x, w = x.to(dev), w.to(dev)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    mag = torch.nn.functional.conv2d(x.double().abs(), w.double().abs(), padding=1)
+    geo = K.geom(B, H, W)
+    xa, ya = K.alloc(geo, cin, dev), K.alloc(geo, cout, dev)
+    xa[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:W + 1] = x.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+    K.conv3x3_split(geo, xa, K.pack_split2d_weight(w), cin, cout, ya)
+    av = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+    out = av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W).double()
+    assert bool(((out - ref).abs() <= (3 * 2.0 ** -16 + 2.0 ** -20) * mag).all()), float(((out - ref).abs() / mag).max())
+    if case == "he_scale":
+        assert rel_err(out, ref) < 5e-6
+
+
+def test_drunet_default_precision_matches_oracle(dev):
     import deepinv_amd as dinv
 
-    monkeypatch.setenv("DINV_DRUNET_CONV", "bf16s")
-    monkeypatch.setenv("DINV_DRUNET_CONV_FORCE", "1")
     sd = OD.init_state_dict(2, 2, seed=1)
     model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
     model.load_state_dict(sd)
     model.eval()
+    assert model.conv_precision == "bf16split"
     x = torch.rand(2, 2, 64, 96, generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
         out = model(x.to(dev), 0.05)
     assert rel_err(out, OD.drunet(sd, x, 0.05)) < 1e-4
+    model.conv_precision = "fp64"
+    with pytest.raises(ValueError, match="conv_precision"):
+        with torch.no_grad():
+            model(x.to(dev), 0.05)
 
 
 def test_tile_parallel_drunet_single_rank(dev):
@@ -262,8 +267,8 @@ def test_tile_parallel_drunet_single_rank(dev):
     assert rel_err(y, ref) < 1e-5
 
 
-def _grad_run(model, x0, sig0, v, mode, monkeypatch):
-    monkeypatch.setenv("DINV_DRUNET_TRAIN", mode)
+def _grad_run(model, x0, sig0, v, mode, monkeypatch=None):
+    model.backend = mode
     model.zero_grad()
     x = x0.clone().requires_grad_(True)
     sig = sig0.clone().requires_grad_(True)
@@ -304,7 +309,7 @@ def test_drunet_hip_backward_matches_autograd(dev, monkeypatch):
     assert worst[0] < 1e-4, worst            # measured ~1e-5 (fp32 forward: same ReLU masks as the fp32 reference)
     # the inference kernels in the forward pass (bf16 split, a few 1e-6): data gradients stay fp32-class, a few ReLU
     # masks at |z| ~ 1e-6 flip and move single rows of single weight gradients (see models/drunet_train.py)
-    monkeypatch.setenv("DINV_DRUNET_TRAIN_PRECISION", "bf16s")
+    model.train_forward_precision = "bf16split"
     y_b, gx_b, gs_b, gw_b = _grad_run(model, x0, sig0, v, "hip", monkeypatch)
     assert rel_err(y_b, y_t) < 1e-4 and rel_err(gx_b, gx_t) < 1e-4 and rel_err(gs_b, gs_t) < 1e-4
     errs = sorted(rel_err(gw_b[n], gw_t[n]) for n in gw_t)
@@ -347,12 +352,9 @@ def test_drunet_hip_backward_frozen_weights_and_unsafe_shape(dev):
     y = model(x, 0.07)
     y.square().sum().backward()
     g_hip = x.grad.clone()
-    os.environ["DINV_DRUNET_TRAIN"] = "torch"
-    try:
-        x2 = x.detach().clone().requires_grad_(True)
-        model(x2, 0.07).square().sum().backward()
-    finally:
-        del os.environ["DINV_DRUNET_TRAIN"]
+    model.backend = "torch"
+    x2 = x.detach().clone().requires_grad_(True)
+    model(x2, 0.07).square().sum().backward()
     assert rel_err(g_hip, x2.grad) < 1e-4
 
 
@@ -371,14 +373,14 @@ def test_drunet3d_hip_matches_torch_graph(dev, monkeypatch):
     sig0 = (0.05 + 0.1 * torch.rand(B, 1, D, H, W, generator=g)).to(dev)
     v = torch.randn(B, 2, D, H, W, generator=g).to(dev)
     with torch.no_grad():
-        monkeypatch.setenv("DINV_DRUNET3D", "torch")
+        model.backend = "torch"
         y_ref = model(x0, sig0)
-        monkeypatch.setenv("DINV_DRUNET3D", "hip")
+        model.backend = "hip"
         y_inf = model(x0, sig0)            # bf16-split kernels
     assert rel_err(y_inf, y_ref) < 1e-4
 
     def run(mode):
-        monkeypatch.setenv("DINV_DRUNET3D", mode)
+        model.backend = mode
         model.zero_grad()
         x = x0.clone().requires_grad_(True)
         sig = sig0.clone().requires_grad_(True)

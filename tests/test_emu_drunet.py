@@ -1,4 +1,4 @@
-"""The bf16-split DRUNet convolution kernel (deepinv_amd/csrc/drunet_bf16s.hip) executed on the HOST by the fiber
+"""The bf16-split DRUNet convolution kernels (deepinv_amd/csrc/drunet_split2d.hip, drunet_bf16s.hip) executed on the HOST by the fiber
 emulation of tests/emu (MFMA emulated from the documented fragment layout) against an fp64 convolution."""
 import ctypes
 
@@ -48,8 +48,8 @@ def from_act(a, g, C):
 def pack(w):
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from deepinv_amd.hip.drunet import pack_bf16s_weight   # pure torch host code
-    return pack_bf16s_weight(w)
+    from deepinv_amd.hip.drunet import pack_split2d_weight   # pure torch host code
+    return pack_split2d_weight(w)
 
 
 def split_to_act(t, g):
@@ -154,38 +154,6 @@ def test_split_worst_case(case):
     assert worst < 3 * 2.0 ** -16
     if case == "he_scale":
         assert float((out - ref).norm() / ref.norm()) < 5e-6
-
-
-@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 12, 20, 16, 64, "plain"), (2, 9, 14, 32, 64, "relu"),
-                                                 (1, 17, 33, 32, 128, "res"), (3, 16, 16, 64, 64, "plain"),
-                                                 (4, 40, 52, 16, 128, "res")])
-@pytest.mark.parametrize("waves", [8, 4])      # 512-pixel workgroups / 256-pixel workgroups (two per CU, the default)
-def test_bf16_split_conv_matches_fp64(B, H, W, cin, cout, mode, waves, monkeypatch):
-    monkeypatch.setenv("DINV_BF16S_WAVES", str(waves))
-    gen = torch.Generator().manual_seed(H * W + cin)
-    x = torch.randn(B, cin, H, W, generator=gen)
-    w = torch.randn(cout, cin, 3, 3, generator=gen) / (3.0 * cin ** 0.5)
-    r = torch.randn(B, cout, H, W, generator=gen)
-    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
-    if mode == "relu":
-        ref = ref.relu()
-    if mode == "res":
-        ref = ref + r.double()
-    g = geom(B, H, W)
-    xa, ra = to_act(x, g), to_act(r, g)
-    ya = torch.full((cout // 8, g.cs, 8), float("nan"))
-    wp = pack(w)
-    l = E.lib()
-    E.check(l.dinv_conv3x3_bf16s(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya),
-                                 E.p(ra) if mode == "res" else None, int(mode == "relu"), None))
-    out = from_act(ya, g, cout)
-    assert not torch.isnan(out).any()
-    err = float((out.double() - ref).norm() / ref.norm())
-    assert err < 2e-5, err          # two-part split: a few 1e-6 per layer
-    # the zero border of the padded layout stays zero (the next layer reads it as padding)
-    full = ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
-    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
-    assert float(full[:, :, H + 1].abs().max()) == 0 and float(full[:, :, :, W + 1:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(1, 8, 12, 16, 64), (2, 10, 6, 32, 128), (3, 16, 16, 64, 64)])
@@ -401,43 +369,10 @@ def test_conv3x3x3_as_three_shifted_2d_launches():
         xv = xa[:, guard + (dz - 1) * g.plane:]
         yv = ya[:, guard:]
         wp = pack(w[:, :, dz].contiguous())
-        E.check(l.dinv_conv3x3_bf16s(ctypes.byref(g), ctypes.c_void_p(xv.data_ptr()), ctypes.c_void_p(wp.data_ptr()), C, cout,
+        E.check(l.dinv_conv3x3_split(ctypes.byref(g), ctypes.c_void_p(xv.data_ptr()), ctypes.c_void_p(wp.data_ptr()), C, cout,
                                      ctypes.c_void_p(yv.data_ptr()), ctypes.c_void_p(yv.data_ptr()) if dz else None, 0, None))
     out = ya[:, guard + g.sl: guard + g.sl + g.np].view(-1, B, D + 2, g.hp, g.wp, 8)[:, :, 1:-1, 1:H + 1, 1:W + 1]
     got = out.permute(1, 0, 5, 2, 3, 4).reshape(B, cout, D, H, W)
     assert float((got.double() - ref).norm() / ref.norm()) < 2e-5
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 16, 16, 16, 64, "plain"), (2, 9, 14, 32, 64, "relu"), (1, 17, 33, 32, 128, "res"),
-                                                 (3, 8, 8, 64, 64, "plain"), (1, 40, 20, 16, 64, "res")])
-def test_winograd_bf16_split_conv_matches_fp64(B, H, W, cin, cout, mode):
-    """csrc/drunet_wbf16.hip (opt-in: Winograd F(2x2,3x3) on the bf16 matrix cores, two-part operand split) on the host
-    emulation against an fp64 convolution: odd sizes, partial 8x8-tile workgroups, several images, ReLU / residual"""
-    import sys, os
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from deepinv_amd.hip.drunet import pack_wbf16_weight
-
-    gen = torch.Generator().manual_seed(H * W + cin)
-    x = torch.randn(B, cin, H, W, generator=gen)
-    w = torch.randn(cout, cin, 3, 3, generator=gen) / (3.0 * cin ** 0.5)
-    r = torch.randn(B, cout, H, W, generator=gen)
-    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
-    if mode == "relu":
-        ref = ref.relu()
-    if mode == "res":
-        ref = ref + r.double()
-    g = geom(B, H, W)
-    xa, ra = to_act(x, g), to_act(r, g)
-    ya = torch.zeros((cout // 8, g.cs, 8))
-    ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, 1:H + 1, 1:W + 1] = float("nan")     # interior must be written
-    up = pack_wbf16_weight(w)
-    l = E.lib()
-    E.check(l.dinv_conv3x3_wbf16(ctypes.byref(g), E.p(xa), ctypes.c_void_p(up.data_ptr()), cin, cout, E.p(ya),
-                                 E.p(ra) if mode == "res" else None, int(mode == "relu"), None))
-    assert not torch.isnan(ya).any()
-    out = from_act(ya, g, cout)
-    err = float((out.double() - ref).norm() / ref.norm())
-    assert err < 3e-5, err          # Winograd transforms + two-part split: ~1e-5 per layer
-    full = ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)                                   # the zero frame is never touched
-    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
-    assert float(full[:, :, H + 1].abs().max()) == 0 and float(full[:, :, :, W + 1:].abs().max()) == 0

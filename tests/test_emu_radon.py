@@ -53,12 +53,11 @@ def test_tiled_forward_adjoint_match_oracle(case):
 
 
 @pytest.mark.parametrize("kw", [1, 2, 4, 8])
-def test_tiled_forward_every_chunk_width(kw, monkeypatch):
-    monkeypatch.setenv("DINV_RADON_KW", str(kw))
+def test_tiled_forward_every_chunk_width(kw):
     W, ang = 40, torch.linspace(0, 180, 24)[:-1]
     geo = E.RadonGeom(ang, W, False)
     x = torch.rand(2, 1, W, W, generator=torch.Generator().manual_seed(kw))
-    y, plan = E.radon_forward_tiled(x, geo)
+    y, plan = E.radon_forward_tiled(x, geo, kw=kw)
     assert plan.kw == kw and rel(y, O.radon_forward(x, ang)) < 2e-6 and misses()[0] == 0
 
 

@@ -154,24 +154,18 @@ def test_tomography_normalised_golden(dev):
     assert rel_err(p.A_dagger(d["y"], fbp=True), d["fbp"]) < TOL
 
 
-@pytest.mark.parametrize("mode", ["", "2", "3", "bf16s"])
-def test_drunet_unit_gain_resblocks_golden(dev, mode, monkeypatch):
+@pytest.mark.parametrize("mode", ["fp32", "bf16split"])
+def test_drunet_unit_gain_resblocks_golden(dev, mode):
     """End-to-end DRUNet parity that is sensitive to the ResBlock kernels: orthogonal gain 1.0 on the 56 ResBlock convs
-    (with the reference's 0.2 every branch is ~0.04x the identity path).  Default fp32 Winograd path and both
-    bf16-split forms must stay within the north_star's 1e-4 of the reference's output."""
+    (with the reference's 0.2 every branch is ~0.04x the identity path).  Both settings of the precision switch must stay
+    within the north_star's 1e-4 of the reference's output."""
     import deepinv_amd as dinv
     from oracle import drunet_cpu as OD
 
-    monkeypatch.delenv("DINV_CONV_BF16X3", raising=False)
-    monkeypatch.setenv("DINV_DRUNET_CONV", "wino")
-    if mode == "bf16s":      # the pipelined two-part split kernel, forced also where its tiles would not fill the chip
-        monkeypatch.setenv("DINV_DRUNET_CONV", "bf16s")
-        monkeypatch.setenv("DINV_DRUNET_CONV_FORCE", "1")
-    elif mode:
-        monkeypatch.setenv("DINV_CONV_BF16X3", mode)
     sd = OD.init_state_dict(2, 2, seed=321, res_gain=1.0)
     den = dinv.models.DRUNet(2, 2, pretrained=None).to(dev).eval()
     den.load_state_dict(sd)
+    den.conv_precision = mode
     d = load("drunet_gain1", dev)
     with torch.no_grad():
         err = rel_err(den(d["x"], 0.05), d["y"])
