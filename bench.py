@@ -328,38 +328,57 @@ def _pgd_cpu(sd, maps, mask, y, iters):
 
 
 def cpu_worker(path):
-    """one process of the whole-box CPU run: the full reconstruction of ONE slice on `threads` cores"""
+    """one process of the whole-box CPU run: a few PGD iterations of ONE slice on `threads` cores; reports seconds per iteration"""
     job = torch.load(path)
     common = torch.load(job["common"])
     torch.set_num_threads(job["threads"])
+    _pgd_cpu(common["sd"], common["maps"], common["mask"], job["y"], 1)      # warm-up (thread pools, oneDNN primitives)
     t0 = time.perf_counter()
-    xk = _pgd_cpu(common["sd"], common["maps"], common["mask"], job["y"], job["iters"])
-    torch.save({"x": xk, "s": time.perf_counter() - t0}, path + ".out")
+    _pgd_cpu(common["sd"], common["maps"], common["mask"], job["y"], job["iters"])
+    torch.save({"s_per_it": (time.perf_counter() - t0) / job["iters"]}, path + ".out")
 
 
-def cpu_baseline(denoiser, maps, mask, H, W, coils, iters, y_cpu, x_gpu):
+def usable_cores():
+    """cores this process may really use: the scheduler affinity and the cgroup CPU quota, not the machine's core count"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(denoiser, maps, mask, H, W, coils, iters, y_cpu, x_gpu, parity_slices=4, box_iters=3, box_timeout=90.0):
     """The oracle ("port": same ATen CPU call sequence as the reference) timed on this box's host cores on a bounded
     sample of the same workload, two ways:
       * one process on its best thread count (calibrated: oneDNN / MKL at batch 1 degrade when oversubscribed): median of
         three timed samples - slice 0 for all `iters` iterations, then twice for iters/5 iterations (per-iteration cost is
         constant) - this is `value` / `cores`;
-      * the whole box: P = host_cores / threads processes at once, each reconstructing a DIFFERENT slice of the GPU batch
-        for all `iters` iterations (`whole_box`: aggregate slices/s over the wall time of the group).
-    The CPU reconstructions are kept: the largest relative distance to the GPU reconstruction of the same measurement over
-    all of them is the headline-configuration parity figure (`parity_rel_err_50it`, north_star bound 1e-4)."""
+      * the whole box (`whole_box`): P = usable cores / threads processes at once, each running `box_iters` iterations of a
+        different slice; aggregate slices/s = P / (slowest per-iteration time x iters).  Bounded: the group is killed after
+        `box_timeout` seconds (an oversubscribed or quota-limited box then reports `timed_out`).
+    Slices 0 .. parity_slices-1 are reconstructed on the CPU for all `iters` iterations: the largest relative distance to the
+    GPU reconstruction of the same measurement is the headline-configuration parity figure (`parity_rel_err_50it`,
+    north_star bound 1e-4)."""
     import statistics
     import subprocess
     import tempfile
 
     from oracle import drunet_cpu as OD
 
-    cores = os.cpu_count() or 1
+    cores, usable = os.cpu_count() or 1, usable_cores()
     sd = {k: v.detach().cpu() for k, v in denoiser.state_dict().items()}
     calib = {}
     with torch.no_grad():
         probe = torch.rand(1, 2, H, W, generator=torch.Generator().manual_seed(7))
         best = None
-        for nt in [c for c in (8, 16, 32, 64, 128) if c <= cores] or [cores]:
+        for nt in [c for c in (8, 16, 32, 64, 128) if c <= usable] or [usable]:
             torch.set_num_threads(nt)
             OD.drunet(sd, probe.new_zeros(1, 2, H, W), 0.05)
             t0 = time.perf_counter()
@@ -383,33 +402,49 @@ def cpu_baseline(denoiser, maps, mask, H, W, coils, iters, y_cpu, x_gpu):
         _pgd_cpu(sd, maps, mask, y_cpu[:1], short)
         samples.append((time.perf_counter() - t0) / short)
     per_it = statistics.median(samples)
-    # ---- whole box: P concurrent single-slice processes
-    nproc = max(1, min(cores // threads, y_cpu.shape[0] - 1, 16))
-    whole = None
-    with tempfile.TemporaryDirectory() as tmp:
-        paths = []
-        common = os.path.join(tmp, "common.pt")
-        torch.save({"sd": sd, "maps": maps, "mask": mask}, common)
-        for i in range(nproc):
-            pth = os.path.join(tmp, f"job{i}.pt")
-            torch.save({"common": common, "y": y_cpu[1 + i:2 + i].clone(), "iters": iters, "threads": threads}, pth)
-            paths.append(pth)
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
-        t0 = time.perf_counter()
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", pth], env=env,
-                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for pth in paths]
-        rcs = [pr.wait() for pr in procs]
-        wall = time.perf_counter() - t0
-        outs = [torch.load(pth + ".out") for pth, rc in zip(paths, rcs) if rc == 0 and os.path.exists(pth + ".out")]
-        if len(outs) == nproc:
-            for i, o in enumerate(outs):
-                recs[1 + i] = o["x"]
-            inner = max(o["s"] for o in outs)   # slowest reconstruction, without interpreter start-up and file IO
-            whole = {"processes": nproc, "threads_each": threads, "value": round(nproc / inner, 5), "unit": "slices/s",
-                     "wall_s_incl_startup": round(wall, 1), "slowest_reconstruction_s": round(inner, 1)}
+    for i in range(1, min(parity_slices, y_cpu.shape[0])):        # more slices for the parity figure (not timed)
+        recs[i] = _pgd_cpu(sd, maps, mask, y_cpu[i:i + 1], iters)
+    # ---- whole box: P concurrent single-slice processes, a few iterations each
+    nproc = max(1, min(usable // threads, y_cpu.shape[0], 32))
+    whole = {"processes": nproc, "threads_each": threads, "usable_cores": usable}
+    if nproc > 1:
+        with tempfile.TemporaryDirectory() as tmp:
+            paths = []
+            common = os.path.join(tmp, "common.pt")
+            torch.save({"sd": sd, "maps": maps, "mask": mask}, common)
+            for i in range(nproc):
+                pth = os.path.join(tmp, f"job{i}.pt")
+                torch.save({"common": common, "y": y_cpu[i:i + 1].clone(), "iters": box_iters, "threads": threads}, pth)
+                paths.append(pth)
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="",
+                       OMP_WAIT_POLICY="PASSIVE")
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", pth], env=env,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for pth in paths]
+            timed_out = False
+            for pr in procs:
+                left = box_timeout - (time.perf_counter() - t0)
+                try:
+                    pr.wait(timeout=max(left, 0.1))
+                except subprocess.TimeoutExpired:
+                    timed_out = True
+            if timed_out:
+                for pr in procs:
+                    if pr.poll() is None:
+                        pr.kill()
+            outs = [torch.load(pth + ".out") for pth in paths if os.path.exists(pth + ".out")]
+            whole["wall_s_incl_startup"] = round(time.perf_counter() - t0, 1)
+            if len(outs) == nproc and not timed_out:
+                slowest = max(o["s_per_it"] for o in outs)
+                whole.update(value=round(nproc / (slowest * iters), 5), unit="slices/s",
+                             slowest_s_per_iteration=round(slowest, 4), sample=f"{box_iters} iterations per process")
+            else:
+                whole.update(timed_out=True, finished=len(outs))
+    else:
+        whole.update(value=round(1.0 / (per_it * iters), 5), unit="slices/s", sample="one process fills the usable cores")
     errs = {i: float((x_gpu[i:i + 1].double() - xk.double()).norm() / xk.double().norm()) for i, xk in recs.items()}
     return {"value": round(1.0 / (per_it * iters), 5), "unit": "slices/s", "cores": threads, "host_cores": cores,
-            "kind": "port", "threads_calibration_s_per_denoiser_call": calib,
+            "usable_cores": usable, "kind": "port", "threads_calibration_s_per_denoiser_call": calib,
             "samples_s_per_iteration": [round(v, 4) for v in samples],
             "sample": f"slice 0 of the batch: median of 3 timed samples ({iters} it once, {short} it twice), "
                       f"{per_it * iters:.1f} s per slice",

@@ -15,3 +15,5 @@ from . import unfolded  # noqa: F401
 from . import utils  # noqa: F401
 from . import sampling  # noqa: F401
 from . import distributed  # noqa: F401
+from . import training  # noqa: F401
+from .training import Trainer, train  # noqa: F401

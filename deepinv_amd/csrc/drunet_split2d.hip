@@ -71,6 +71,10 @@ struct S2Args {
     int32_t cin;
     int32_t ntc, ytiles, ntiles, tiles_per_xcd;
     int32_t rows;        // batch * hp flattened image rows
+    // 3x3x3 mode (volumes as stacks of depth_s = D + 2 slices, a zero slice at each end): the K loop also runs over the
+    // ndz = 3 depth taps, tap dz reading the input shifted by dz - 1 slices (dz_stride floats per slice); ndz = 1: plain 2-D
+    int32_t ndz, depth_s;
+    int64_t dz_stride;
 };
 
 __device__ __forceinline__ unsigned f2bf(float f) {   // round to nearest even, as v_cvt_pk_bf16_f32
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split2d_kernel(S2Args a) {
     const int tr_i = tile / a.ntc, tc_i = tile - tr_i * a.ntc;
     const int r0 = tr_i * TR, c0 = 1 + tc_i * TC;      // first interior row (flattened over images) / column of the tile
     const int nstep = a.cin / 16, nsub = 3 * nstep;
+    const int nk = a.ndz * nstep;                       // K steps: depth taps x 16-channel steps
 
     f32x16 acc[2][NREP];
 #pragma unroll
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split2d_kernel(S2Args a) {
         xoff[k] = (int)(((int64_t)cb * a.g.cs + a.g.sl + (int64_t)(r0 - 1 + row) * a.g.wp + (c0 - 1 + col)) * 8);
         loff[k] = cb * APL + row * AW + col;
     }
-    const uint4* wsrc0 = a.w + (int64_t)ty * nsub * WUNITS;
+    const uint4* wsrc0 = a.w + (int64_t)ty * a.ndz * nsub * WUNITS;
     const int64_t step_stride = (int64_t)2 * a.g.cs * 8;      // floats per 16-channel step
 
     // operand slots of this lane: A = weights (row l31 of m-tile, k half = channel block lhi),
@@ -217,8 +222,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split2d_kernel(S2Args a) {
         lds_w[768 + tid] = w3; lds_w[1024 + tid] = w4; lds_w[1280 + tid] = w5;
         lds_w[1536 + tid] = w6; lds_w[1792 + tid] = w7; lds_w[2048 + tid] = w8;
     };
-    auto ld = [&](int s, int rd, uint4& ua, uint4& ub) {
-        const float* p = a.x + (int64_t)s * step_stride + xoff[rd];
+    auto ld = [&](int k, int rd, uint4& ua, uint4& ub) {   // K step k = depth tap k / nstep, channel step k % nstep
+        const int dz = k / nstep, s = k - dz * nstep;
+        const float* p = a.x + (int64_t)s * step_stride + (int64_t)(dz - (a.ndz >> 1)) * a.dz_stride + xoff[rd];
         ua = ldu4(p);
         ub = ldu4(p + 4);
     };
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split2d_kernel(S2Args a) {
     putw();
     __syncthreads();
 
-    for (int s = 0; s < nstep; ++s) {
-        const bool more = s + 1 < nstep;
+    for (int s = 0; s < nk; ++s) {
+        const bool more = s + 1 < nk;
         if (more) {    // every load of the next step up front: a whole step of MFMAs to land in
             ldw(s + 1);
             ld(s + 1, 0, n0a, n0b); ld(s + 1, 1, n1a, n1b); ld(s + 1, 2, n2a, n2b);
@@ -270,8 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split2d_kernel(S2Args a) {
     for (int n = 0; n < NREP; ++n) {
         const int RR = r0 + prow[n], cc = c0 + pcol[n];
         if (RR >= a.rows || cc > a.g.w) continue;
-        const int rr = RR % a.g.hp;
-        const bool in = rr >= 1 && rr <= a.g.h;     // frame rows between images stay zero
+        const int img = RR / a.g.hp, rr = RR - img * a.g.hp;
+        bool in = rr >= 1 && rr <= a.g.h;           // frame rows between images stay zero
+        if (a.depth_s > 0) {                        // ... and so do the two padding slices of every volume
+            const int z = img % a.depth_s;
+            in = in && z >= 1 && z <= a.depth_s - 2;
+        }
         const int64_t opix = a.g.sl + (int64_t)RR * a.g.wp + cc;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -351,10 +361,8 @@ int dispatch_tile(const S2Args& a, int tc, int nrep, hipStream_t st) {
 
 }  // namespace
 
-// flags: bit 0 = x is pre-split, bit 1 = write y pre-split, bit 2 = relu; bits 8-9 = pixels per workgroup (0: chosen from the
-// grid size, 1: 128, 2: 256)
-extern "C" int dinv_conv3x3_split(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout,
-                                  void* y, const float* res1, int32_t flags, dinv_stream_t stream) {
+static int split_launch(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout, void* y,
+                        const float* res1, int32_t flags, int32_t depth, dinv_stream_t stream) {
     if (int e = check_geom(g)) return e;
     DINV_REQUIRE(x && w_split && y, "null tensor pointer");
     DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0,
@@ -363,11 +371,15 @@ extern "C" int dinv_conv3x3_split(const dinv_act_geom* g, const void* x, const v
     DINV_REQUIRE((flags & ~0x307) == 0 && ((flags >> 8) & 3) != 3, "unknown flags %d", flags);
     DINV_REQUIRE(!(relu && res1), "relu and residual are not combined in DRUNet");
     DINV_REQUIRE(!(out_split && res1), "a pre-split output carries no residual");
+    DINV_REQUIRE(depth == 0 || (depth >= 1 && g->batch % (depth + 2) == 0), "batch %d is not a stack of volumes of %d + 2 slices",
+                 g->batch, depth);
     // halo rows of the last row tile and the column overhang of a partial column tile must stay inside a channel block
-    DINV_REQUIRE(g->cs >= g->sl + g->np + (int64_t)34 * g->wp + 64, "channel-block stride too small for 2-D tiles (rebuild the geometry)");
+    DINV_REQUIRE(g->cs >= g->sl + g->np + (int64_t)34 * g->wp + 64 + (depth ? 2 * g->plane : 0),
+                 "channel-block stride too small for 2-D tiles (rebuild the geometry%s)", depth ? "; 3-D: one guard plane on each side" : "");
     DINV_REQUIRE(g->cs * 16 < ((int64_t)1 << 31), "activation row too long for 32-bit staging offsets");
     S2Args a{make_geom(*g), reinterpret_cast<const float*>(x), reinterpret_cast<const uint4*>(w_split),
-             reinterpret_cast<float*>(y), res1, cin, 0, cout / 64, 0, 0, g->batch * g->hp};
+             reinterpret_cast<float*>(y), res1, cin, 0, cout / 64, 0, 0, g->batch * g->hp,
+             depth ? 3 : 1, depth ? depth + 2 : 0, g->plane * 8};
     // tile width: the widest of 32 / 16 / 8 that divides the image width (DRUNet levels: 320 -> 32, 160 -> 32, 80 -> 16,
     // 40 -> 8); tiles of 128 pixels when 256-pixel tiles would leave the 512 resident workgroup slots under-filled
     const int tc = g->width % 32 == 0 ? 32 : (g->width % 16 == 0 ? 16 : 8);
@@ -386,4 +398,22 @@ extern "C" int dinv_conv3x3_split(const dinv_act_geom* g, const void* x, const v
     if (relu) return dispatch_tile<false, false, true, 0>(a, tc, nrep, st);
     if (res1) return dispatch_tile<false, false, false, 1>(a, tc, nrep, st);
     return dispatch_tile<false, false, false, 0>(a, tc, nrep, st);
+}
+
+// flags: bit 0 = x is pre-split, bit 1 = write y pre-split, bit 2 = relu; bits 8-9 = pixels per workgroup (0: chosen from the
+// grid size, 1: 128, 2: 256)
+extern "C" int dinv_conv3x3_split(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout,
+                                  void* y, const float* res1, int32_t flags, dinv_stream_t stream) {
+    return split_launch(g, x, w_split, cin, cout, y, res1, flags, 0, stream);
+}
+
+// 3x3x3 convolution of volumes stored as stacks of depth + 2 slices (g->batch = volumes x (depth + 2), a zero slice at each
+// end of every volume): ONE launch, the K loop runs over the three depth taps as well (tap dz reads the slices shifted by
+// dz - 1), the accumulators never leave the registers; the two padding slices of the output are written as zeros.  x must
+// have one plane of readable memory in front of its first slice and behind its last one (the tap views reach there).
+// w_split: [cout/64][dz 3][cin/16][dy 3][plane 2][dx 3][cblk 2][row 64][8] bf16 (pack_split3d_weight).
+extern "C" int dinv_conv3x3x3_split(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout,
+                                    void* y, const float* res1, int32_t flags, int32_t depth, dinv_stream_t stream) {
+    DINV_REQUIRE(depth >= 1, "bad depth %d", depth);
+    return split_launch(g, x, w_split, cin, cout, y, res1, flags, depth, stream);
 }

@@ -582,49 +582,6 @@ __global__ __launch_bounds__(256) void mri_coil_combine_kernel(const float2* __r
     }
 }
 
-// coil expansion as a streaming pass: t[b,n] = S[n] * x[b]; same blocking as the combine kernel
-template <int NC>
-__global__ __launch_bounds__(256) void mri_coil_expand_kernel(const float* __restrict__ x,
-                                                              const float2* __restrict__ maps,
-                                                              float2* __restrict__ t, int64_t vol, int batch, int ncoil,
-                                                              int maps_batch) {
-    const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t pix = quad * 4;
-    if (pix >= vol) return;
-    const int b0 = blockIdx.y * CB;
-    float2 sv[NC][4];
-    const bool shared_maps = maps_batch <= 1;
-    const bool cached = maps && shared_maps && ncoil <= NC;
-    if (cached) {
-#pragma unroll
-        for (int n = 0; n < NC; ++n)
-            if (n < ncoil) ld_c4(maps + (int64_t)n * vol + pix, sv[n]);
-    }
-    for (int bb = 0; bb < CB; ++bb) {
-        const int b = b0 + bb;
-        if (b >= batch) break;
-        const float* xre = x + ((int64_t)b * 2) * vol + pix;
-        const float4 re = ld_f4(xre), im = ld_f4(xre + vol);
-        const float2 xv[4] = {make_float2(re.x, im.x), make_float2(re.y, im.y), make_float2(re.z, im.z), make_float2(re.w, im.w)};
-        for (int n0 = 0; n0 < ncoil; n0 += NC) {
-#pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                if (n0 + n >= ncoil) break;
-                float2 o[4];
-                if (maps) {
-                    if (!cached) ld_c4(maps + ((int64_t)(shared_maps ? 0 : b) * ncoil + n0 + n) * vol + pix, sv[n]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = cmul(sv[n][e], xv[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = xv[e];
-                }
-                st_c4(t + ((int64_t)b * ncoil + n0 + n) * vol + pix, o);
-            }
-        }
-    }
-}
-
 template <int N>
 int launch_cols_expand_fwd(const float* x, const float2* maps, float2* t, int64_t B, int ncoil, int maps_batch, int64_t Q,
                            const void* table, float scale, hipStream_t s) {
@@ -754,9 +711,6 @@ inline int64_t volume(const dinv_mri_desc* d) {
     return v;
 }
 
-// TEMPORARY (round-3 A/B on hardware): 1 = the round-2 three-pass forms (streaming expand / combine + in-place column pass)
-int g_mri_variant = 0;
-
 }  // namespace
 
 extern "C" size_t dinv_mri_workspace_bytes(const dinv_mri_desc* d) {
@@ -786,20 +740,13 @@ extern "C" int dinv_mri_forward(const dinv_mri_desc* d, const float* x, const fl
         const int64_t N0 = d->dims[0], Q0 = vol / N0;
         const float sc0 = 1.0f / sqrtf((float)N0);
         int e = 0;
-        if (Q0 % 4 == 0 && N0 > 16 && g_mri_variant == 0) {
+        if (Q0 % 4 == 0 && N0 > 16) {
             // fused first pass: coil expansion + transform along the first axis, t written once
             switch (d->dims[0]) {
 #define DINV_CASE(NN) case NN: e = launch_cols_expand_fwd<NN>(x, mp, t, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s); break;
                 DINV_CASE(32) DINV_STATIC_SIZES(DINV_CASE)
 #undef DINV_CASE
             }
-        } else if (vol % 4 == 0 && N0 > 16) {
-            const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
-            hipLaunchKernelGGL((mri_coil_expand_kernel<8>), grid, dim3(256), 0, s, x, mp, t, vol, d->batch, d->coils,
-                               d->maps_batch);
-            DINV_CHECK_LAUNCH();
-            C2CIo fio{t, t, 0, 0};
-            e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s);
         } else {
             // short first axis (a 3-D volume's depth): single-stage transform straight from x and the maps
             ColsCoilLoadIo cio{x, mp, t, d->coils, d->maps_batch, 0, 0};
@@ -852,7 +799,11 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
         const float2* mp = reinterpret_cast<const float2*>(maps);
         const int64_t N0 = d->dims[0], Q0 = vol / N0;
         const float sc0 = 1.0f / sqrtf((float)N0);
-        if ((g_mri_variant == 1 || N0 > 320) && vol % 4 == 0 && N0 > 16) {   // 512: the fused kernel spills (444 B / lane)
+        if (vol % 4 == 0 && N0 > 16) {
+            // C2C pass along the first axis in place, then a wide streaming coil combination.  A fused form (one workgroup
+            // walking the coils of a column tile, next coil's loads in flight during the transform) was built in round 3 and
+            // measured 2x slower than these two passes (152 vs 44 + 27 us at cfg2): the serial coil loop leaves too few
+            // independent tiles in flight
             C2CIo fio{t, t, 0, 0};
             if (int e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 1, 1, sc0, s)) return e;
             const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
@@ -861,12 +812,8 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
             DINV_CHECK_LAUNCH();
             return 0;
         }
-        // fused last pass: inverse transform along the first axis + conj(S) + coil sum, t read once
-        switch (d->dims[0]) {
-#define DINV_CASE(NN) case NN: return launch_cols_combine_inv<NN>(t, mp, x, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s);
-            DINV_ALL_STATIC(DINV_CASE)
-#undef DINV_CASE
-        }
+        // short first axis (a 3-D volume's depth): single-stage inverse transform with the coil sum in its store phase
+        return launch_cols_combine_inv<16>(t, mp, x, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s);
     }
     const int64_t Na = d->dims[0];
     ColsPlanarMaskLoadIo cio{y, mask, t, d->coils, d->mask_batch, 0, 0};
@@ -910,18 +857,13 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
 // 2-D: 4 passes over t instead of the 10 of dinv_mri_forward + dinv_mri_adjoint (which also write and re-read y).
 static bool normal_ok(const dinv_mri_desc* d) {
     if (!all_static(d)) return false;
-    const int64_t vol = volume(d), N0 = d->dims[0], W = d->dims[d->ndim - 1];
-    bool wok = false;
-    switch ((int)W) {
-#define DINV_CASE(NN) case NN: wok = true; break;
+    switch (d->dims[d->ndim - 1]) {
+#define DINV_CASE(NN) case NN: return true;
         DINV_STATIC_SIZES(DINV_CASE)
 #undef DINV_CASE
-        default: break;
+        default: return false;
     }
-    return wok && N0 > 16 && (vol / N0) % 4 == 0;
 }
-
-extern "C" int dinv_mri_debug_variant(int v) { g_mri_variant = v; return 0; }
 
 extern "C" int dinv_mri_normal_supported(const dinv_mri_desc* d) { return d && validate(d) == 0 && normal_ok(d) ? 1 : 0; }
 
@@ -944,24 +886,23 @@ extern "C" int dinv_mri_normal(const dinv_mri_desc* d, const float* x, const flo
     const int64_t P = (int64_t)d->batch * d->coils;
     const float2* mp = reinterpret_cast<const float2*>(maps);
     const float scw = 1.0f / sqrtf((float)W);
-    const int64_t N0v = d->dims[0], Q0 = vol / N0v;
-    const float sc0 = 1.0f / sqrtf((float)N0v);
-    // fused expand + cols(first axis) -> (cols(H)) -> rows(W): F, M^2, F^H in one tile -> (cols(H)^-1) -> fused cols^-1 + combine
+    const int64_t N0 = d->dims[0], Q0 = vol / N0;
+    const float sc0 = 1.0f / sqrtf((float)N0);
+    // first pass (x, S -> t, transformed along the first axis) -> (cols(H)) -> rows(W): F, M^2, F^H in one tile ->
+    // (cols(H)^-1) -> cols(first axis)^-1 -> coil combination: the k-space tensor is never formed
     int e = 0;
     C2CIo fio{t, t, 0, 0};
-    const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
-    if (g_mri_variant == 1) {
-        hipLaunchKernelGGL((mri_coil_expand_kernel<8>), grid, dim3(256), 0, s, x, mp, t, vol, d->batch, d->coils, d->maps_batch);
-        DINV_CHECK_LAUNCH();
-        if ((e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s))) return e;
-    } else {
+    if (Q0 % 4 == 0 && N0 > 16) {
         switch (d->dims[0]) {
 #define DINV_CASE(NN) case NN: e = launch_cols_expand_fwd<NN>(x, mp, t, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s); break;
             DINV_CASE(32) DINV_STATIC_SIZES(DINV_CASE)
 #undef DINV_CASE
         }
-        if (e) return e;
+    } else {
+        ColsCoilLoadIo cio{x, mp, t, d->coils, d->maps_batch, 0, 0};
+        e = launch_cols(cio, P, Q0, d->plan[0], d->table[0], 0, 1, sc0, s, d->coils);
     }
+    if (e) return e;
     if (nd == 3)
         if ((e = launch_cols(fio, P * d->dims[0], W, d->plan[1], d->table[1], 0, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
     switch ((int)W) {
@@ -973,16 +914,12 @@ extern "C" int dinv_mri_normal(const dinv_mri_desc* d, const float* x, const flo
     if (e) return e;
     if (nd == 3)
         if ((e = launch_cols(fio, P * d->dims[0], W, d->plan[1], d->table[1], 1, 1, 1.0f / sqrtf((float)d->dims[1]), s))) return e;
-    if (g_mri_variant == 1 || N0v > 320) {
+    if (vol % 4 == 0 && N0 > 16) {
         if ((e = launch_cols(fio, P, Q0, d->plan[0], d->table[0], 1, 1, sc0, s))) return e;
+        const dim3 grid((unsigned)ceil_div(vol / 4, 256), (unsigned)ceil_div(d->batch, CB));
         hipLaunchKernelGGL((mri_coil_combine_kernel<8>), grid, dim3(256), 0, s, t, mp, out, vol, d->batch, d->coils, d->maps_batch);
         DINV_CHECK_LAUNCH();
         return 0;
     }
-    switch (d->dims[0]) {
-#define DINV_CASE(NN) case NN: return launch_cols_combine_inv<NN>(t, mp, out, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s);
-        DINV_ALL_STATIC(DINV_CASE)
-#undef DINV_CASE
-    }
-    return fail(2, "unreachable");
+    return launch_cols_combine_inv<16>(t, mp, out, d->batch, d->coils, d->maps_batch, Q0, d->table[0], sc0, s);
 }

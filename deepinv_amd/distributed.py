@@ -16,7 +16,10 @@ import torch.distributed as dist
 
 
 class BatchParallelContext:
-    def __init__(self, backend: str | None = None, device: torch.device | None = None):
+    def __init__(self, backend: str | None = None, device: torch.device | None = None, init_always: bool = False):
+        """init_always: create the process group and run the collectives even at world size 1 (exercises RCCL initialisation
+        and the collective code path on a single GPU; off by default: a single process needs no communicator)"""
+        self.init_always = bool(init_always)
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -28,7 +31,7 @@ class BatchParallelContext:
     def __enter__(self):
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
-        if self.world_size > 1 and not dist.is_initialized():
+        if (self.world_size > 1 or self.init_always) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             kw = {"device_id": self.device} if self.backend == "nccl" else {}
@@ -54,7 +57,7 @@ class BatchParallelContext:
 
     def all_gather_batch(self, x_local: torch.Tensor, n_total: int) -> torch.Tensor:
         """gather the per-rank slabs back into the full batch on every rank (one collective)"""
-        if self.world_size == 1:
+        if self.world_size == 1 and not (self.init_always and dist.is_initialized()):
             return x_local
         q, r = divmod(n_total, self.world_size)
         x_local = x_local.contiguous()

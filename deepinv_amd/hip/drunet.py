@@ -32,6 +32,7 @@ def _l():
         l.dinv_conv3x3_tail.argtypes = [G, vp, vp, vp, i32, i32, vp, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
+        l.dinv_conv3x3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_down2x2_bf16s.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2_bf16s.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
@@ -113,6 +114,12 @@ def pack_split2d_weight(w: torch.Tensor) -> torch.Tensor:
     return packed.index_select(6, idx).contiguous()
 
 
+def pack_split3d_weight(w5: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3,3] -> the per-depth-tap packs of pack_split2d_weight stacked behind the cout tile:
+    [Cout/64][dz 3][Cin/16][dy 3][plane 2][dx 3][cblk 2][row 64][ci 8] (bf16) for dinv_conv3x3x3_split"""
+    return torch.stack([pack_split2d_weight(w5[:, :, dz]) for dz in range(3)], dim=1).contiguous()
+
+
 def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
     """OIHW [Cout,Cin,3,3] -> U = G g G^T (fp64, rounded once) packed [Cout/64][Cin/8][ci 8][co 64][16];
     needs Cin % 16 == 0, Cin >= 32 and Cout % 64 == 0 (the ResBlock convs; the kernel pipelines channel blocks
@@ -159,6 +166,27 @@ def pack_up_weight(w: torch.Tensor) -> torch.Tensor:
     """ConvTranspose2d k2 s2 weight [Cin,Cout,2,2] -> [tap=dy*2+dx][Cin/8][Cout][8]"""
     cin, cout = w.shape[:2]
     return w.detach().float().permute(2, 3, 0, 1).reshape(4, cin // 8, 8, cout).permute(0, 1, 3, 2).contiguous()
+
+
+# Packed weights of the training / 3-D paths are cached per (source tensor storage, version): an unfolded network calls the
+# denoiser `max_iter` times per training step with the same weights and every layer needs a pack (a dozen small torch ops) per
+# call otherwise - more host time than the kernels take.  An entry keeps its source tensor alive, so the address cannot be
+# handed to another tensor while the entry exists; an in-place optimizer step bumps the version counter.
+_PACKS: dict = {}
+
+
+def cached_pack(kind, w, make, sub=0):
+    try:
+        ver = w._version
+    except RuntimeError:      # inference tensors carry no version counter
+        ver = -1
+    key = (kind, w.data_ptr(), ver, tuple(w.shape), sub)
+    hit = _PACKS.get(key)
+    if hit is None:
+        if len(_PACKS) > 4096:
+            _PACKS.clear()
+        hit = _PACKS[key] = (make(), w)
+    return hit[0]
 
 
 def pack_input(g, x, sigma, act):
@@ -249,6 +277,15 @@ def conv3x3_split(g, x, wsplit, cin, cout, y, res1=None, relu=False, x_presplit=
         e1.record()
         fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
         _prof.append((e0, e1, "conv3x3_split2d_kernel", fl, 3.0 * fl))
+
+
+def conv3x3x3_split(g, x, wsplit, cin, cout, y, depth, res1=None, relu=False, x_presplit=False, y_presplit=False):
+    """3x3x3 convolution of volumes stored as stacks of depth + 2 slices, one launch (depth taps inside the K loop of
+    csrc/drunet_split2d.hip); wsplit from pack_split3d_weight; x / y / res1 are views whose first plane is a volume's
+    leading zero slice, with one more readable plane on each side of x"""
+    flags = (1 if x_presplit else 0) | (2 if y_presplit else 0) | (4 if relu else 0)
+    check(_l().dinv_conv3x3x3_split(ctypes.byref(g), ptr(x), ptr(wsplit), cin, cout, ptr(y), ptr(res1), flags, int(depth),
+                                    stream_ptr(y.device)))
 
 
 def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):

@@ -207,7 +207,7 @@ def mri_normal(x, coil_maps=None, mask=None, coil_dim=True):
     needs_param_grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in (coil_maps, mask))
     if not needs_param_grad and ENABLE_FUSED_NORMAL:
         B, vol = x.shape[0], tuple(x.shape[2:])
-        if all(_static_ok(n) for n in vol) and vol[-1] >= 64:
+        if all(_static_ok(n) for n in vol) and vol[-1] >= 64 and vol[0] >= 16:
             return _MriNormal.apply(x, coil_maps, mask, bool(coil_dim))
     return mri_adjoint(mri_forward(x, coil_maps, mask, coil_dim), coil_maps, mask, coil_dim)
 

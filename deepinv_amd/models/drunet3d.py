@@ -20,7 +20,6 @@ The forward pass of the 3x3x3 convolutions runs on the fp32 matrix cores when gr
 as models/drunet_train.py: ReLU masks of an fp32 reference), on the bf16-split kernels otherwise."""
 from __future__ import annotations
 
-import os
 
 import torch
 
@@ -73,21 +72,36 @@ def _pad_w(w, d0, d1):
     return out
 
 
-def _conv2d(g, w, x, y, res1, fp32):
-    cout, cin = w.shape[:2]
-    if cin >= 16 and cout >= 16 and not fp32:
-        K.conv3x3_split(g, x, K.pack_split2d_weight(_pad_w(w, _r64(cout), _r16(cin))), _r16(cin), _r64(cout), y, res1=res1)
+def _cached(kind, w, dz, make):
+    return K.cached_pack(kind, w, make, sub=dz)
+
+
+def _conv2d(g, pk, x, y, res1):
+    kind, wpk, ci_p, co_p, cout = pk
+    if kind == "split":
+        K.conv3x3_split(g, x, wpk, ci_p, co_p, y, res1=res1)
     else:           # thin head / tail layers, and the mask-exact forward of the training path
-        wpk, ci_p, co_p = K.pack_conv3x3_weight(w)
         K.conv3x3(g, x, wpk, ci_p, co_p, y, cout_valid=cout, res1=res1)
 
 
-def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False) -> Vol:
-    """3x3x3 convolution, stride 1, zero padding 1, no bias; w5 [Cout, Cin, 3, 3, 3] (true channel counts)"""
-    y = Vol(lv, w5.shape[0], x.t.device)
+def _pack2d(w, fp32):
+    cout, cin = w.shape[:2]
+    if cin >= 16 and cout >= 16 and not fp32:
+        return ("split", K.pack_split2d_weight(_pad_w(w, _r64(cout), _r16(cin))), _r16(cin), _r64(cout), cout)
+    wpk, ci_p, co_p = K.pack_conv3x3_weight(w)
+    return ("direct", wpk, ci_p, co_p, cout)
+
+
+def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=False) -> Vol:
+    """3x3x3 convolution, stride 1, zero padding 1, no bias; w5 [Cout, Cin, 3, 3, 3] (true channel counts).
+    flip: convolve with the transposed, tap-reversed filter instead (the data gradient of the same layer)"""
+    cout = w5.shape[1] if flip else w5.shape[0]
+    y = Vol(lv, cout, x.t.device)
     for dz in range(3):
+        pk = _cached(("c3", flip, fp32), w5, dz,
+                     lambda dz=dz: _pack2d((_flip_t(w5) if flip else w5)[:, :, dz].contiguous(), fp32))
         r = (res.view() if res is not None else None) if dz == 0 else y.view()
-        _conv2d(lv.g, w5[:, :, dz].contiguous(), x.view(dz - 1), y.view(), r, fp32)
+        _conv2d(lv.g, pk, x.view(dz - 1), y.view(), r)
     y.zero_pads()
     if relu:
         K.relu_inplace(y.t)
@@ -100,8 +114,8 @@ def down(lvi, lvo, w5, x: Vol) -> Vol:
     y = Vol(lvo, cout, x.t.device)
     cop, cip = _r64(cout), _r16(cin)
     for dz in range(2):
-        K.down2x2_bf16s_3d(lvi.g, lvo.g, x.view(), K.pack_down_bf16s_weight(_pad_w(w5[:, :, dz], cop, cip)), cip, cop, y.view(),
-                           lvo.D, dz, dz > 0)
+        pk = _cached("down", w5, dz, lambda dz=dz: K.pack_down_bf16s_weight(_pad_w(w5[:, :, dz], cop, cip)))
+        K.down2x2_bf16s_3d(lvi.g, lvo.g, x.view(), pk, cip, cop, y.view(), lvo.D, dz, dz > 0)
     return y
 
 
@@ -111,7 +125,8 @@ def up(lvi, lvo, w5, x: Vol) -> Vol:
     y = Vol(lvo, cout, x.t.device)
     cip, cop = _r16(cin), _r64(cout)
     for dz in range(2):
-        K.up2x2_bf16s_3d(lvi.g, lvo.g, x.view(), K.pack_up_bf16s_weight(_pad_w(w5[:, :, dz], cip, cop)), cip, cop, y.view(), lvi.D, dz)
+        pk = _cached("up", w5, dz, lambda dz=dz: K.pack_up_bf16s_weight(_pad_w(w5[:, :, dz], cip, cop)))
+        K.up2x2_bf16s_3d(lvi.g, lvo.g, x.view(), pk, cip, cop, y.view(), lvi.D, dz)
     return y
 
 
@@ -212,11 +227,11 @@ class DRUNet3dFunction(torch.autograd.Function):
                 n1, n2 = f"{_blk(model, prefix, k)}.res.0.weight", f"{_blk(model, prefix, k)}.res.2.weight"
                 if want_w:
                     keep(n2, wgrad3(l, gout, a1, W[n2].shape[0], W[n2].shape[1]))
-                gt = conv3(l, _flip_t(W[n2]), gout)
+                gt = conv3(l, W[n2], gout, flip=True)
                 K.relu_backward(a1.t, gt.t)
                 if want_w:
                     keep(n1, wgrad3(l, gt, x_in, W[n1].shape[0], W[n1].shape[1]))
-                gout = conv3(l, _flip_t(W[n1]), gt, res=gout)
+                gout = conv3(l, W[n1], gt, res=gout, flip=True)
             return gout
 
         g2 = torch.nn.functional.pad(gy.contiguous().float().permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, 0, 1, 1))
@@ -226,7 +241,7 @@ class DRUNet3dFunction(torch.autograd.Function):
         wt = W["m_tail.weight"]
         if want_w:
             keep("m_tail.weight", wgrad3(lv[0], gy_act, saved["tail_in"], wt.shape[0], wt.shape[1]))
-        gcur = conv3(lv[0], _flip_t(wt), gy_act)
+        gcur = conv3(lv[0], wt, gy_act, flip=True)
         gskip = {0: gcur}
         for i, name in zip((0, 1, 2), ("m_up1", "m_up2", "m_up3")):
             gcur = res_back(lv[i], name, 1, gcur)
@@ -247,7 +262,7 @@ class DRUNet3dFunction(torch.autograd.Function):
             keep("m_head.weight", wgrad3(lv[0], gcur, saved["x_act"], wh.shape[0], wh.shape[1]))
         gx = None
         if ctx.needs_input_grad[1]:
-            gin = conv3(lv[0], _flip_t(wh), gcur)
+            gin = conv3(lv[0], wh, gcur, flip=True)
             g2 = torch.empty((B * (D + 2), C, H, Wd), device=dev, dtype=torch.float32)
             K.unpack_output(lv[0].g, gin.view(), C, g2)
             gx = g2.view(B, D + 2, C, H, Wd)[:, 1:-1].permute(0, 2, 1, 3, 4).contiguous()

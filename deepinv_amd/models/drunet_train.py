@@ -24,7 +24,6 @@ fp32 matrix cores by default (direct kernels, 3e-7 per layer: the masks are thos
 The backward pass always uses the bf16-split kernels for the data gradients (no ReLU decision depends on them)."""
 from __future__ import annotations
 
-import os
 
 import torch
 
@@ -67,14 +66,18 @@ def _fp32_forward(model) -> bool:
     return v == "fp32"
 
 
-def _conv3(g, w, x, relu=False, res1=None, fp32=False):
-    """y = [relu](conv3x3(x, w)) (+ res1) on activation buffers; bf16-split kernel where the shapes allow it"""
-    cout, cin = w.shape[:2]
+def _conv3(g, w, x, relu=False, res1=None, fp32=False, flip=False):
+    """y = [relu](conv3x3(x, w)) (+ res1) on activation buffers; bf16-split kernel where the shapes allow it.
+    flip: convolve with the transposed, tap-reversed filter (the data gradient of the same layer); packs are cached per
+    weight tensor and version (hip/drunet.py: cached_pack)"""
+    cout, cin = (w.shape[1], w.shape[0]) if flip else w.shape[:2]
     y = K.alloc(g, cout, x.device)
+    src = lambda: _flip_t(w) if flip else w  # noqa: E731
     if cout % 64 == 0 and cin % 16 == 0 and not fp32:
-        K.conv3x3_split(g, x, K.pack_split2d_weight(w), cin, cout, y, res1=res1, relu=relu)
+        K.conv3x3_split(g, x, K.cached_pack(("c3s", flip), w, lambda: K.pack_split2d_weight(src())), cin, cout, y, res1=res1,
+                        relu=relu)
     else:
-        wpk, ci_p, co_p = K.pack_conv3x3_weight(w)
+        wpk, ci_p, co_p = K.cached_pack(("c3d", flip), w, lambda: K.pack_conv3x3_weight(src()))
         K.conv3x3(g, x, wpk, ci_p, co_p, y, cout_valid=cout, res1=res1, relu=relu)
     return y
 
@@ -84,9 +87,9 @@ def _down(gi, go, w, x, fp32=False):
     cout, cin = w.shape[:2]
     y = K.alloc(go, cout, x.device)
     if cin % 16 == 0 and not fp32:
-        K.down2x2_bf16s(gi, go, x, K.pack_down_bf16s_weight(w), cin, cout, y)
+        K.down2x2_bf16s(gi, go, x, K.cached_pack("dns", w, lambda: K.pack_down_bf16s_weight(w)), cin, cout, y)
     else:
-        K.down2x2(gi, go, x, K.pack_down_weight(w), cin, cout, y)
+        K.down2x2(gi, go, x, K.cached_pack("dnd", w, lambda: K.pack_down_weight(w)), cin, cout, y)
     return y
 
 
@@ -95,9 +98,9 @@ def _up(gi, go, w, x, fp32=False):
     cin, cout = w.shape[:2]
     y = K.alloc(go, cout, x.device)
     if cin % 16 == 0 and not fp32:
-        K.up2x2_bf16s(gi, go, x, None, K.pack_up_bf16s_weight(w), cin, cout, y)
+        K.up2x2_bf16s(gi, go, x, None, K.cached_pack("ups", w, lambda: K.pack_up_bf16s_weight(w)), cin, cout, y)
     else:
-        K.up2x2(gi, go, x, None, K.pack_up_weight(w), cin, cout, y)
+        K.up2x2(gi, go, x, None, K.cached_pack("upd", w, lambda: K.pack_up_weight(w)), cin, cout, y)
     return y
 
 
@@ -181,17 +184,17 @@ class DRUNetFunction(torch.autograd.Function):
                 x_in, a1 = saved["res"][f"{prefix}.{k}"]
                 w1, w2 = W[f"{_blk(model, prefix, k)}.res.0.weight"], W[f"{_blk(model, prefix, k)}.res.2.weight"]
                 wgrad(f"{_blk(model, prefix, k)}.res.2.weight", gl, gl, gout, a1, 9)
-                gt = _conv3(gl, _flip_t(w2), gout)
+                gt = _conv3(gl, w2, gout, flip=True)
                 K.relu_backward(a1, gt)
                 wgrad(f"{_blk(model, prefix, k)}.res.0.weight", gl, gl, gt, x_in, 9)
-                gout = _conv3(gl, _flip_t(w1), gt, res1=gout)
+                gout = _conv3(gl, w1, gt, res1=gout, flip=True)
             return gout
 
         gy = gy.contiguous().float()
         gy_act = K.alloc(g[0], model.out_channels, dev)
         K.pack_input(g[0], gy, 0.0, gy_act)
         wgrad("m_tail.weight", g[0], g[0], gy_act, saved["tail_in"], 9)
-        gcur = _conv3(g[0], _flip_t(W["m_tail.weight"]), gy_act)
+        gcur = _conv3(g[0], W["m_tail.weight"], gy_act, flip=True)
         gskip = {0: gcur}                     # s0 = u0 + x1
         for i, name in zip((0, 1, 2), ("m_up1", "m_up2", "m_up3")):
             gcur = res_back(g[i], name, 1, gcur)
@@ -208,7 +211,7 @@ class DRUNetFunction(torch.autograd.Function):
         wgrad("m_head.weight", g[0], g[0], gcur, saved["x_act"], 9)
         gx = None
         if ctx.needs_input_grad[1]:
-            gin_act = _conv3(g[0], _flip_t(W["m_head.weight"]), gcur)
+            gin_act = _conv3(g[0], W["m_head.weight"], gcur, flip=True)
             B, H, Wd = g[0].batch, g[0].height, g[0].width
             gx = torch.empty((B, ctx.in_channels, H, Wd), device=dev, dtype=torch.float32)
             K.unpack_output(g[0], gin_act, ctx.in_channels, gx)

@@ -173,6 +173,13 @@ int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w
  * The geometry must come from dinv_act_geom_init of this library version (trailing slack for the halo rows of the last tile). */
 int dinv_conv3x3_split(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout, void* y,
                        const float* res1, int32_t flags, dinv_stream_t stream);
+/* 3x3x3 convolution (nn.Conv3d in DRUNet(dim=3), drunet.py:39-263) of volumes stored as stacks of depth + 2 slices
+ * (g->batch = volumes x (depth + 2), one zero slice at each end of a volume) in ONE launch: the K loop of
+ * dinv_conv3x3_split also runs over the three depth taps (tap dz reads the slices shifted by dz - 1), the padding slices of
+ * y are written as zeros.  x needs one readable plane in front of its first and behind its last slice; same flags.
+ * w_split: [cout/64][dz 3][cin/16][dy 3][plane 2][dx 3][cblk 2][row 64][8] bf16 (hip/drunet.py: pack_split3d_weight). */
+int dinv_conv3x3x3_split(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout, void* y,
+                         const float* res1, int32_t flags, int32_t depth, dinv_stream_t stream);
 
 /* 2x2 stride-2 convolution (downsample_strideconv, drunet.py:524-552) on the bf16 matrix cores with the same exact
  * two-part operand split; w_split: [tap = dy*2+dx][Cin/16][plane hi/lo][cblk 2][Cout][ci 8] bf16.  Same operator as
@@ -291,7 +298,9 @@ typedef struct {
 } dinv_radon_plan;
 size_t dinv_radon_plan_bytes(const dinv_radon_desc* d);
 /* cs_host:[A][2] fp32 (cos,sin) as uploaded to the device; host_blob: dinv_radon_plan_bytes(d) bytes, to be
- * copied to the device unchanged */
+ * copied to the device unchanged.  plan->kw on ENTRY: 0 = choose the angles per workgroup (the largest of 8, 4, 2, 1
+ * whose widest window fits 128 columns), 1 / 2 / 4 / 8 = force that count; every other field is output.
+ * win_w (the LDS pitch) is a multiple of 16 so that a window cell's bank slot is its column modulo 16. */
 int dinv_radon_plan_init(const dinv_radon_desc* d, const float* cs_host, dinv_radon_plan* plan, void* host_blob);
 size_t dinv_radon_tiled_workspace_bytes(const dinv_radon_desc* d, int32_t adjoint);
 /* norm_dev: optional device scalar; when non-NULL the result is DIVIDED by it (tomography.py:253-254: the

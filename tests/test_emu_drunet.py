@@ -347,6 +347,59 @@ def test_relu_inplace():
     assert torch.equal(x, ref)
 
 
+@pytest.mark.parametrize("mode", ["plain", "relu_split_chain"])
+def test_conv3x3x3_single_launch(mode):
+    """dinv_conv3x3x3_split: the three depth taps inside the K loop of the 2-D-tile kernel, padding slices written as zeros;
+    `relu_split_chain`: conv1 (ReLU, pre-split output) feeding conv2 (pre-split input + fp32 residual) like a 3-D ResBlock,
+    against conv3d in fp64"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_split3d_weight
+    B, C, D, H, W, cout = 2, 16, 3, 6, 16, 64
+    gen = torch.Generator().manual_seed(19)
+    x = torch.randn(B, C, D, H, W, generator=gen)
+    w1 = torch.randn(cout, C, 3, 3, 3, generator=gen) / (27 * C) ** 0.5
+    w2 = torch.randn(cout, cout, 3, 3, 3, generator=gen) / (27 * cout) ** 0.5
+    g = geom(B * (D + 2), H, W)
+    guard = g.plane
+    g.cs = (g.cs + 2 * guard + 3) // 4 * 4
+
+    def to_vol(t):
+        c = t.shape[1]
+        a = torch.zeros(c // 8, g.cs, 8)
+        t2 = torch.nn.functional.pad(t.permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, 0, 1, 1)).reshape(B * (D + 2), c, H, W)
+        fr = a[:, guard + g.sl: guard + g.sl + g.np].view(-1, B * (D + 2), g.hp, g.wp, 8)
+        fr[:, :, 1:H + 1, 1:W + 1] = t2.reshape(B * (D + 2), -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    def from_vol(a, c):
+        out = a[:, guard + g.sl: guard + g.sl + g.np].view(-1, B, D + 2, g.hp, g.wp, 8)
+        assert float(out[:, :, 0].abs().max()) == 0 and float(out[:, :, D + 1].abs().max()) == 0     # padding slices
+        return out[:, :, 1:-1, 1:H + 1, 1:W + 1].permute(1, 0, 5, 2, 3, 4).reshape(B, c, D, H, W)
+
+    l = E.lib()
+    xa = to_vol(x)
+    view = lambda a: ctypes.c_void_p(a[:, guard:].data_ptr())
+    p1, p2 = pack_split3d_weight(w1), pack_split3d_weight(w2)
+    if mode == "plain":
+        ya = torch.full((cout // 8, g.cs, 8), 7.0)      # stale values in the padding slices must be overwritten
+        ya[:, :guard + g.sl] = 0
+        ya[:, guard + g.sl + g.np:] = 0
+        fr = ya[:, guard + g.sl: guard + g.sl + g.np].view(-1, B * (D + 2), g.hp, g.wp, 8)
+        fr[:, :, :, 0] = 0
+        fr[:, :, :, W + 1:] = 0
+        E.check(l.dinv_conv3x3x3_split(ctypes.byref(g), view(xa), ctypes.c_void_p(p1.data_ptr()), C, cout, view(ya), None, 0, D, None))
+        ref = torch.nn.functional.conv3d(x.double(), w1.double(), padding=1)
+        assert float((from_vol(ya, cout).double() - ref).norm() / ref.norm()) < 2e-5
+        return
+    ta, ya, ra = torch.zeros(cout // 8, g.cs, 8), torch.zeros(cout // 8, g.cs, 8), to_vol(torch.randn(B, cout, D, H, W, generator=gen))
+    E.check(l.dinv_conv3x3x3_split(ctypes.byref(g), view(xa), ctypes.c_void_p(p1.data_ptr()), C, cout, view(ta), None, 2 | 4, D, None))
+    E.check(l.dinv_conv3x3x3_split(ctypes.byref(g), view(ta), ctypes.c_void_p(p2.data_ptr()), cout, cout, view(ya), view(ra), 1, D, None))
+    t_ref = torch.nn.functional.conv3d(x.double(), w1.double(), padding=1).relu()
+    ref = torch.nn.functional.conv3d(t_ref, w2.double(), padding=1) + from_vol(ra, cout).double()
+    assert float((from_vol(ya, cout).double() - ref).norm() / ref.norm()) < 3e-5
+
+
 def test_conv3x3x3_as_three_shifted_2d_launches():
     """the composition models/drunet3d.py uses for a 3x3x3 convolution: three launches of the bf16-split 3x3 kernel on
     views of the input shifted by -1 / 0 / +1 slices (one guard plane in front of the buffer), accumulated IN PLACE

@@ -266,3 +266,33 @@ def test_early_stop_is_decided_on_the_device(dev):
     never = build(0.0)
     full = never(y, phys)
     assert not never.has_converged and torch.isfinite(full).all()
+
+
+def test_rccl_collectives_on_one_gpu(dev):
+    """RCCL initialisation and the collectives of the multi-GPU path on ONE GPU (world size 1 through backend "nccl"):
+    the all-gather of the reconstructions (bench.py's collective) and the all-reduce of coil-parallel MultiCoilMRI"""
+    import socket
+
+    import deepinv_amd as dinv
+    from deepinv_amd.distributed import BatchParallelContext, coil_parallel_mri
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    g = torch.Generator().manual_seed(12)
+    H = W = 64
+    x = torch.rand(3, 2, H, W, generator=g).to(dev)
+    maps = (torch.randn(1, 4, H, W, dtype=torch.complex64, generator=g) / 2).to(dev)
+    mask = dinv.utils.radial_mask(H, W, 16).to(dev)
+    with BatchParallelContext(backend="nccl", init_always=True) as ctx:
+        assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+        out = ctx.all_gather_batch(x, 3)                  # all_gather_into_tensor on the RCCL communicator
+        assert out.data_ptr() != x.data_ptr() and torch.equal(out, x)
+        phys = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, H, W), device=dev)
+        cp = coil_parallel_mri(ctx, mask, maps, (2, H, W))
+        t = cp.A_adjoint_A(x)
+        torch.distributed.all_reduce(t)                    # the reduction the N > 1 run issues
+        assert rel_err(t, phys.A_adjoint_A(x)) < 1e-6
+    assert not torch.distributed.is_initialized()

@@ -2,6 +2,8 @@
 the loop, parameter schedules, CG / least squares, unfolded trainable parameters.
 Mirrors reference tests: optim/optimizers.py:179-218 doctest, test_optim.py:373-465 (optimality
 condition), :1131-1180 (least-squares solvers)."""
+import os
+
 import pytest
 import torch
 
@@ -337,3 +339,60 @@ def test_overlap_tiling_edge_cases():
     import pytest
     with pytest.raises(ValueError):
         OverlapTiling((1, 1, 32, 32), patch_size=(16, 16, 16), overlap=2, tiling_dims=(-2, -1))
+
+
+def test_trainer_loop_host():
+    """deepinv_amd.Trainer's call sequence on CPU tensors with a toy linear physics (no kernels involved): two epochs of SGD
+    on a least-squares 'network' reproduce the hand-written update, the scheduler steps once per epoch, checkpoints load"""
+    import tempfile
+
+    import deepinv_amd as dinv
+
+    torch.manual_seed(0)
+    M = torch.randn(6, 4)
+
+    class P(dinv.physics.LinearPhysics):
+        def A(self, x, **k):
+            return x @ M.T
+
+        def A_adjoint(self, y, **k):
+            return y @ M
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor(0.05))
+
+        def forward(self, y, physics, **k):
+            return self.w * physics.A_adjoint(y)
+
+    x = torch.randn(8, 4)
+    y = x @ M.T
+    data = [(x[i], y[i]) for i in range(8)]
+    loader = torch.utils.data.DataLoader(data, batch_size=4, shuffle=False)
+    net = Net()
+    opt = torch.optim.SGD(net.parameters(), lr=0.01)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    with tempfile.TemporaryDirectory() as tmp:
+        tr = dinv.Trainer(model=net, physics=P(), optimizer=opt, train_dataloader=loader, epochs=2, device="cpu", verbose=False,
+                          scheduler=sched, save_path=tmp, eval_dataloader=loader)
+        tr.train()
+        w, lr = torch.tensor(0.05), 0.01
+        for epoch in range(2):
+            for i in range(2):
+                xb, yb = x[4 * i:4 * i + 4], y[4 * i:4 * i + 4]
+                aty = yb @ M
+                grad = (2 * (w * aty - xb) * aty).mean()
+                w = w - lr * grad
+            lr *= 0.5
+        assert abs(float(net.w) - float(w)) < 1e-6
+        assert len(tr.train_loss_history) == 2 and len(tr.eval_metric_history) == 2
+        net2 = Net()
+        tr2 = dinv.Trainer(model=net2, physics=P(), optimizer=torch.optim.SGD(net2.parameters(), lr=0.01), train_dataloader=loader,
+                           epochs=2, device="cpu", verbose=False, ckpt_pretrained=os.path.join(tmp, "ckp_1.pth.tar"))
+        tr2.setup_train()
+        assert abs(float(net2.w) - float(net.w)) < 1e-7 and tr2.epoch_start == 2
+    with pytest.raises(ValueError, match="tuple"):
+        bad = dinv.Trainer(model=net, physics=P(), optimizer=opt, train_dataloader=torch.utils.data.DataLoader(list(x), batch_size=4),
+                           epochs=1, device="cpu", verbose=False)
+        bad.train()
