@@ -266,7 +266,15 @@ def other_config_ops(dinv, device, op_row, ops_last):
     op_row("Tomography.A_adjoint", "cfg3", B, lambda: phys.A_adjoint(y), alg, n=5, Gsamples_per_s=smp / 1e9,
            lds_model_TB_per_s=smp * 16 / 1e12)
     op_row("Tomography.fbp", "cfg3", B, lambda: phys.A_dagger(y, fbp=True), alg + 2 * B * G * A * 4, n=5)
-    del phys, x, y
+    del phys, y
+    # the same geometry with fan-beam rays (first-generation gather kernels: stated, not tuned)
+    fphys = dinv.physics.Tomography(angles=A, img_width=W, circle=False, normalize=False, fan_beam=True, device=device)
+    fy = fphys.A(x)
+    fsmp = float(B) * fy.shape[2] * G * A       # detector pixels x march steps x angles
+    falg = B * (W * W + fy.shape[2] * A) * 4
+    op_row("Tomography(fan_beam).A", "cfg3-geometry", B, lambda: fphys.A(x), falg, n=3, Gsamples_per_s=fsmp / 1e9)
+    op_row("Tomography(fan_beam).A_adjoint", "cfg3-geometry", B, lambda: fphys.A_adjoint(fy), falg, n=3, Gsamples_per_s=fsmp / 1e9)
+    del fphys, fy, x
     # cfg4: 3-D MultiCoilMRI 12 coils 16x256x256, 2 volumes per GPU
     B, coils, vol = 2, 12, (16, 256, 256)
     nv = vol[0] * vol[1] * vol[2]

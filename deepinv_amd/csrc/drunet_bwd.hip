@@ -108,6 +108,72 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// The same reduction for THIN layers (M <= 16 and N <= 16: the 16-channel level of BASELINE config 4's 3-D DRUNet, which holds
+// most of its voxels): v_mfma_f32_16x16x4_f32 - a 16 x 16 (m, n) tile, K = 4 pixels per instruction (lane quarter k takes
+// pixel k), 32 cycles instead of the 64 a 32 x 32 x 2 instruction spends on a tile that would be three quarters padding:
+// 4x fewer matrix-pipe cycles per pixel (the 32 x 32 form was pipe-bound there: 9 taps x 64 cycles per 2 pixels).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int T, bool STRIDE2>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wv;           // one (m, n) tile: the unit is the pixel slice
+    if (unit >= a.nsplit) return;
+    const int split = (int)unit;
+    const bool mv = l15 < a.cs_alloc, nv = l15 < a.cl_alloc;     // lanes beyond the allocated channels feed zeros
+    const float* sp = a.s + ((int64_t)(mv ? l15 / 8 : 0) * a.gs.cs + a.gs.sl) * 8 + (mv ? l15 % 8 : 0);
+    const float* lp = a.l + ((int64_t)(nv ? l15 / 8 : 0) * a.gl.cs + a.gl.sl) * 8 + (nv ? l15 % 8 : 0);
+    int64_t off[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        off[t] = STRIDE2 ? ((int64_t)(t >> 1) * a.gl.wp + (t & 1)) * 8 : ((int64_t)(t / 3 - 1) * a.gl.wp + (t % 3 - 1)) * 8;
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t pbeg = (int64_t)split * a.per_split;
+    const int64_t pend = min(pbeg + a.per_split, a.gs.np);
+    constexpr int U = 4;      // k-steps (4 pixels each) whose loads are issued before the first MFMA of the iteration
+    for (int64_t p4 = pbeg; p4 < pend; p4 += 4 * U) {
+        float sv[U], lv[U][T];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p4 + 4 * u + lq;
+            const bool pv = p < pend;
+            int64_t q = pv ? p : 0;
+            if (STRIDE2) {
+                q = 0;
+                if (pv) {
+                    const int64_t b = p / a.gs.plane;
+                    const int pi = (int)(p - b * a.gs.plane);
+                    const int r = pi / a.gs.wp, c = pi - r * a.gs.wp;
+                    const int64_t bl = depth_pair(a.dm, b);
+                    if (bl >= 0 && r >= 1 && r <= a.gs.h && c >= 1 && c <= a.gs.w)
+                        q = bl * a.gl.plane + (int64_t)(2 * (r - 1) + 1) * a.gl.wp + (2 * (c - 1) + 1);
+                }
+            }
+            sv[u] = (pv && mv) ? sp[p * 8] : 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) lv[u][t] = (pv && nv) ? lp[q * 8 + off[t]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], lv[u][t], acc[t], 0, 0, 0);
+    }
+    // D[i][j]: j = lane & 15 (column n), i = 4 (lane >> 4) + reg (row m)
+    float* out = a.part + (int64_t)split * a.M * a.N * T;
+    if (l15 < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * lq + r;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int t = 0; t < T; ++t) out[((int64_t)m * a.N + l15) * T + t] = acc[t][r];
+        }
+    }
+}
+
 // dw[e] (+)= sum over slices in a fixed order: 16 lanes share an element (lane j adds slices j, j + 16, ... in order,
 // then the 16 partial sums are added in lane order), 16 elements per workgroup
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int nsplit, int accumulate,
@@ -189,12 +255,15 @@ static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const 
     a.cs_alloc = (m + 7) / 8 * 8; a.cl_alloc = (n + 7) / 8 * 8;
     a.mt = (m + 31) / 32; a.nt = (n + 31) / 32;
     a.nsplit = split_count(gs, a.mt, a.nt);
-    a.per_split = (ceil_div(gs->np, a.nsplit) + 7) / 8 * 8;     // whole iterations of 4 k-steps
+    a.per_split = (ceil_div(gs->np, a.nsplit) + 15) / 16 * 16;   // whole iterations of 4 k-steps (of 2 or 4 pixels)
     a.dm = dm;
     const int64_t units = (int64_t)a.mt * a.nt * a.nsplit;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)ceil_div(units, 4)), block(256);
-    if (taps == 9) hipLaunchKernelGGL((wgrad_kernel<9, false>), grid, block, 0, st, a);
+    if (m <= 16 && n <= 16) {      // thin layer: 16 x 16 x 4 instruction (mt = nt = 1: one unit per pixel slice)
+        if (taps == 9) hipLaunchKernelGGL((wgrad_thin_kernel<9, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wgrad_thin_kernel<4, true>), grid, block, 0, st, a);
+    } else if (taps == 9) hipLaunchKernelGGL((wgrad_kernel<9, false>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<4, true>), grid, block, 0, st, a);
     DINV_CHECK_LAUNCH();
     const int64_t ne = (int64_t)m * n * taps;

@@ -92,11 +92,20 @@ def _pack2d(w, fp32):
     return ("direct", wpk, ci_p, co_p, cout)
 
 
-def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=False) -> Vol:
+def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=False, x_presplit=False,
+          y_presplit=False) -> Vol:
     """3x3x3 convolution, stride 1, zero padding 1, no bias; w5 [Cout, Cin, 3, 3, 3] (true channel counts).
-    flip: convolve with the transposed, tap-reversed filter instead (the data gradient of the same layer)"""
-    cout = w5.shape[1] if flip else w5.shape[0]
+    flip: convolve with the transposed, tap-reversed filter instead (the data gradient of the same layer).
+    bf16-split arithmetic: ONE launch (the depth taps are part of the kernel's K loop, ReLU and the zero padding slices
+    in its epilogue); fp32 arithmetic (thin head / tail layers, mask-exact training forward): three accumulated launches"""
+    cout, cin = (w5.shape[1], w5.shape[0]) if flip else w5.shape[:2]
     y = Vol(lv, cout, x.t.device)
+    if cin >= 16 and cout >= 16 and not fp32:
+        pk = _cached(("c3x3", flip), w5, 0, lambda: K.pack_split3d_weight(_pad_w(_flip_t(w5) if flip else w5, _r64(cout), _r16(cin))))
+        K.conv3x3x3_split(lv.g, x.view(), pk, _r16(cin), _r64(cout), y.view(), lv.D, res1=res.view() if res is not None else None,
+                          relu=relu, x_presplit=x_presplit, y_presplit=y_presplit)
+        return y
+    assert not (x_presplit or y_presplit)
     for dz in range(3):
         pk = _cached(("c3", flip, fp32), w5, dz,
                      lambda dz=dz: _pack2d((_flip_t(w5) if flip else w5)[:, :, dz].contiguous(), fp32))
@@ -177,8 +186,12 @@ class DRUNet3dFunction(torch.autograd.Function):
 
         def res_chain(l, prefix, first, cur):
             for k in range(first, first + nb):
-                a1 = conv3(l, W[f"{_blk(model, prefix, k)}.res.0.weight"], cur, relu=True, fp32=f32)
-                out = conv3(l, W[f"{_blk(model, prefix, k)}.res.2.weight"], a1, res=cur, fp32=f32)
+                w1, w2 = W[f"{_blk(model, prefix, k)}.res.0.weight"], W[f"{_blk(model, prefix, k)}.res.2.weight"]
+                # inference: the ReLU temporary travels pre-split (consumed only by the second convolution); training keeps
+                # it in fp32 (the backward pass reads its sign)
+                ps = (not train) and min(w1.shape[0], w1.shape[1], w2.shape[0], w2.shape[1]) >= 16
+                a1 = conv3(l, w1, cur, relu=True, fp32=f32, y_presplit=ps)
+                out = conv3(l, w2, a1, res=cur, fp32=f32, x_presplit=ps)
                 if train:
                     saved["res"][f"{prefix}.{k}"] = (cur, a1)
                 cur = out

@@ -294,3 +294,26 @@ inline emu_f32x16 emu_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c) {
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32(a, b, c)
+// f32 16x16x4: lane l holds A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D element r of lane l is row 4(l>>4) + r, column l&15
+inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c) {
+    uint64_t mine[1];
+    float ab[2] = {a, b};
+    std::memcpy(mine, ab, 8);
+    uint64_t* buf = emu::wave_exchange_begin(mine, 1);
+    const int l = emu::lane(), j = l & 15;
+    emu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = d[r];
+        for (int k = 0; k < 4; ++k) {
+            float pa[2], pb[2];
+            std::memcpy(pa, &buf[(size_t)(i + 16 * k) * 64], 8);
+            std::memcpy(pb, &buf[(size_t)(j + 16 * k) * 64], 8);
+            acc = std::fmaf(pa[0], pb[1], acc);
+        }
+        d[r] = acc;
+    }
+    emu::wave_exchange_end();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32(a, b, c)

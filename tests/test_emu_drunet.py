@@ -223,7 +223,8 @@ def _wgrad(gs, gl, s, m, l, n, taps):
     return dw
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 9, 14, 16, 64), (1, 12, 8, 3, 64), (3, 8, 8, 64, 2), (1, 20, 33, 40, 24)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 9, 14, 16, 64), (1, 12, 8, 3, 64), (3, 8, 8, 64, 2), (1, 20, 33, 40, 24),
+                                            (2, 9, 14, 16, 16), (1, 7, 5, 3, 16), (2, 6, 6, 16, 2)])   # last three: thin-layer (16x16x4) kernel
 def test_wgrad_3x3_matches_autograd(B, H, W, cin, cout):
     """dW of a 3x3 convolution (csrc/drunet_bwd.hip on the host emulation) vs torch autograd in fp64"""
     gen = torch.Generator().manual_seed(cin * cout + H)
@@ -237,7 +238,8 @@ def test_wgrad_3x3_matches_autograd(B, H, W, cin, cout):
     assert float((dw.double() - w.grad).norm() / w.grad.norm()) < 1e-5
 
 
-@pytest.mark.parametrize("B,H,W,cs,cl,up", [(2, 6, 8, 64, 16, False), (1, 5, 4, 32, 128, True), (2, 8, 8, 24, 40, False)])
+@pytest.mark.parametrize("B,H,W,cs,cl,up", [(2, 6, 8, 64, 16, False), (1, 5, 4, 32, 128, True), (2, 8, 8, 24, 40, False),
+                                              (2, 6, 8, 16, 16, False), (1, 5, 4, 16, 8, True)])
 def test_wgrad_2x2_matches_autograd(B, H, W, cs, cl, up):
     """dW of the 2x2 stride-2 convolution (S = dL/dy on the half grid) and of the transposed one (S = x on the half grid)"""
     gen = torch.Generator().manual_seed(cs + cl)
