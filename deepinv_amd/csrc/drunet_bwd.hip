@@ -29,147 +29,134 @@ struct WgradArgs {
     Geom gs, gl;          // geometry of S and of L (equal for the 3x3 case)
     const float* s;       // [cs_alloc/8][gs.cs][8]
     const float* l;       // [cl_alloc/8][gl.cs][8]
-    float* part;          // [nsplit][M][N][T]
+    float* part;          // [nparts][M][N][T]
     int32_t M, N;         // logical channel counts (rows / columns of dW)
     int32_t cs_alloc, cl_alloc;   // allocated channels (multiples of 8) of S and L
-    int32_t mt, nt;       // 32-wide tiles
-    int32_t nsplit;
-    int64_t per_split;    // pixels per slice (even)
+    int32_t mt, nt;       // tiles (32 wide; 16 wide for the thin-layer kernel, where mt = nt = 1)
+    int32_t nparts;       // pixel slices per tile = workgroups per tile (each of the 4 waves takes a quarter of the slice)
+    int64_t per_wave;     // pixels per wave (a multiple of 16)
     DepthMap dm;          // 3-D stride-2 layers: image of S (half grid) -> image of L (full grid)
 };
 
-template <int T, bool STRIDE2>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int TILE> struct WgAcc { typedef f32x16 type; };
+template <> struct WgAcc<16> { typedef f32x4 type; };
+
+constexpr int WG_U = 4;   // k-steps per loop iteration: all their operand loads are in flight together
+
+// operands of WG_U k-steps starting at pixel p0 (PX pixels per k-step, lane part lk takes pixel lk of each).  The loads
+// are unconditional and nothing looks at a loaded value before the MFMAs (a predicated load, or a select on its result,
+// makes the compiler wait for it in the middle of the batch): pixels past the end of the slice read pixel 0 - the corner
+// of the first frame, where S is zero like on every frame pixel.  Lanes of channels beyond the allocation read channel
+// 0; their rows / columns of the tile are never written.
+template <int T, bool STRIDE2, int PX>
+__device__ __forceinline__ void wg_load(const WgradArgs& a, const float* sp, const float* lp, const int64_t (&off)[T],
+                                        int64_t p0, int64_t pend, int lk, float (&sv)[WG_U], float (&lv)[WG_U][T]) {
+#pragma unroll
+    for (int u = 0; u < WG_U; ++u) {
+        const int64_t pp = p0 + PX * u + lk;
+        const int64_t p = pp < pend ? pp : 0;
+        int64_t q = p;                                   // pixel of L that tap (0,0) of pixel p reads
+        if (STRIDE2) {                                   // 32-bit index arithmetic (np < 2^31 is checked at launch)
+            const unsigned pu = (unsigned)p, plane = (unsigned)a.gs.plane, wp = (unsigned)a.gs.wp;
+            const unsigned b = pu / plane, pi = pu - b * plane;
+            const int r = (int)(pi / wp), c = (int)(pi - (unsigned)r * wp);
+            // frame pixels (and zero slices) of S are zero: send them to a valid address
+            int bl = (int)b;
+            if (a.dm.dep_s != 0) {
+                const unsigned vol = b / (unsigned)a.dm.dep_s;
+                const int z = (int)(b - vol * (unsigned)a.dm.dep_s);
+                bl = (z < 1 || z > a.dm.dep_s - 2) ? -1 : (int)vol * a.dm.dep_l + 2 * (z - 1) + a.dm.dz + 1;
+            }
+            const bool in = bl >= 0 && r >= 1 && r <= a.gs.h && c >= 1 && c <= a.gs.w;
+            q = in ? (int64_t)bl * a.gl.plane + (int64_t)(2 * (r - 1) + 1) * a.gl.wp + (2 * (c - 1) + 1) : 0;
+        }
+        sv[u] = sp[p * 8];
+#pragma unroll
+        for (int t = 0; t < T; ++t) lv[u][t] = lp[q * 8 + off[t]];
+    }
+}
+
+// TILE = 32: v_mfma_f32_32x32x2_f32 (64 cycles, 2 pixels per instruction), a 32 x 32 (m, n) tile per wave.
+// TILE = 16: v_mfma_f32_16x16x4_f32 (32 cycles, 4 pixels per instruction) for THIN layers (M, N <= 16: the 16-channel level
+//            of BASELINE config 4's 3-D DRUNet, which holds most of its voxels) - the 32 x 32 instruction would spend
+//            4x the matrix-pipe cycles per pixel on a tile that is three quarters padding, and was pipe-bound there.
+// A workgroup = 4 waves on ONE tile and 4 consecutive pixel slices; the operands of iteration i + 1 are loaded while the
+// MFMAs of iteration i run (register double buffer: one wave per SIMD already overlaps memory latency and matrix pipe);
+// the four waves' tiles are added through LDS (fixed order) and written as one partial sum per workgroup.
+template <int T, bool STRIDE2, int TILE>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + wv;           // (m tile, n tile, slice), slice fastest
-    const int64_t ntile = (int64_t)a.mt * a.nt * a.nsplit;
-    if (unit >= ntile) return;
-    const int split = (int)(unit % a.nsplit);
-    const int tile = (int)(unit / a.nsplit);
-    const int m0 = (tile / a.nt) * 32, n0 = (tile % a.nt) * 32;
-    const int cm = m0 + l31, cn = n0 + l31;
-    const bool mv = cm < a.cs_alloc, nv = cn < a.cl_alloc;        // lanes beyond the allocated channels feed zeros
+    constexpr int PX = 64 / TILE, NACC = TILE == 32 ? 16 : 4;
+    constexpr int TG = TILE == 32 ? 3 : T;               // taps per reduction round (48 KB / 36 KB of LDS)
+    typedef typename WgAcc<TILE>::type Acc;
+    __shared__ float red[4 * 3 * 16 * 64];
+    static_assert(TG * NACC <= 48, "reduction round");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: slice bounds and loop control in SGPRs
+    const int lc = lane & (TILE - 1), lk = lane / TILE;
+    const int part = (int)(blockIdx.x % a.nparts), tile = (int)(blockIdx.x / a.nparts);
+    const int m0 = (tile / a.nt) * TILE, n0 = (tile % a.nt) * TILE;
+    const int cm = m0 + lc, cn = n0 + lc;
+    const bool mv = cm < a.cs_alloc, nv = cn < a.cl_alloc;
     const float* sp = a.s + ((int64_t)(mv ? cm / 8 : 0) * a.gs.cs + a.gs.sl) * 8 + (mv ? cm % 8 : 0);
     const float* lp = a.l + ((int64_t)(nv ? cn / 8 : 0) * a.gl.cs + a.gl.sl) * 8 + (nv ? cn % 8 : 0);
     int64_t off[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
         off[t] = STRIDE2 ? ((int64_t)(t >> 1) * a.gl.wp + (t & 1)) * 8 : ((int64_t)(t / 3 - 1) * a.gl.wp + (t % 3 - 1)) * 8;
-    f32x16 acc[T];
+    Acc acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int64_t pbeg = (int64_t)split * a.per_split;
-    const int64_t pend = min(pbeg + a.per_split, a.gs.np);
-    // U k-steps (2 pixels each) per iteration: all operand loads of the iteration are issued before its first MFMA, so
-    // one memory latency is paid per U * T MFMAs instead of per T (the loop is latency-, not bandwidth-bound)
-    constexpr int U = 4;
-    for (int64_t p2 = pbeg; p2 < pend; p2 += 2 * U) {
-        float sv[U], lv[U][T];
+        for (int r = 0; r < NACC; ++r) acc[t][r] = 0.f;
+    const int64_t pbeg = min(((int64_t)part * 4 + wv) * a.per_wave, a.gs.np);
+    const int64_t pend = min(pbeg + a.per_wave, a.gs.np);
+    float sv[WG_U], lv[WG_U][T], sn[WG_U], ln[WG_U][T];
+    if (pbeg < pend) wg_load<T, STRIDE2, PX>(a, sp, lp, off, pbeg, pend, lk, sv, lv);
+    // vmcnt(0): the loop is entered with nothing in flight, like every later iteration (the copy at its end waits for the
+    // prefetch) - otherwise the compiler's wait-count bookkeeping makes the first MFMAs of each iteration wait for the
+    // prefetch issued just before them
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int64_t p = pbeg; p < pend; p += PX * WG_U) {
+        const bool more = p + PX * WG_U < pend;
+        if (more) wg_load<T, STRIDE2, PX>(a, sp, lp, off, p + PX * WG_U, pend, lk, sn, ln);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t p = p2 + 2 * u + lhi;
-            const bool pv = p < pend;
-            int64_t q = pv ? p : 0;                          // pixel of L that tap (0,0) of pixel p reads
-            if (STRIDE2) {
-                q = 0;
-                if (pv) {
-                    const int64_t b = p / a.gs.plane;
-                    const int pi = (int)(p - b * a.gs.plane);
-                    const int r = pi / a.gs.wp, c = pi - r * a.gs.wp;
-                    // frame pixels (and zero slices) of S are zero: send them to a valid address
-                    const int64_t bl = depth_pair(a.dm, b);
-                    if (bl >= 0 && r >= 1 && r <= a.gs.h && c >= 1 && c <= a.gs.w)
-                        q = bl * a.gl.plane + (int64_t)(2 * (r - 1) + 1) * a.gl.wp + (2 * (c - 1) + 1);
-                }
+        for (int u = 0; u < WG_U; ++u)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if constexpr (TILE == 32) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[u], lv[u][t], acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], lv[u][t], acc[t], 0, 0, 0);
             }
-            sv[u] = (pv && mv) ? sp[p * 8] : 0.f;
+        if (more) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) lv[u][t] = (pv && nv) ? lp[q * 8 + off[t]] : 0.f;
-        }
+            for (int u = 0; u < WG_U; ++u) {
+                sv[u] = sn[u];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[u], lv[u][t], acc[t], 0, 0, 0);
-    }
-    // D[i][j]: j = l31 (column n), i = (reg & 3) + 8 (reg >> 2) + 4 lhi (row m)
-    float* out = a.part + (int64_t)split * a.M * a.N * T;
-    const int n = n0 + l31;
-    if (n < a.N) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int t = 0; t < T; ++t) out[((int64_t)m * a.N + n) * T + t] = acc[t][r];
-        }
-    }
-}
-
-// The same reduction for THIN layers (M <= 16 and N <= 16: the 16-channel level of BASELINE config 4's 3-D DRUNet, which holds
-// most of its voxels): v_mfma_f32_16x16x4_f32 - a 16 x 16 (m, n) tile, K = 4 pixels per instruction (lane quarter k takes
-// pixel k), 32 cycles instead of the 64 a 32 x 32 x 2 instruction spends on a tile that would be three quarters padding:
-// 4x fewer matrix-pipe cycles per pixel (the 32 x 32 form was pipe-bound there: 9 taps x 64 cycles per 2 pixels).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int T, bool STRIDE2>
-__global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradArgs a) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int64_t unit = (int64_t)blockIdx.x * 4 + wv;           // one (m, n) tile: the unit is the pixel slice
-    if (unit >= a.nsplit) return;
-    const int split = (int)unit;
-    const bool mv = l15 < a.cs_alloc, nv = l15 < a.cl_alloc;     // lanes beyond the allocated channels feed zeros
-    const float* sp = a.s + ((int64_t)(mv ? l15 / 8 : 0) * a.gs.cs + a.gs.sl) * 8 + (mv ? l15 % 8 : 0);
-    const float* lp = a.l + ((int64_t)(nv ? l15 / 8 : 0) * a.gl.cs + a.gl.sl) * 8 + (nv ? l15 % 8 : 0);
-    int64_t off[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-        off[t] = STRIDE2 ? ((int64_t)(t >> 1) * a.gl.wp + (t & 1)) * 8 : ((int64_t)(t / 3 - 1) * a.gl.wp + (t % 3 - 1)) * 8;
-    f32x4 acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int64_t pbeg = (int64_t)split * a.per_split;
-    const int64_t pend = min(pbeg + a.per_split, a.gs.np);
-    constexpr int U = 4;      // k-steps (4 pixels each) whose loads are issued before the first MFMA of the iteration
-    for (int64_t p4 = pbeg; p4 < pend; p4 += 4 * U) {
-        float sv[U], lv[U][T];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t p = p4 + 4 * u + lq;
-            const bool pv = p < pend;
-            int64_t q = pv ? p : 0;
-            if (STRIDE2) {
-                q = 0;
-                if (pv) {
-                    const int64_t b = p / a.gs.plane;
-                    const int pi = (int)(p - b * a.gs.plane);
-                    const int r = pi / a.gs.wp, c = pi - r * a.gs.wp;
-                    const int64_t bl = depth_pair(a.dm, b);
-                    if (bl >= 0 && r >= 1 && r <= a.gs.h && c >= 1 && c <= a.gs.w)
-                        q = bl * a.gl.plane + (int64_t)(2 * (r - 1) + 1) * a.gl.wp + (2 * (c - 1) + 1);
-                }
+                for (int t = 0; t < T; ++t) lv[u][t] = ln[u][t];
             }
-            sv[u] = (pv && mv) ? sp[p * 8] : 0.f;
-#pragma unroll
-            for (int t = 0; t < T; ++t) lv[u][t] = (pv && nv) ? lp[q * 8 + off[t]] : 0.f;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], lv[u][t], acc[t], 0, 0, 0);
     }
-    // D[i][j]: j = lane & 15 (column n), i = 4 (lane >> 4) + reg (row m)
-    float* out = a.part + (int64_t)split * a.M * a.N * T;
-    if (l15 < a.N) {
+    // workgroup sum (waves in order) of TG taps at a time, then one partial tile per workgroup.
+    // D[i][j] of lane l, register r:  32 x 32: j = l & 31, i = (r & 3) + 8 (r >> 2) + 4 (l >> 5);  16 x 16: j = l & 15, i = 4 (l >> 4) + r
+    float* out = a.part + (int64_t)part * a.M * a.N * T;
+    constexpr int RG = TG * NACC;                        // registers per lane per round
+    for (int t0 = 0; t0 < T; t0 += TG) {
+        if (t0) __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = 4 * lq + r;
-            if (m >= a.M) continue;
+        for (int t = 0; t < T; ++t) {
+            if (t < t0 || t >= t0 + TG) continue;
 #pragma unroll
-            for (int t = 0; t < T; ++t) out[((int64_t)m * a.N + l15) * T + t] = acc[t][r];
+            for (int r = 0; r < NACC; ++r) red[(wv * RG + (t - t0) * NACC + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < RG * 64; e += 256) {
+            const int j = e >> 6, l = e & 63;
+            const int t = t0 + j / NACC, r = j % NACC;
+            if (t >= T) continue;
+            const float v = ((red[e] + red[RG * 64 + e]) + red[2 * RG * 64 + e]) + red[3 * RG * 64 + e];
+            const int n = n0 + (l & (TILE - 1));
+            const int m = m0 + (TILE == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) : 4 * (l >> 4) + r);
+            if (m < a.M && n < a.N) out[((int64_t)m * a.N + n) * T + t] = v;
         }
     }
 }
@@ -215,19 +202,20 @@ __global__ __launch_bounds__(256) void relu_kernel(int64_t n4, float4* __restric
     }
 }
 
-int split_count(const dinv_act_geom* gs, int mt, int nt) {
-    // enough waves for ~8 per CU, slices of at least 512 pixels, an even number of pixels per slice
-    const int64_t want = (int64_t)256 * 8 / std::max(1, mt * nt);
+int part_count(const dinv_act_geom* gs, int m, int n) {
+    // workgroups (4 waves each) per tile: ~2 waves per SIMD over the chip, wave slices of at least 128 pixels
+    const bool thin = m <= 16 && n <= 16;
+    const int tiles = thin ? 1 : ((m + 31) / 32) * ((n + 31) / 32);
+    const int64_t want = std::max<int64_t>(1, 512 / tiles);
     const int64_t maxs = std::max<int64_t>(1, gs->np / 512);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, maxs), 1024));
+    return (int)std::min<int64_t>(want, maxs);
 }
 
 }  // namespace
 
 extern "C" size_t dinv_conv_wgrad_workspace_bytes(const dinv_act_geom* gs, int32_t m, int32_t n, int32_t taps) {
     if (!gs || m < 1 || n < 1 || (taps != 9 && taps != 4)) return 0;
-    const int mt = (m + 31) / 32, nt = (n + 31) / 32;
-    return (size_t)split_count(gs, mt, nt) * m * n * taps * sizeof(float);
+    return (size_t)part_count(gs, m, n) * m * n * taps * sizeof(float);
 }
 
 static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m, const float* l, int32_t n,
@@ -248,26 +236,27 @@ static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const 
                          gs->batch / dm.dep_s == gl->batch / dm.dep_l && (dm.dz == 0 || dm.dz == 1), "2x2x2 weight gradient: bad depth pairing");
     }
     DINV_REQUIRE(ws_bytes >= dinv_conv_wgrad_workspace_bytes(gs, m, n, taps), "workspace too small");
+    DINV_REQUIRE(gs->np < (int64_t)1 << 31 && gl->np < (int64_t)1 << 31, "more than 2^31 padded pixels");
     WgradArgs a{};
     a.gs = make_geom(*gs); a.gl = make_geom(*gl);
     a.s = s; a.l = l; a.part = reinterpret_cast<float*>(ws);
     a.M = m; a.N = n;
     a.cs_alloc = (m + 7) / 8 * 8; a.cl_alloc = (n + 7) / 8 * 8;
-    a.mt = (m + 31) / 32; a.nt = (n + 31) / 32;
-    a.nsplit = split_count(gs, a.mt, a.nt);
-    a.per_split = (ceil_div(gs->np, a.nsplit) + 15) / 16 * 16;   // whole iterations of 4 k-steps (of 2 or 4 pixels)
+    const bool thin = m <= 16 && n <= 16;          // 16 x 16 x 4 instruction, one tile
+    a.mt = thin ? 1 : (m + 31) / 32; a.nt = thin ? 1 : (n + 31) / 32;
+    a.nparts = part_count(gs, m, n);
+    a.per_wave = (ceil_div(gs->np, (int64_t)4 * a.nparts) + 15) / 16 * 16;   // whole iterations of 4 k-steps (of 2 or 4 pixels)
     a.dm = dm;
-    const int64_t units = (int64_t)a.mt * a.nt * a.nsplit;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)ceil_div(units, 4)), block(256);
-    if (m <= 16 && n <= 16) {      // thin layer: 16 x 16 x 4 instruction (mt = nt = 1: one unit per pixel slice)
-        if (taps == 9) hipLaunchKernelGGL((wgrad_thin_kernel<9, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((wgrad_thin_kernel<4, true>), grid, block, 0, st, a);
-    } else if (taps == 9) hipLaunchKernelGGL((wgrad_kernel<9, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<4, true>), grid, block, 0, st, a);
+    const dim3 grid((unsigned)(a.mt * a.nt * a.nparts)), block(256);
+    if (thin) {
+        if (taps == 9) hipLaunchKernelGGL((wgrad_kernel<9, false, 16>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wgrad_kernel<4, true, 16>), grid, block, 0, st, a);
+    } else if (taps == 9) hipLaunchKernelGGL((wgrad_kernel<9, false, 32>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<4, true, 32>), grid, block, 0, st, a);
     DINV_CHECK_LAUNCH();
     const int64_t ne = (int64_t)m * n * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ne, 16)), dim3(256), 0, st, a.part, ne, a.nsplit,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ne, 16)), dim3(256), 0, st, a.part, ne, a.nparts,
                        accumulate, dw);
     DINV_CHECK_LAUNCH();
     return 0;

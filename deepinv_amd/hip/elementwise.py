@@ -42,9 +42,10 @@ def eligible(*tensors) -> bool:
     return True
 
 
-def lincomb(a: float, x, b: float = 0.0, y=None, c: float = 0.0, z=None):
-    """a*x + b*y + c*z in one pass"""
-    out = torch.empty_like(x)
+def lincomb(a: float, x, b: float = 0.0, y=None, c: float = 0.0, z=None, out=None):
+    """a*x + b*y + c*z in one pass (into `out` when given: same shape, contiguous)"""
+    if out is None:
+        out = torch.empty_like(x)
     check(_l().dinv_lincomb(x.numel(), float(a), ptr(x), float(b), ptr(y), float(c), ptr(z), ptr(out), stream_ptr(x.device)))
     return out
 

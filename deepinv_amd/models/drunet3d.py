@@ -39,12 +39,39 @@ def _r16(c):
     return (c + 15) // 16 * 16
 
 
+_POOL: dict = {}        # (device, channels, level shape) -> released activation buffers
+_POOL_MAX_BYTES = 64 << 30
+_pool_bytes = 0
+
+
 class Vol:
-    """activation volume: tensor [C/8, cs, 8] with one guard plane in front, so that slice-shifted views stay inside"""
+    """activation volume: tensor [C/8, cs, 8] with one guard plane in front, so that slice-shifted views stay inside.
+
+    Buffers are recycled through a free list keyed by (device, channel count, level shape) instead of being zero-filled
+    per layer (the fills were 6 % of config 4's training step): every kernel that writes a volume writes ALL of its
+    in-range pixels (exact zeros on frames and padding slices) and nothing outside, so a released buffer still has
+    zero guard planes, zero slack and zero padded channel blocks - the only things a fresh ``torch.zeros`` adds."""
 
     def __init__(self, lv, channels, device):
         self.lv = lv
-        self.t = torch.zeros((_r64(channels) // 8, lv.g.cs, 8), device=device, dtype=torch.float32)
+        self.key = (torch.device(device), int(channels), lv.B, lv.D, lv.H, lv.W)
+        free = _POOL.get(self.key)
+        if free:
+            global _pool_bytes
+            self.t = free.pop()
+            _pool_bytes -= self.t.numel() * 4
+        else:
+            self.t = torch.zeros((_r64(channels) // 8, lv.g.cs, 8), device=device, dtype=torch.float32)
+
+    def __del__(self):
+        global _pool_bytes
+        try:
+            t, key = self.t, self.key
+            if _pool_bytes + t.numel() * 4 <= _POOL_MAX_BYTES:
+                _POOL.setdefault(key, []).append(t)
+                _pool_bytes += t.numel() * 4
+        except Exception:       # interpreter shutdown
+            pass
 
     def view(self, dz=0):
         return self.t[:, self.lv.guard + dz * self.lv.g.plane:]
@@ -140,9 +167,16 @@ def up(lvi, lvo, w5, x: Vol) -> Vol:
 
 
 def add(lv, a: Vol, b: Vol) -> Vol:
-    out = Vol.__new__(Vol)
-    out.lv, out.t = lv, ew.lincomb(1.0, a.t, 1.0, b.t)
+    out = Vol(lv, a.key[1], a.t.device)
+    ew.lincomb(1.0, a.t, 1.0, b.t, out=out.t)
     return out
+
+
+def release_buffers():
+    """drop the recycled activation buffers (they are kept between calls; 64 GiB cap)"""
+    global _pool_bytes
+    _POOL.clear()
+    _pool_bytes = 0
 
 
 def _blk(model, prefix, k):

@@ -222,6 +222,7 @@ inline int emu_readfirstlane(int v) { return __shfl(v, 0, 64); }
 #define __builtin_amdgcn_readfirstlane(x) emu_readfirstlane(x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_wavefrontsize() 64
 
 // ------------------------------------------------------------------ math / bit helpers

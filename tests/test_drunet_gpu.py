@@ -395,6 +395,23 @@ def test_drunet3d_hip_matches_torch_graph(dev, monkeypatch):
     assert all(gw_h[n].shape == gw_t[n].shape for n in gw_t)
     worst = max((rel_err(gw_h[n], gw_t[n]), n) for n in gw_t)
     assert worst[0] < 2e-4, worst
+    # recycled activation buffers (models/drunet3d.py: Vol free list): poison every interior voxel of every released
+    # buffer - a kernel that did not overwrite all of them would leak NaNs - and require bit-identical results
+    from deepinv_amd.models import drunet3d as M3
+
+    assert M3._POOL, "the free list is empty after a training step"
+    for (_, ch, b, d, h, w), bufs in M3._POOL.items():
+        lv = M3.Level(b, d, h, w)
+        for t in bufs:
+            vol = t[:, lv.guard + lv.g.sl: lv.guard + lv.g.sl + lv.g.np].view(t.shape[0], b, d + 2, h + 2, -1, 8)
+            vol[:(ch + 7) // 8, :, 1:-1, 1:h + 1, 1:w + 1] = float("nan")     # (blocks of padded channels stay zero)
+    y_h2, gx_h2, gs_h2, gw_h2 = run("hip")
+    assert torch.equal(y_h2, y_h) and torch.equal(gx_h2, gx_h) and torch.equal(gs_h2, gs_h)
+    assert all(torch.equal(gw_h2[n], gw_h[n]) for n in gw_h)
+    with torch.no_grad():
+        assert torch.equal(model(x0, sig0), y_inf)
+    M3.release_buffers()
+    assert not M3._POOL
 
 
 def test_drunet_hip_backward_padded_channels(dev, monkeypatch):

@@ -224,7 +224,8 @@ def _wgrad(gs, gl, s, m, l, n, taps):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 9, 14, 16, 64), (1, 12, 8, 3, 64), (3, 8, 8, 64, 2), (1, 20, 33, 40, 24),
-                                            (2, 9, 14, 16, 16), (1, 7, 5, 3, 16), (2, 6, 6, 16, 2)])   # last three: thin-layer (16x16x4) kernel
+                                            (2, 9, 14, 16, 16), (1, 7, 5, 3, 16), (2, 6, 6, 16, 2),     # thin-layer (16x16x4) kernel
+                                            (2, 30, 29, 16, 16), (2, 30, 29, 24, 40)])                  # several workgroups per tile
 def test_wgrad_3x3_matches_autograd(B, H, W, cin, cout):
     """dW of a 3x3 convolution (csrc/drunet_bwd.hip on the host emulation) vs torch autograd in fp64"""
     gen = torch.Generator().manual_seed(cin * cout + H)
