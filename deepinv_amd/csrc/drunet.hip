@@ -40,7 +40,21 @@ struct Conv3Args {
     const float* res2;
     int32_t cin, cblocks_valid, relu;
     int32_t ntiles, ytiles, tiles_per_xcd;  // pixel tiles, cout tiles, ceil(ntiles / 8)
+    // 3x3x3 mode (volumes as stacks of depth_s = D + 2 slices, a zero slice at each end): the K loop also runs over the
+    // ndz = 3 depth taps, tap dz reading the input shifted by dz - 1 slices (dz_stride floats per slice); ndz = 1: plain 2-D
+    int32_t ndz, depth_s;
+    int64_t dz_stride;
 };
+
+// frame pixels, pixels past the end and (3-D) the two padding slices of every volume are written as exact zeros
+__device__ __forceinline__ bool writes_value(const Conv3Args& a, int64_t p) {
+    if (!interior(a.g, p)) return false;
+    if (a.depth_s > 0) {
+        const int z = (int)((p / a.g.plane) % a.depth_s);
+        return z >= 1 && z <= a.depth_s - 2;
+    }
+    return true;
+}
 
 template <int MREP, bool RELU, int NRES>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
@@ -59,7 +73,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     const int tile = xcd * a.tiles_per_xcd + tl;
     if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;
     const int64_t p0 = (int64_t)tile * NT;
-    const int nchunks = a.cin / KC;
+    const int ncin = a.cin / KC;
+    const int nchunks = a.ndz * ncin;        // K steps: depth taps x 8-channel blocks
     f32x16 acc[MREP][2];
 #pragma unroll
     for (int m = 0; m < MREP; ++m)
@@ -103,12 +118,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
             __syncthreads();
         }
         if (ch + 1 < nchunks) {
-            const float* xb = a.x + (int64_t)(ch + 1) * a.g.cs * 8 + row0;
+            const int dz = (ch + 1) / ncin, cb = (ch + 1) - dz * ncin;
+            const int64_t koff = (int64_t)cb * a.g.cs * 8 + row0 + (int64_t)(dz - (a.ndz >> 1)) * a.dz_stride;
+            const float* xb = a.x + koff;
 #define DINV_XLD(IT, REG) REG = ld4(xb + xoff_g[IT]);
             DINV_XLD(0, xv0) DINV_XLD(1, xv1) DINV_XLD(2, xv2) DINV_XLD(3, xv3) DINV_XLD(4, xv4) DINV_XLD(5, xv5) DINV_XLD(6, xv6)
 #undef DINV_XLD
             if (a.x2) {
-                const float* xb2 = a.x2 + (int64_t)(ch + 1) * a.g.cs * 8 + row0;
+                const float* xb2 = a.x2 + koff;
 #define DINV_XLD2(IT, REG) REG = add4(REG, ld4(xb2 + xoff_g[IT]));
                 DINV_XLD2(0, xv0) DINV_XLD2(1, xv1) DINV_XLD2(2, xv2) DINV_XLD2(3, xv3) DINV_XLD2(4, xv4) DINV_XLD2(5, xv5) DINV_XLD2(6, xv6)
 #undef DINV_XLD2
@@ -144,8 +161,99 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     for (int n = 0; n < 2; ++n) {
         const int64_t p = p0 + wv * 64 + n * 32 + l31;
         if (p >= a.g.np) continue;
-        store_tile<MREP, RELU, NRES>(acc, n, a.g.sl + p, interior(a.g, p), cb0, a.cblocks_valid, a.g.cs, lhi, a.y, a.res1,
+        store_tile<MREP, RELU, NRES>(acc, n, a.g.sl + p, writes_value(a, p), cb0, a.cblocks_valid, a.g.cs, lhi, a.y, a.res1,
                                      a.res2);
+    }
+}
+
+// THIN layers (cout <= 16: the 16-channel level of BASELINE config 4's 3-D DRUNet, which holds most of its voxels, and
+// its 2-channel tail) on v_mfma_f32_16x16x4_f32: a 16-cout x 16-pixel tile per instruction instead of a 32-cout tile that
+// would be half (or more) zero padding - same matrix-pipe rate, no wasted rows.  Same staging as conv3x3_kernel (3 row
+// segments of 258 pixels x 8 channels + the 9 x 16 x 8 weight block per K step, register prefetch of the next step);
+// a wave owns 64 pixels = 4 tiles; lane (i = lane & 15, q = lane >> 4) holds channels 2q, 2q+1 of cout row i / pixel i
+// (one 8-byte LDS read feeds the two k-steps of an 8-channel block; rows are 12 floats apart: conflict-free).
+// D: pixel = lane & 15, couts 4q .. 4q+3 = one 16-byte store into channel block q >> 1.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool RELU, int NRES>
+__global__ __launch_bounds__(256) void conv3_thin_kernel(Conv3Args a) {
+    constexpr int MT = 16;
+    __shared__ __attribute__((aligned(16))) float xs[3 * SEG * LP];
+    __shared__ __attribute__((aligned(16))) float ws[9 * MT * LP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int xcd = blockIdx.x & 7, tl = blockIdx.x >> 3;
+    const int tile = xcd * a.tiles_per_xcd + tl;
+    if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;
+    const int64_t p0 = (int64_t)tile * NT;
+    const int ncin = a.cin / KC;
+    const int nchunks = a.ndz * ncin;
+    f32x4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int XSEG = SEG * 2, XV = 3 * XSEG, WV = 9 * MT * 2;
+    constexpr int XI = (XV + 255) / 256, WI = (WV + 255) / 256;
+    static_assert(XI == 7 && WI == 2, "prefetch slots");
+    const float4* wblk = reinterpret_cast<const float4*>(a.w);
+    int xoff_lds[XI], xoff_g[XI];
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+        const int idx = min(tid + it * 256, XV - 1);
+        const int seg = idx / XSEG, r = idx - seg * XSEG;
+        xoff_lds[it] = (seg * SEG + (r >> 1)) * LP + (r & 1) * 4;
+        xoff_g[it] = ((seg - 1) * a.g.wp - HALO) * 8 + r * 4;
+    }
+    const int64_t row0 = (a.g.sl + p0) * 8;
+    float4 xv0, xv1, xv2, xv3, xv4, xv5, xv6, w0, w1;
+    for (int ch = -1; ch < nchunks; ++ch) {
+        if (ch >= 0) {
+            __syncthreads();
+#define DINV_XST(IT, REG) if (IT < XI - 1 || tid + IT * 256 < XV) st4(xs + xoff_lds[IT], REG);
+            DINV_XST(0, xv0) DINV_XST(1, xv1) DINV_XST(2, xv2) DINV_XST(3, xv3) DINV_XST(4, xv4) DINV_XST(5, xv5) DINV_XST(6, xv6)
+#undef DINV_XST
+            st4(ws + (tid >> 1) * LP + (tid & 1) * 4, w0);
+            if (tid + 256 < WV) st4(ws + ((tid + 256) >> 1) * LP + (tid & 1) * 4, w1);
+            __syncthreads();
+        }
+        if (ch + 1 < nchunks) {
+            const int dz = (ch + 1) / ncin, cb = (ch + 1) - dz * ncin;
+            const float* xb = a.x + (int64_t)cb * a.g.cs * 8 + row0 + (int64_t)(dz - (a.ndz >> 1)) * a.dz_stride;
+#define DINV_XLD(IT, REG) REG = ld4(xb + xoff_g[IT]);
+            DINV_XLD(0, xv0) DINV_XLD(1, xv1) DINV_XLD(2, xv2) DINV_XLD(3, xv3) DINV_XLD(4, xv4) DINV_XLD(5, xv5) DINV_XLD(6, xv6)
+#undef DINV_XLD
+            const float4* wsrc = wblk + (int64_t)(ch + 1) * WV;
+            w0 = wsrc[tid];
+            w1 = wsrc[min(tid + 256, WV - 1)];
+        }
+        if (ch < 0) continue;
+        const float* xrow = xs + (wv * 64 + l15 + HALO) * LP + 2 * lq;
+        const float* wrow = ws + l15 * LP + 2 * lq;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3 - 1;
+            const float2 av = *reinterpret_cast<const float2*>(wrow + tap * MT * LP);
+            float2 bv[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bv[n] = *reinterpret_cast<const float2*>(xrow + (dy * SEG + n * 16 + dx) * LP);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[n].y, acc[n], 0, 0, 0);
+        }
+    }
+    const int cb = lq >> 1;
+    if (cb >= a.cblocks_valid) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int64_t p = p0 + wv * 64 + n * 16 + l15;
+        if (p >= a.g.np) continue;
+        const int64_t o = ((int64_t)cb * a.g.cs + a.g.sl + p) * 8 + 4 * (lq & 1);
+        float4 v = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+        if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (NRES >= 1) v = add4(v, ld4(a.res1 + o));
+        if (!writes_value(a, p)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(a.y + o, v);
     }
 }
 
@@ -452,31 +560,40 @@ extern "C" int dinv_act_geom_init(int32_t batch, int32_t height, int32_t width, 
     return 0;
 }
 
-extern "C" int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float* x2, const float* w_packed,
-                            int32_t cin, int32_t cout, int32_t cout_valid, int32_t cout_tile, float* y,
-                            const float* res1, const float* res2, int32_t relu, dinv_stream_t stream) {
+static int conv3_launch(const dinv_act_geom* g, const float* x, const float* x2, const float* w_packed, int32_t cin,
+                        int32_t cout, int32_t cout_valid, int32_t cout_tile, float* y, const float* res1, const float* res2,
+                        int32_t relu, int32_t depth, dinv_stream_t stream) {
     if (int e = check_geom(g)) return e;
     DINV_REQUIRE(x && w_packed && y, "null tensor pointer");
     DINV_REQUIRE(cin % KC == 0 && cin >= KC, "cin=%d must be a positive multiple of %d (pad with zero channels)", cin, KC);
-    DINV_REQUIRE(cout % 32 == 0 && cout_valid >= 1 && cout_valid <= cout, "bad cout=%d/valid=%d", cout, cout_valid);
-    DINV_REQUIRE((cout_tile == 32 || cout_tile == 64) && cout % cout_tile == 0, "cout_tile=%d must be 32 or 64 and divide cout=%d", cout_tile, cout);
+    const bool thin = cout_tile == 16;
+    if (thin) {
+        DINV_REQUIRE(cout == 16 && cout_valid >= 1 && cout_valid <= 16 && !x2 && !res2, "thin kernel: cout padded to 16, no x2 / res2");
+    } else {
+        DINV_REQUIRE(cout % 32 == 0 && cout_valid >= 1 && cout_valid <= cout, "bad cout=%d/valid=%d", cout, cout_valid);
+        DINV_REQUIRE((cout_tile == 32 || cout_tile == 64) && cout % cout_tile == 0, "cout_tile=%d must be 16, 32 or 64 and divide cout=%d", cout_tile, cout);
+    }
+    if (depth > 0) DINV_REQUIRE(g->batch % (depth + 2) == 0, "batch %d is not a whole number of (depth + 2)-slice volumes", g->batch);
     const int cbv = (cout_valid + 7) / 8;  // channel blocks that exist in the output buffer
     const int ntiles = (int)ceil_div(g->np, NT);
     const int tpx = (ntiles + 7) / 8;
     const int ytiles = cout / cout_tile;
-    Conv3Args a{make_geom(*g), x, x2, w_packed, y, res1, res2, cin, cbv, relu, ntiles, ytiles, tpx};
+    Conv3Args a{make_geom(*g), x, x2, w_packed, y, res1, res2, cin, cbv, relu, ntiles, ytiles, tpx,
+                depth > 0 ? 3 : 1, depth > 0 ? depth + 2 : 0, g->plane * 8};
     const unsigned gx = (unsigned)(8 * tpx * ytiles);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nres = (res1 ? 1 : 0) + (res2 ? 1 : 0);
     DINV_REQUIRE(res1 || !res2, "res2 given without res1");
-    if (cout_tile == 64) {
-        const dim3 grid(gx);
+    const dim3 grid(gx);
+    if (thin) {
+        if (relu) { if (nres) hipLaunchKernelGGL((conv3_thin_kernel<true, 1>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv3_thin_kernel<true, 0>), grid, dim3(256), 0, s, a); }
+        else      { if (nres) hipLaunchKernelGGL((conv3_thin_kernel<false, 1>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv3_thin_kernel<false, 0>), grid, dim3(256), 0, s, a); }
+    } else if (cout_tile == 64) {
 #define DINV_LAUNCH_C3(RELU, NRES) hipLaunchKernelGGL((conv3x3_kernel<2, RELU, NRES>), grid, dim3(256), 0, s, a)
         if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }
         else      { if (nres == 0) DINV_LAUNCH_C3(false, 0); else if (nres == 1) DINV_LAUNCH_C3(false, 1); else DINV_LAUNCH_C3(false, 2); }
 #undef DINV_LAUNCH_C3
     } else {
-        const dim3 grid(gx);
 #define DINV_LAUNCH_C3(RELU, NRES) hipLaunchKernelGGL((conv3x3_kernel<1, RELU, NRES>), grid, dim3(256), 0, s, a)
         if (relu) { if (nres == 0) DINV_LAUNCH_C3(true, 0); else if (nres == 1) DINV_LAUNCH_C3(true, 1); else DINV_LAUNCH_C3(true, 2); }
         else      { if (nres == 0) DINV_LAUNCH_C3(false, 0); else if (nres == 1) DINV_LAUNCH_C3(false, 1); else DINV_LAUNCH_C3(false, 2); }
@@ -484,6 +601,20 @@ extern "C" int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float*
     }
     DINV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float* x2, const float* w_packed,
+                            int32_t cin, int32_t cout, int32_t cout_valid, int32_t cout_tile, float* y,
+                            const float* res1, const float* res2, int32_t relu, dinv_stream_t stream) {
+    return conv3_launch(g, x, x2, w_packed, cin, cout, cout_valid, cout_tile, y, res1, res2, relu, 0, stream);
+}
+
+extern "C" int dinv_conv3x3x3(const dinv_act_geom* g, const float* x, const float* w_packed, int32_t cin, int32_t cout,
+                              int32_t cout_valid, int32_t cout_tile, float* y, const float* res1, int32_t relu,
+                              int32_t depth, dinv_stream_t stream) {
+    DINV_REQUIRE(depth >= 1, "bad depth %d", depth);
+    DINV_REQUIRE(g && g->cs >= g->sl + g->np + 2 * g->plane, "3-D views need a guard slice on each side of the buffer");
+    return conv3_launch(g, x, nullptr, w_packed, cin, cout, cout_valid, cout_tile, y, res1, nullptr, relu, depth, stream);
 }
 
 extern "C" int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const float* x2, const float* w_tail,

@@ -194,14 +194,6 @@ __global__ __launch_bounds__(256) void relu_backward_kernel(int64_t n4, const fl
     }
 }
 
-__global__ __launch_bounds__(256) void relu_kernel(int64_t n4, float4* __restrict__ x) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 v = x[i];
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        x[i] = v;
-    }
-}
-
 int part_count(const dinv_act_geom* gs, int m, int n) {
     // workgroups (4 waves each) per tile: ~2 waves per SIMD over the chip, wave slices of at least 128 pixels
     const bool thin = m <= 16 && n <= 16;
@@ -282,17 +274,6 @@ extern "C" int dinv_relu_backward(int64_t n, const float* act, float* grad, dinv
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n / 4, 256), 8192);
     hipLaunchKernelGGL(relu_backward_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n / 4,
                        reinterpret_cast<const float4*>(act), reinterpret_cast<float4*>(grad));
-    DINV_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int dinv_relu_inplace(int64_t n, float* x, dinv_stream_t stream) {
-    DINV_REQUIRE(n >= 0 && n % 4 == 0, "length must be a multiple of 4");
-    if (n == 0) return 0;
-    DINV_REQUIRE(x != nullptr, "null pointer");
-    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n / 4, 256), 8192);
-    hipLaunchKernelGGL(relu_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n / 4,
-                       reinterpret_cast<float4*>(x));
     DINV_CHECK_LAUNCH();
     return 0;
 }

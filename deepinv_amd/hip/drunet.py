@@ -33,6 +33,7 @@ def _l():
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
+        l.dinv_conv3x3x3.argtypes = [G, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_down2x2_bf16s.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2_bf16s.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
@@ -40,7 +41,6 @@ def _l():
         l.dinv_conv_wgrad_workspace_bytes.argtypes = [G, i32, i32, i32]
         l.dinv_conv_wgrad.argtypes = [G, G, vp, i32, vp, i32, i32, vp, i32, vp, ctypes.c_size_t, vp]
         l.dinv_relu_backward.argtypes = [ctypes.c_int64, vp, vp, vp]
-        l.dinv_relu_inplace.argtypes = [ctypes.c_int64, vp, vp]
         l.dinv_conv_down2x2_bf16s_3d.argtypes = [G, G, vp, vp, i32, i32, vp, i32, i32, i32, vp]
         l.dinv_conv_up2x2_bf16s_3d.argtypes = [G, G, vp, vp, vp, i32, i32, vp, i32, i32, vp]
         l.dinv_conv_wgrad_3d.argtypes = [G, G, vp, i32, vp, i32, vp, i32, vp, ctypes.c_size_t, i32, i32, vp]
@@ -258,6 +258,30 @@ def _conv3x3(g, x, wpk, cin, cout, y, cout_valid=None, x2=None, res1=None, res2=
                             int(wpk.shape[3]), ptr(y), ptr(res1), ptr(res2), int(relu), stream_ptr(y.device)))
 
 
+def pack_conv3x3x3_weight(w5: torch.Tensor) -> tuple[torch.Tensor, int, int]:
+    """[Cout, Cin, 3, 3, 3] -> fp32 pack of dinv_conv3x3x3: [cout/MT][dz][cin/8][9 taps][MT][8] (zero padded; MT = 16 for
+    Cout <= 16 - the thin-layer kernel -, else 64 / 32 as in pack_conv3x3_weight).  Returns (packed, cin_p, cout_p)."""
+    cout, cin = w5.shape[:2]
+    cin_p = (cin + 7) // 8 * 8
+    if cout <= 16:
+        mt, cout_p = 16, 16
+    else:
+        cout_p = (cout + 31) // 32 * 32
+        mt = 64 if cout_p % 64 == 0 else 32
+    wp = torch.zeros((cout_p, cin_p, 3, 3, 3), device=w5.device, dtype=torch.float32)
+    wp[:cout, :cin] = w5.detach().float()
+    # (co/mt, mt, ci/8, 8, dz, 9) -> (co/mt, dz, ci/8, 9, mt, 8)
+    wp = wp.reshape(cout_p // mt, mt, cin_p // 8, 8, 3, 9).permute(0, 4, 2, 5, 1, 3).contiguous()
+    return wp, cin_p, cout_p
+
+
+def conv3x3x3(g, x, wpk, cin, cout, y, depth, cout_valid=None, res1=None, relu=False):
+    """fp32 3x3x3 convolution of volumes stored as stacks of depth + 2 slices, ONE launch (depth taps inside the K loop
+    of csrc/drunet.hip: conv3x3_kernel / conv3_thin_kernel); wpk from pack_conv3x3x3_weight; views as for conv3x3x3_split"""
+    check(_l().dinv_conv3x3x3(ctypes.byref(g), ptr(x), ptr(wpk), cin, cout, cout if cout_valid is None else cout_valid,
+                              int(wpk.shape[4]), ptr(y), ptr(res1), int(relu), int(depth), stream_ptr(y.device)))
+
+
 def conv3x3_tail(g, x, wtail, cin, cout, y, x2=None):
     """last layer on the vector ALU: y[:cout] = conv3x3(x (+x2)); wtail from pack_tail_weight"""
     check(_l().dinv_conv3x3_tail(ctypes.byref(g), ptr(x), ptr(x2), ptr(wtail), cin, cout, ptr(y), stream_ptr(y.device)))
@@ -339,11 +363,6 @@ def relu_backward(act, grad):
     """grad <- grad * (act > 0) in place, on whole activation buffers"""
     check(_l().dinv_relu_backward(grad.numel(), ptr(act), ptr(grad), stream_ptr(grad.device)))
     return grad
-
-
-def relu_inplace(x):
-    check(_l().dinv_relu_inplace(x.numel(), ptr(x), stream_ptr(x.device)))
-    return x
 
 
 def down2x2_bf16s_3d(gi, go, x, wsplit, cin, cout, y, depth_out, dz, accumulate):

@@ -4,9 +4,9 @@ kernels - BASELINE config 4's denoiser (unfolded PGD on 3-D multi-coil MRI, deep
 A volume of D slices lives in the padded channel-blocked activation layout as D + 2 consecutive "images" (one zero
 slice at each end), so that
 
-* a 3x3x3 convolution is three 3x3 launches on views of the input shifted by -1 / 0 / +1 slices, accumulated through the
-  kernels' residual input (``res1 = y``), followed by re-zeroing the two padding slices; the ReLU of a ResBlock is a
-  separate in-place pass (it must see the sum of the three taps);
+* a 3x3x3 convolution is ONE launch of the 2-D-tile kernels with the three depth taps inside the K loop (tap dz reads
+  the input shifted by dz - 1 slices), ReLU / residual / zeroed padding slices in the epilogue: ``dinv_conv3x3x3_split``
+  (bf16-split arithmetic) or ``dinv_conv3x3x3`` (fp32; layers of <= 16 output channels on the 16x16x4 MFMA tile);
 * the 2x2x2 stride-2 convolution / transposed convolution are two launches of the 2-D kernels with the slice pairing
   z <-> 2 z + dz done inside the kernel (``dinv_conv_down2x2_bf16s_3d`` / ``dinv_conv_up2x2_bf16s_3d``);
 * data gradients are the same operators on re-packed weights (flipped + transposed 3x3x3 filters; down <-> up);
@@ -76,12 +76,6 @@ class Vol:
     def view(self, dz=0):
         return self.t[:, self.lv.guard + dz * self.lv.g.plane:]
 
-    def zero_pads(self):
-        lv = self.lv
-        v = self.t[:, lv.guard + lv.g.sl: lv.guard + lv.g.sl + lv.g.np].view(self.t.shape[0], lv.B, lv.D + 2, lv.g.plane, 8)
-        v[:, :, 0].zero_()
-        v[:, :, lv.D + 1].zero_()
-
 
 class Level:
     def __init__(self, B, D, H, W):
@@ -103,28 +97,13 @@ def _cached(kind, w, dz, make):
     return K.cached_pack(kind, w, make, sub=dz)
 
 
-def _conv2d(g, pk, x, y, res1):
-    kind, wpk, ci_p, co_p, cout = pk
-    if kind == "split":
-        K.conv3x3_split(g, x, wpk, ci_p, co_p, y, res1=res1)
-    else:           # thin head / tail layers, and the mask-exact forward of the training path
-        K.conv3x3(g, x, wpk, ci_p, co_p, y, cout_valid=cout, res1=res1)
-
-
-def _pack2d(w, fp32):
-    cout, cin = w.shape[:2]
-    if cin >= 16 and cout >= 16 and not fp32:
-        return ("split", K.pack_split2d_weight(_pad_w(w, _r64(cout), _r16(cin))), _r16(cin), _r64(cout), cout)
-    wpk, ci_p, co_p = K.pack_conv3x3_weight(w)
-    return ("direct", wpk, ci_p, co_p, cout)
-
-
 def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=False, x_presplit=False,
           y_presplit=False) -> Vol:
     """3x3x3 convolution, stride 1, zero padding 1, no bias; w5 [Cout, Cin, 3, 3, 3] (true channel counts).
     flip: convolve with the transposed, tap-reversed filter instead (the data gradient of the same layer).
-    bf16-split arithmetic: ONE launch (the depth taps are part of the kernel's K loop, ReLU and the zero padding slices
-    in its epilogue); fp32 arithmetic (thin head / tail layers, mask-exact training forward): three accumulated launches"""
+    ONE launch either way (the depth taps are part of the kernel's K loop, ReLU and the zero padding slices in its
+    epilogue): bf16-split arithmetic (csrc/drunet_split2d.hip) or fp32 (csrc/drunet.hip: thin head / tail layers and the
+    mask-exact training forward; layers of <= 16 output channels on the 16x16x4 MFMA tile)"""
     cout, cin = (w5.shape[1], w5.shape[0]) if flip else w5.shape[:2]
     y = Vol(lv, cout, x.t.device)
     if cin >= 16 and cout >= 16 and not fp32:
@@ -133,14 +112,9 @@ def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=F
                           relu=relu, x_presplit=x_presplit, y_presplit=y_presplit)
         return y
     assert not (x_presplit or y_presplit)
-    for dz in range(3):
-        pk = _cached(("c3", flip, fp32), w5, dz,
-                     lambda dz=dz: _pack2d((_flip_t(w5) if flip else w5)[:, :, dz].contiguous(), fp32))
-        r = (res.view() if res is not None else None) if dz == 0 else y.view()
-        _conv2d(lv.g, pk, x.view(dz - 1), y.view(), r)
-    y.zero_pads()
-    if relu:
-        K.relu_inplace(y.t)
+    pk, cip, cop = _cached(("c3f", flip), w5, 0, lambda: K.pack_conv3x3x3_weight(_flip_t(w5) if flip else w5))
+    K.conv3x3x3(lv.g, x.view(), pk, cip, cop, y.view(), lv.D, cout_valid=cout, res1=res.view() if res is not None else None,
+                relu=relu)
     return y
 
 

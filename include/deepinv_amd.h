@@ -145,6 +145,14 @@ int dinv_act_unpack(const dinv_act_geom* g, const float* act, int32_t cout, floa
 int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float* x2, const float* w_packed,
                  int32_t cin, int32_t cout, int32_t cout_valid, int32_t cout_tile, float* y, const float* res1,
                  const float* res2, int32_t relu, dinv_stream_t stream);
+/* fp32 3x3x3 convolution (nn.Conv3d of DRUNet with dim = 3, drunet.py:39-263) of volumes stored as stacks of
+ * depth + 2 slices (see the 3-D section below), ONE launch: y = [relu](conv3x3x3(x)) (+res1), the padding slices of y
+ * written as zeros.  w_packed: [cout/MT][dz 3][cin/8][9 taps][MT][8]; cout_tile = MT in {16, 32, 64}; MT = 16 (cout
+ * padded to 16) selects the thin-layer kernel on the 16x16x4 fp32 MFMA tile (also accepted by dinv_conv3x3: x2 = res2 =
+ * NULL).  x must be readable one slice before and after the buffer's range. */
+int dinv_conv3x3x3(const dinv_act_geom* g, const float* x, const float* w_packed, int32_t cin, int32_t cout,
+                   int32_t cout_valid, int32_t cout_tile, float* y, const float* res1, int32_t relu, int32_t depth,
+                   dinv_stream_t stream);
 /* Last DRUNet layer: y[first channel block, channels 0..cout-1] = conv3x3(x (+x2)), 1 <= cout <= 4, stride 1,
  * zero padding 1, no bias (m_tail, drunet.py:39-101, input x + x1 at :210), on the vector ALU (HBM-bound).
  * w_tail: [cin/8][9 taps][cout][8]; cin % 8 == 0. */
@@ -207,8 +215,6 @@ int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl, const floa
                     dinv_stream_t stream);
 /* grad <- grad where act > 0 else 0 (ReLU backward on whole activation buffers; n floats, n % 4 == 0) */
 int dinv_relu_backward(int64_t n, const float* act, float* grad, dinv_stream_t stream);
-/* x <- max(x, 0) on a whole activation buffer (the ReLU of a 3-D ResBlock, applied after the three depth taps are summed) */
-int dinv_relu_inplace(int64_t n, float* x, dinv_stream_t stream);
 
 /* ---- 3-D volumes (DRUNet with dim = 3, deepinv/models/drunet.py:39-263 with Conv3d / ConvTranspose3d) on the 2-D
  * kernels: a volume of D slices occupies D + 2 consecutive images of the padded layout (a zero slice at each end).

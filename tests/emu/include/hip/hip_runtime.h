@@ -223,6 +223,18 @@ inline int emu_readfirstlane(int v) { return __shfl(v, 0, 64); }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+// buffer resources (range-checked loads / stores: offsets >= num_records are dropped / read as zero)
+struct __amdgpu_buffer_rsrc_t { char* base; unsigned num; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) { return {(char*)p, (unsigned)num}; }
+typedef unsigned int emu_u32x4 __attribute__((ext_vector_type(4)));
+inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned off, int soff, int) {
+    emu_u32x4 v = {0, 0, 0, 0};
+    if ((uint64_t)off + soff + 16 <= r.num) std::memcpy(&v, r.base + off + soff, 16);
+    return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off, int soff, int) {
+    if ((uint64_t)off + soff + 16 <= r.num) std::memcpy(r.base + off + soff, &v, 16);
+}
 #define __builtin_amdgcn_wavefrontsize() 64
 
 // ------------------------------------------------------------------ math / bit helpers

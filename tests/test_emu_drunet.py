@@ -343,13 +343,6 @@ def test_wgrad_2x2x2_depth_tap(up):
         assert float((dw.double() - w.grad[:, :, dz]).norm() / w.grad[:, :, dz].norm()) < 1e-5
 
 
-def test_relu_inplace():
-    x = torch.randn(1000)
-    ref = x.clamp(min=0)
-    E.check(E.lib().dinv_relu_inplace(ctypes.c_int64(1000), E.p(x), None))
-    assert torch.equal(x, ref)
-
-
 @pytest.mark.parametrize("mode", ["plain", "relu_split_chain"])
 def test_conv3x3x3_single_launch(mode):
     """dinv_conv3x3x3_split: the three depth taps inside the K loop of the 2-D-tile kernel, padding slices written as zeros;
@@ -432,3 +425,78 @@ def test_conv3x3x3_as_three_shifted_2d_launches():
     assert float((got.double() - ref).norm() / ref.norm()) < 2e-5
 
 
+
+
+@pytest.mark.parametrize("cin,cout,relu,res", [(16, 16, True, False), (3, 16, False, False), (16, 2, False, True), (16, 32, True, False),
+                                              (24, 64, False, True)])
+def test_conv3x3x3_fp32_single_launch(cin, cout, relu, res):
+    """dinv_conv3x3x3 (csrc/drunet.hip: fp32 MFMA, depth taps inside the K loop; cout <= 16: conv3_thin_kernel on the
+    16x16x4 tile) against conv3d in fp64: ReLU / residual epilogues, zeroed padding slices, stale output overwritten"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_conv3x3x3_weight
+    B, D, H, W = 2, 3, 6, 15
+    gen = torch.Generator().manual_seed(cin + 7 * cout)
+    x = torch.randn(B, cin, D, H, W, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=gen) / (27 * cin) ** 0.5
+    r = torch.randn(B, cout, D, H, W, generator=gen)
+    g = geom(B * (D + 2), H, W)
+    guard = g.plane
+    g.cs = (g.cs + 2 * guard + 3) // 4 * 4
+
+    def to_vol(t):
+        c = t.shape[1]
+        cp = (c + 7) // 8 * 8
+        t = torch.cat((t, torch.zeros(B, cp - c, D, H, W)), 1)
+        a = torch.zeros(cp // 8, g.cs, 8)
+        t2 = torch.nn.functional.pad(t.permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, 0, 1, 1)).reshape(B * (D + 2), cp, H, W)
+        fr = a[:, guard + g.sl: guard + g.sl + g.np].view(-1, B * (D + 2), g.hp, g.wp, 8)
+        fr[:, :, 1:H + 1, 1:W + 1] = t2.reshape(B * (D + 2), -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    xa, ra = to_vol(x), to_vol(r)
+    cb = (cout + 7) // 8
+    ya = torch.full((cb, g.cs, 8), 7.0)                # stale values everywhere the kernel must write
+    ya[:, :guard + g.sl] = 0
+    ya[:, guard + g.sl + g.np:] = 0
+    wpk, cip, cop = pack_conv3x3x3_weight(w)
+    view = lambda a: ctypes.c_void_p(a[:, guard:].data_ptr())
+    E.check(E.lib().dinv_conv3x3x3(ctypes.byref(g), view(xa), ctypes.c_void_p(wpk.data_ptr()), cip, cop, cout, int(wpk.shape[4]),
+                                   view(ya), view(ra) if res else None, int(relu), D, None))
+    out = ya[:, guard + g.sl: guard + g.sl + g.np].view(-1, B, D + 2, g.hp, g.wp, 8)
+    assert float(out[:, :, 0].abs().max()) == 0 and float(out[:, :, D + 1].abs().max()) == 0          # padding slices
+    assert float(out[:, :, :, 0].abs().max()) == 0 and float(out[:, :, :, :, 0].abs().max()) == 0     # frames
+    assert float(out[:, :, :, :, W + 1:].abs().max()) == 0
+    got = out[:, :, 1:-1, 1:H + 1, 1:W + 1].permute(1, 0, 5, 2, 3, 4).reshape(B, cb * 8, D, H, W)[:, :cout]
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
+    if relu:
+        ref = ref.clamp_min(0)
+    if res:
+        ref = ref + r.double()
+    assert float((got.double() - ref).norm() / ref.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("cout", [16, 32, 64])
+def test_conv3x3_fp32_direct(cout):
+    """dinv_conv3x3 (fp32 MFMA direct kernel; cout_tile 16 = the thin-layer kernel) against conv2d in fp64"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_conv3x3_weight
+    B, C, H, W = 2, 16, 9, 21
+    gen = torch.Generator().manual_seed(cout)
+    x = torch.randn(B, C, H, W, generator=gen)
+    w = torch.randn(cout, C, 3, 3, generator=gen) / (9 * C) ** 0.5
+    g = geom(B, H, W)
+    if cout == 16:
+        wpk = w.reshape(1, 16, C // 8, 8, 9).permute(0, 2, 4, 1, 3).contiguous()
+        mt = 16
+    else:
+        wpk, _, _ = pack_conv3x3_weight(w)
+        mt = int(wpk.shape[3])
+    ya = torch.full((cout // 8, g.cs, 8), 7.0)
+    ya[:, :g.sl] = 0
+    ya[:, g.sl + g.np:] = 0
+    xa = to_act(x, g)
+    E.check(E.lib().dinv_conv3x3(ctypes.byref(g), E.p(xa), None, E.p(wpk), C, cout, cout, mt, E.p(ya), None, None, 0, None))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    assert float((from_act(ya, g, cout).double() - ref).norm() / ref.norm()) < 2e-6
