@@ -591,7 +591,10 @@ int launch_cols_expand_fwd(const float* x, const float2* maps, float2* t, int64_
         const int64_t qtiles = ceil_div(Q, L), nsets = B * qtiles;
         const int64_t padded = ceil_div(nsets, 8) * 8 * ncoil;
         const unsigned grid = (unsigned)std::min<int64_t>(padded, 4 * kMaxGrid);
-        constexpr int NT = N >= 256 ? 512 : 256;
+        // 256 threads: two workgroups per CU at N = 320 (210 VGPRs), so one tile's loads overlap another's transform
+        // (measured at cfg2: 111 us; 512 threads / 148 VGPRs = one workgroup per CU: 135 us; 512 threads capped at 128
+        // VGPRs (spills): 171 us)
+        constexpr int NT = 256;
         hipLaunchKernelGGL((mri_cols_expand_fwd_kernel<P, L, NT>), dim3(grid), dim3(NT), 0, s, x, maps, t, ncoil, maps_batch, Q,
                            qtiles, nsets, table, scale);
         DINV_CHECK_LAUNCH();
