@@ -218,9 +218,9 @@ int dinv_relu_backward(int64_t n, const float* act, float* grad, dinv_stream_t s
 
 /* ---- 3-D volumes (DRUNet with dim = 3, deepinv/models/drunet.py:39-263 with Conv3d / ConvTranspose3d) on the 2-D
  * kernels: a volume of D slices occupies D + 2 consecutive images of the padded layout (a zero slice at each end).
- *   3x3x3 convolution = three 3x3 launches (dinv_conv3x3_split / dinv_conv3x3) on views of x shifted by -1 / 0 / +1
- *     slices (pointer + dz * plane * 8 floats), accumulated through `res1 = y`; same for its weight gradient
- *     (dinv_conv_wgrad with a shifted L);
+ *   3x3x3 convolution = ONE launch of dinv_conv3x3x3_split / dinv_conv3x3x3 (the depth taps are part of the kernel's K
+ *     loop: tap dz reads x shifted by dz - 1 slices = pointer + (dz - 1) * plane * 8 floats); its weight gradient is
+ *     dinv_conv_wgrad per depth tap with L shifted the same way;
  *   2x2x2 stride-2 layers pair slice z of the half grid with slice 2 z + dz of the full grid: the _3d entry points
  *     below take the depth of the half-grid volume and the depth tap dz in {0, 1}; zero slices are skipped / kept zero. */
 int dinv_conv_down2x2_bf16s_3d(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
