@@ -161,6 +161,137 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---- 3x3 weight gradient with the operands staged through LDS (the form the 3x3 / 3x3x3 layers use; the stride-2 layers keep
+// the register-gather kernel above).  A workgroup = 4 waves on one (m, n) tile and one pixel slice, walked in chunks of P
+// pixels: the chunk of S (P pixels x TILE channels) and the three row segments of L it touches ((P + 2) pixels each, rows
+// -1 / 0 / +1) are copied global -> registers -> LDS with 16-byte accesses in the global layout's own order (a pixel's
+// TILE channels are contiguous: no transposition), double buffered - the loads of chunk c + 1 are in flight while chunk
+// c is on the matrix cores, one barrier per chunk.  Each wave takes a quarter of the chunk's pixels for all 9 taps and reads
+// its MFMA operands with conflict-free 4-byte LDS reads (TILE lanes = TILE consecutive floats, the lane parts = consecutive
+// pixels).  Against the gather form: the 36 strided 4-byte global loads per 36 MFMAs (2-4 of 16 lanes per cache line) become
+// 9 coalesced 16-byte loads per thread per chunk, and each L value is fetched once per row role instead of once per tap.
+template <int TILE>
+__global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradArgs a) {
+    constexpr int T = 9;
+    constexpr int PX = 64 / TILE, NACC = TILE == 32 ? 16 : 4;
+    constexpr int P = TILE == 32 ? 64 : 128;             // pixels per chunk
+    constexpr int SEG = P + 2;                           // pixels per staged row segment of L
+    constexpr int Q = TILE / 4;                          // float4 per staged pixel
+    constexpr int STAGE = (P + 3 * SEG) * TILE;          // floats per stage: 33.5 KB / 33.2 KB
+    constexpr int NS = P * Q, NL = 3 * SEG * Q;          // float4 of S / of L per chunk
+    constexpr int SI = (NS + 255) / 256, LI = (NL + 255) / 256;
+    constexpr int TG = TILE == 32 ? 3 : T;               // taps per reduction round
+    constexpr int RG = TG * NACC;
+    typedef typename WgAcc<TILE>::type Acc;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    static_assert(4 * RG * 64 <= 2 * STAGE, "reduction scratch aliases the stages");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & (TILE - 1), lk = lane / TILE;
+    const int part = (int)(blockIdx.x % a.nparts), tile = (int)(blockIdx.x / a.nparts);
+    const int m0 = (tile / a.nt) * TILE, n0 = (tile % a.nt) * TILE;
+    const int64_t pbeg = min((int64_t)part * 4 * a.per_wave, a.gs.np);
+    const int64_t pend = min(pbeg + 4 * a.per_wave, a.gs.np);
+    const int nchunks = (int)((pend - pbeg + P - 1) / P);
+    // staging slots of this thread (fixed across chunks): float offsets relative to the chunk's first pixel / LDS offsets
+    int s_g[SI], s_l[SI], l_g[LI], l_l[LI];
+    bool s_ok[SI], l_ok[LI];
+#pragma unroll
+    for (int k = 0; k < SI; ++k) {
+        const int f = min(tid + 256 * k, NS - 1), pix = f / Q, q = f - pix * Q;
+        const int ch = m0 + 4 * q, cb = ch < a.cs_alloc ? ch / 8 : 0;      // channel blocks beyond the allocation: block 0 (the
+        s_ok[k] = tid + 256 * k < NS;                                       // tile rows they feed are never written)
+        s_g[k] = (int)((cb * a.gs.cs + pix) * 8 + (ch & 4));
+        s_l[k] = pix * TILE + 4 * q;
+    }
+#pragma unroll
+    for (int k = 0; k < LI; ++k) {
+        const int f = min(tid + 256 * k, NL - 1), rp = f / Q, q = f - rp * Q;
+        const int rr = rp / SEG, sp = rp - rr * SEG;
+        const int ch = n0 + 4 * q, cb = ch < a.cl_alloc ? ch / 8 : 0;
+        l_ok[k] = tid + 256 * k < NL;
+        l_g[k] = (int)((cb * a.gl.cs + (int64_t)(rr - 1) * a.gl.wp + sp - 1) * 8 + (ch & 4));
+        l_l[k] = (P + rp) * TILE + 4 * q;
+    }
+    const float* sbase = a.s + a.gs.sl * 8;
+    const float* lbase = a.l + a.gl.sl * 8;
+    float4 sr[SI], lr[LI];
+    // chunk c -> registers.  S pixels past the end of the slice are redirected to pixel 0 of the buffer (the corner of the
+    // first frame: zero in S like every frame pixel); L needs no guard (finite data in the slack, multiplied by S = 0)
+    auto fetch = [&](int c) {
+        const int64_t p0 = pbeg + (int64_t)c * P;
+#pragma unroll
+        for (int k = 0; k < SI; ++k) {
+            const int pix = s_l[k] / TILE;
+            const int64_t po = p0 + pix < pend ? p0 * 8 + s_g[k] : (int64_t)s_g[k] - (int64_t)pix * 8;
+            sr[k] = ld4(sbase + po);
+        }
+#pragma unroll
+        for (int k = 0; k < LI; ++k) lr[k] = ld4(lbase + p0 * 8 + l_g[k]);
+    };
+    auto commit = [&](int stage) {
+        float* st = lds + stage * STAGE;
+#pragma unroll
+        for (int k = 0; k < SI; ++k)
+            if (s_ok[k]) st4(st + s_l[k], sr[k]);
+#pragma unroll
+        for (int k = 0; k < LI; ++k)
+            if (l_ok[k]) st4(st + l_l[k], lr[k]);
+    };
+    Acc acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) acc[t][r] = 0.f;
+    if (nchunks > 0) {
+        fetch(0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) fetch(c + 1);
+        const float* st = lds + (c & 1) * STAGE;
+        const float* sp = st + (wv * (P / 4) + lk) * TILE + lc;                  // S[pixel][channel]
+        const float* lp = st + (P + wv * (P / 4) + lk + 1) * TILE + lc;          // L row segment 0, tap dx = 0
+#pragma unroll
+        for (int u = 0; u < P / 4 / PX; ++u) {
+            const float av = sp[u * PX * TILE];
+            float bv[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bv[t] = lp[((t / 3) * SEG + u * PX + (t % 3 - 1)) * TILE];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if constexpr (TILE == 32) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) commit((c + 1) & 1);
+        __syncthreads();
+    }
+    // workgroup sum (waves in order) of TG taps at a time, then one partial tile per workgroup (as in wgrad_kernel)
+    float* red = lds;
+    float* out = a.part + (int64_t)part * a.M * a.N * T;
+    for (int t0 = 0; t0 < T; t0 += TG) {
+        if (t0) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (t < t0 || t >= t0 + TG) continue;
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) red[(wv * RG + (t - t0) * NACC + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < RG * 64; e += 256) {
+            const int j = e >> 6, l = e & 63;
+            const int t = t0 + j / NACC, r = j % NACC;
+            if (t >= T) continue;
+            const float v = ((red[e] + red[RG * 64 + e]) + red[2 * RG * 64 + e]) + red[3 * RG * 64 + e];
+            const int n = n0 + (l & (TILE - 1));
+            const int m = m0 + (TILE == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) : 4 * (l >> 4) + r);
+            if (m < a.M && n < a.N) out[((int64_t)m * a.N + n) * T + t] = v;
+        }
+    }
+}
+
 // dw[e] (+)= sum over slices in a fixed order: 16 lanes share an element (lane j adds slices j, j + 16, ... in order,
 // then the 16 partial sums are added in lane order), 16 elements per workgroup
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int nsplit, int accumulate,
@@ -241,10 +372,12 @@ static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const 
     a.dm = dm;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.mt * a.nt * a.nparts)), block(256);
-    if (thin) {
-        if (taps == 9) hipLaunchKernelGGL((wgrad_kernel<9, false, 16>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((wgrad_kernel<4, true, 16>), grid, block, 0, st, a);
-    } else if (taps == 9) hipLaunchKernelGGL((wgrad_kernel<9, false, 32>), grid, block, 0, st, a);
+    if (taps == 9) {
+        DINV_REQUIRE((int64_t)(a.cs_alloc / 8 + 1) * gs->cs * 8 < ((int64_t)1 << 31) && (int64_t)(a.cl_alloc / 8 + 1) * gl->cs * 8 < ((int64_t)1 << 31),
+                     "activation buffers too large for 32-bit staging offsets");
+        if (thin) hipLaunchKernelGGL((wgrad_lds_kernel<16>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wgrad_lds_kernel<32>), grid, block, 0, st, a);
+    } else if (thin) hipLaunchKernelGGL((wgrad_kernel<4, true, 16>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<4, true, 32>), grid, block, 0, st, a);
     DINV_CHECK_LAUNCH();
     const int64_t ne = (int64_t)m * n * taps;
