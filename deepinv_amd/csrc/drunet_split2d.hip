@@ -304,10 +304,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split2d_kernel(S2Args a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (NRES >= 1) {
+                if (NRES == 1) {
                     const float4 ra = rs[2 * k], rb = rs[2 * k + 1];
                     v[0] += ra.x; v[1] += ra.y; v[2] += ra.z; v[3] += ra.w;
                     v[4] += rb.x; v[5] += rb.y; v[6] += rb.z; v[7] += rb.w;
+                }
+                if (NRES == 2) {      // gate: res1 is the ReLU output of the forward pass, its sign masks this data gradient
+                    const float4 ra = rs[2 * k], rb = rs[2 * k + 1];
+                    v[0] = ra.x > 0.f ? v[0] : 0.f; v[1] = ra.y > 0.f ? v[1] : 0.f; v[2] = ra.z > 0.f ? v[2] : 0.f; v[3] = ra.w > 0.f ? v[3] : 0.f;
+                    v[4] = rb.x > 0.f ? v[4] : 0.f; v[5] = rb.y > 0.f ? v[5] : 0.f; v[6] = rb.z > 0.f ? v[6] : 0.f; v[7] = rb.w > 0.f ? v[7] : 0.f;
                 }
                 if (!in) {
 #pragma unroll
@@ -367,8 +372,9 @@ static int split_launch(const dinv_act_geom* g, const void* x, const void* w_spl
     DINV_REQUIRE(x && w_split && y, "null tensor pointer");
     DINV_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 64 && cout % 64 == 0,
                  "bf16-split conv needs cin %% 16 == 0 and cout %% 64 == 0 (got %d,%d)", cin, cout);
-    const bool in_split = flags & 1, out_split = flags & 2, relu = flags & 4;
-    DINV_REQUIRE((flags & ~0x307) == 0 && ((flags >> 8) & 3) != 3, "unknown flags %d", flags);
+    const bool in_split = flags & 1, out_split = flags & 2, relu = flags & 4, gate = flags & 8;
+    DINV_REQUIRE((flags & ~0x30f) == 0 && ((flags >> 8) & 3) != 3, "unknown flags %d", flags);
+    DINV_REQUIRE(!gate || (res1 && !relu && !in_split && !out_split), "gate mode: fp32 in / out, no relu, res1 = the activation whose sign gates the output");
     DINV_REQUIRE(!(relu && res1), "relu and residual are not combined in DRUNet");
     DINV_REQUIRE(!(out_split && res1), "a pre-split output carries no residual");
     DINV_REQUIRE(depth == 0 || (depth >= 1 && g->batch % (depth + 2) == 0), "batch %d is not a stack of volumes of %d + 2 slices",
@@ -396,6 +402,7 @@ static int split_launch(const dinv_act_geom* g, const void* x, const void* w_spl
         return dispatch_tile<false, true, false, 0>(a, tc, nrep, st);
     }
     if (relu) return dispatch_tile<false, false, true, 0>(a, tc, nrep, st);
+    if (gate) return dispatch_tile<false, false, false, 2>(a, tc, nrep, st);
     if (res1) return dispatch_tile<false, false, false, 1>(a, tc, nrep, st);
     return dispatch_tile<false, false, false, 0>(a, tc, nrep, st);
 }

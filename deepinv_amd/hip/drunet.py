@@ -287,14 +287,14 @@ def conv3x3_tail(g, x, wtail, cin, cout, y, x2=None):
     check(_l().dinv_conv3x3_tail(ctypes.byref(g), ptr(x), ptr(x2), ptr(wtail), cin, cout, ptr(y), stream_ptr(y.device)))
 
 
-def conv3x3_split(g, x, wsplit, cin, cout, y, res1=None, relu=False, x_presplit=False, y_presplit=False):
+def conv3x3_split(g, x, wsplit, cin, cout, y, res1=None, relu=False, x_presplit=False, y_presplit=False, gate=False):
     """y = [relu](conv3x3(x)) (+res1) on the bf16 matrix cores, two-part exact operand split, 2-D pixel tiles
     (csrc/drunet_split2d.hip); wsplit from pack_split2d_weight.  `x_presplit` / `y_presplit`: the activation buffer holds
     (8 bf16 high parts | 8 bf16 low parts) per pixel and channel block instead of 8 fp32 values (same 32 bytes)."""
     if _prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    flags = (1 if x_presplit else 0) | (2 if y_presplit else 0) | (4 if relu else 0)
+    flags = (1 if x_presplit else 0) | (2 if y_presplit else 0) | (4 if relu else 0) | (8 if gate else 0)   # gate: y = res1 > 0 ? conv : 0
     check(_l().dinv_conv3x3_split(ctypes.byref(g), ptr(x), ptr(wsplit), cin, cout, ptr(y), ptr(res1), flags,
                                   stream_ptr(y.device)))
     if _prof is not None:
@@ -303,11 +303,11 @@ def conv3x3_split(g, x, wsplit, cin, cout, y, res1=None, relu=False, x_presplit=
         _prof.append((e0, e1, "conv3x3_split2d_kernel", fl, 3.0 * fl))
 
 
-def conv3x3x3_split(g, x, wsplit, cin, cout, y, depth, res1=None, relu=False, x_presplit=False, y_presplit=False):
+def conv3x3x3_split(g, x, wsplit, cin, cout, y, depth, res1=None, relu=False, x_presplit=False, y_presplit=False, gate=False):
     """3x3x3 convolution of volumes stored as stacks of depth + 2 slices, one launch (depth taps inside the K loop of
     csrc/drunet_split2d.hip); wsplit from pack_split3d_weight; x / y / res1 are views whose first plane is a volume's
     leading zero slice, with one more readable plane on each side of x"""
-    flags = (1 if x_presplit else 0) | (2 if y_presplit else 0) | (4 if relu else 0)
+    flags = (1 if x_presplit else 0) | (2 if y_presplit else 0) | (4 if relu else 0) | (8 if gate else 0)   # gate: y = res1 > 0 ? conv : 0
     check(_l().dinv_conv3x3x3_split(ctypes.byref(g), ptr(x), ptr(wsplit), cin, cout, ptr(y), ptr(res1), flags, int(depth),
                                     stream_ptr(y.device)))
 

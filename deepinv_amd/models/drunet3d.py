@@ -98,9 +98,10 @@ def _cached(kind, w, dz, make):
 
 
 def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=False, x_presplit=False,
-          y_presplit=False) -> Vol:
+          y_presplit=False, gate: Vol | None = None) -> Vol:
     """3x3x3 convolution, stride 1, zero padding 1, no bias; w5 [Cout, Cin, 3, 3, 3] (true channel counts).
-    flip: convolve with the transposed, tap-reversed filter instead (the data gradient of the same layer).
+    flip: convolve with the transposed, tap-reversed filter instead (the data gradient of the same layer);
+    gate: the forward pass's ReLU output whose sign masks the result (ReLU backward).
     ONE launch either way (the depth taps are part of the kernel's K loop, ReLU and the zero padding slices in its
     epilogue): bf16-split arithmetic (csrc/drunet_split2d.hip) or fp32 (csrc/drunet.hip: thin head / tail layers and the
     mask-exact training forward; layers of <= 16 output channels on the 16x16x4 MFMA tile)"""
@@ -108,13 +109,16 @@ def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=F
     y = Vol(lv, cout, x.t.device)
     if cin >= 16 and cout >= 16 and not fp32:
         pk = _cached(("c3x3", flip), w5, 0, lambda: K.pack_split3d_weight(_pad_w(_flip_t(w5) if flip else w5, _r64(cout), _r16(cin))))
-        K.conv3x3x3_split(lv.g, x.view(), pk, _r16(cin), _r64(cout), y.view(), lv.D, res1=res.view() if res is not None else None,
-                          relu=relu, x_presplit=x_presplit, y_presplit=y_presplit)
+        r1 = gate if gate is not None else res
+        K.conv3x3x3_split(lv.g, x.view(), pk, _r16(cin), _r64(cout), y.view(), lv.D, res1=r1.view() if r1 is not None else None,
+                          relu=relu, x_presplit=x_presplit, y_presplit=y_presplit, gate=gate is not None)
         return y
     assert not (x_presplit or y_presplit)
     pk, cip, cop = _cached(("c3f", flip), w5, 0, lambda: K.pack_conv3x3x3_weight(_flip_t(w5) if flip else w5))
     K.conv3x3x3(lv.g, x.view(), pk, cip, cop, y.view(), lv.D, cout_valid=cout, res1=res.view() if res is not None else None,
                 relu=relu)
+    if gate is not None:
+        K.relu_backward(gate.t, y.t)
     return y
 
 
@@ -248,8 +252,7 @@ class DRUNet3dFunction(torch.autograd.Function):
                 n1, n2 = f"{_blk(model, prefix, k)}.res.0.weight", f"{_blk(model, prefix, k)}.res.2.weight"
                 if want_w:
                     keep(n2, wgrad3(l, gout, a1, W[n2].shape[0], W[n2].shape[1]))
-                gt = conv3(l, W[n2], gout, flip=True)
-                K.relu_backward(a1.t, gt.t)
+                gt = conv3(l, W[n2], gout, flip=True, gate=a1)       # ReLU backward in the epilogue (gate = the forward activation)
                 if want_w:
                     keep(n1, wgrad3(l, gt, x_in, W[n1].shape[0], W[n1].shape[1]))
                 gout = conv3(l, W[n1], gt, res=gout, flip=True)

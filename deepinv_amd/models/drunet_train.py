@@ -66,19 +66,22 @@ def _fp32_forward(model) -> bool:
     return v == "fp32"
 
 
-def _conv3(g, w, x, relu=False, res1=None, fp32=False, flip=False):
+def _conv3(g, w, x, relu=False, res1=None, fp32=False, flip=False, gate=None):
     """y = [relu](conv3x3(x, w)) (+ res1) on activation buffers; bf16-split kernel where the shapes allow it.
     flip: convolve with the transposed, tap-reversed filter (the data gradient of the same layer); packs are cached per
-    weight tensor and version (hip/drunet.py: cached_pack)"""
+    weight tensor and version (hip/drunet.py: cached_pack).  gate: the forward pass's ReLU output whose sign masks the
+    result (ReLU backward fused into the epilogue of the data-gradient convolution)"""
     cout, cin = (w.shape[1], w.shape[0]) if flip else w.shape[:2]
     y = K.alloc(g, cout, x.device)
     src = lambda: _flip_t(w) if flip else w  # noqa: E731
     if cout % 64 == 0 and cin % 16 == 0 and not fp32:
-        K.conv3x3_split(g, x, K.cached_pack(("c3s", flip), w, lambda: K.pack_split2d_weight(src())), cin, cout, y, res1=res1,
-                        relu=relu)
+        K.conv3x3_split(g, x, K.cached_pack(("c3s", flip), w, lambda: K.pack_split2d_weight(src())), cin, cout, y,
+                        res1=gate if gate is not None else res1, relu=relu, gate=gate is not None)
     else:
         wpk, ci_p, co_p = K.cached_pack(("c3d", flip), w, lambda: K.pack_conv3x3_weight(src()))
         K.conv3x3(g, x, wpk, ci_p, co_p, y, cout_valid=cout, res1=res1, relu=relu)
+        if gate is not None:
+            K.relu_backward(gate, y)
     return y
 
 
@@ -184,8 +187,7 @@ class DRUNetFunction(torch.autograd.Function):
                 x_in, a1 = saved["res"][f"{prefix}.{k}"]
                 w1, w2 = W[f"{_blk(model, prefix, k)}.res.0.weight"], W[f"{_blk(model, prefix, k)}.res.2.weight"]
                 wgrad(f"{_blk(model, prefix, k)}.res.2.weight", gl, gl, gout, a1, 9)
-                gt = _conv3(gl, w2, gout, flip=True)
-                K.relu_backward(a1, gt)
+                gt = _conv3(gl, w2, gout, flip=True, gate=a1)
                 wgrad(f"{_blk(model, prefix, k)}.res.0.weight", gl, gl, gt, x_in, 9)
                 gout = _conv3(gl, w1, gt, res1=gout, flip=True)
             return gout

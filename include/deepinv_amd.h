@@ -176,6 +176,8 @@ int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w
  * flags: bit 0  x is PRE-SPLIT: each pixel's 8-channel block holds 8 bf16 high parts then 8 bf16 low parts in the 32 bytes
  *               an fp32 block occupies (what this kernel would split an fp32 block into);
  *        bit 1  write y pre-split (no residual then);  bit 2  ReLU (no residual then);
+ *        bit 3  GATE: res1 is not added but gates the output, y = res1 > 0 ? conv : 0 (the data gradient through the ReLU of
+ *               a ResBlock: res1 = the forward pass's ReLU output; replaces a separate dinv_relu_backward pass; fp32 in / out);
  *        bits 8-9  pixels per workgroup: 0 = chosen from the grid size, 1 = 128, 2 = 256.
  * In a ResBlock (drunet.py:403-434) conv1 runs with flags 2|4 into a scratch buffer that conv2 reads with flag 1 and res1 = x.
  * The geometry must come from dinv_act_geom_init of this library version (trailing slack for the halo rows of the last tile). */

@@ -8,3 +8,5 @@ rocprofv3 --kernel-trace --stats -d $R/prof_cfg4b -o cfg4 --output-format csv --
 N=3 python $GRAFT_REPO_ROOT/scripts/r03/prof_cfg4.py > $R/r03_cfg4b_plain.json 2>&1
 N=3 python $GRAFT_REPO_ROOT/scripts/r03/prof_cfg4.py bf16split > $R/r03_cfg4b_bf16split.json 2>&1
 tail -1 $R/r03_cfg4b_plain.json $R/r03_cfg4b_bf16split.json
+timeout 600 python $GRAFT_REPO_ROOT/scripts/bench_train.py > $R/r03_train_step.jsonl 2>&1
+tail -n 3 $R/r03_train_step.jsonl | cut -c1-300

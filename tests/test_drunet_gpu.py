@@ -329,7 +329,7 @@ def test_drunet_hip_backward_unit_gain_linearised(dev, monkeypatch):
         if hasattr(m, "res"):
             m.res[1] = torch.nn.Identity()
     conv3 = T._conv3
-    monkeypatch.setattr(T, "_conv3", lambda g, w, x, relu=False, res1=None, fp32=False, flip=False: conv3(g, w, x, False, res1, fp32, flip))
+    monkeypatch.setattr(T, "_conv3", lambda g, w, x, relu=False, res1=None, fp32=False, flip=False, gate=None: conv3(g, w, x, False, res1, fp32, flip))
     monkeypatch.setattr(K, "relu_backward", lambda act, grad: grad)
     y_t, gx_t, gs_t, gw_t = _grad_run(model, x0, sig0, v, "torch", monkeypatch)
     y_h, gx_h, gs_h, gw_h = _grad_run(model, x0, sig0, v, "hip", monkeypatch)

@@ -68,7 +68,8 @@ def split_from_act(a, g, C):
 @pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 12, 20, 16, 64, "plain"), (2, 9, 14, 32, 64, "relu"),
                                                  (1, 17, 33, 32, 128, "res"), (3, 16, 16, 64, 64, "plain"),
                                                  (1, 8, 32, 16, 64, "relu"), (2, 40, 48, 16, 128, "res"),
-                                                 (2, 40, 64, 32, 64, "res")])
+                                                 (2, 40, 64, 32, 64, "res"), (2, 9, 14, 32, 64, "gate"),
+                                                 (1, 17, 33, 16, 128, "gate")])
 @pytest.mark.parametrize("fmt", ["f32", "in_split", "out_split"])
 @pytest.mark.parametrize("tile", [1, 2])     # 128- / 256-pixel workgroups
 def test_split2d_conv_matches_fp64(B, H, W, cin, cout, mode, fmt, tile):
@@ -76,6 +77,8 @@ def test_split2d_conv_matches_fp64(B, H, W, cin, cout, mode, fmt, tile):
     16 / 8 incl. partial column tiles (W = 20, 14, 33) and row tiles that straddle images"""
     if fmt == "out_split" and mode == "res":
         pytest.skip("a pre-split output carries no residual")
+    if mode == "gate" and fmt != "f32":
+        pytest.skip("the gate (ReLU backward in the epilogue) is an fp32 in / out mode")
     gen = torch.Generator().manual_seed(H * W + cin)
     x = torch.randn(B, cin, H, W, generator=gen)
     w = torch.randn(cout, cin, 3, 3, generator=gen) / (3.0 * cin ** 0.5)
@@ -94,6 +97,9 @@ def test_split2d_conv_matches_fp64(B, H, W, cin, cout, mode, fmt, tile):
         ref = ref.relu()
     if mode == "res":
         ref = ref + r.double()
+    if mode == "gate":        # y = r > 0 ? conv : 0  (r = the ReLU output of the forward pass)
+        r = r.relu()
+        ref = ref * (r > 0)
     ra = to_act(r, g)
     ya = torch.full((cout // 8, g.cs, 8), float("nan"))
     ya[:, :g.sl] = 0
@@ -102,9 +108,10 @@ def test_split2d_conv_matches_fp64(B, H, W, cin, cout, mode, fmt, tile):
     ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, :, W + 1:] = 0
     wp = pack_split2d_weight(w)
     flags = (1 if fmt == "in_split" else 0) | (2 if fmt == "out_split" else 0) | (4 if mode == "relu" else 0) | (tile << 8)
+    flags |= 8 if mode == "gate" else 0
     l = E.lib()
     E.check(l.dinv_conv3x3_split(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya),
-                                 E.p(ra) if mode == "res" else None, flags, None))
+                                 E.p(ra) if mode in ("res", "gate") else None, flags, None))
     assert not torch.isnan(ya).any()
     out = split_from_act(ya, g, cout) if fmt == "out_split" else from_act(ya, g, cout)
     err = float((out.double() - ref).norm() / ref.norm())
