@@ -1,5 +1,5 @@
 """One training step (forward + backward) of unfolded PnP-PGD with a DRUNet prior on 2-D multi-coil MRI:
-the hand-written DRUNet backward (DINV_DRUNET_TRAIN=hip, models/drunet_train.py) vs the PyTorch-ROCm graph (MIOpen).
+the hand-written DRUNet backward (DRUNet.backend = "hip", models/drunet_train.py) vs the PyTorch-ROCm graph (MIOpen).
 Usage: python scripts/bench_train.py [B] [iters]"""
 import json
 import os
@@ -35,10 +35,10 @@ def step():
     return loss
 
 
-for mode, prec in (("torch", ""), ("hip", "fp32"), ("hip", "bf16s")):
-    os.environ["DINV_DRUNET_TRAIN"] = mode
+for mode, prec in (("torch", ""), ("hip", "fp32"), ("hip", "bf16split")):
+    den.backend = mode
     if prec:
-        os.environ["DINV_DRUNET_TRAIN_PRECISION"] = prec
+        den.train_forward_precision = prec
     step()
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
