@@ -387,10 +387,12 @@ static int split_launch(const dinv_act_geom* g, const void* x, const void* w_spl
              reinterpret_cast<float*>(y), res1, cin, 0, cout / 64, 0, 0, g->batch * g->hp,
              depth ? 3 : 1, depth ? depth + 2 : 0, g->plane * 8};
     // tile width: the widest of 32 / 16 / 8 that divides the image width (DRUNet levels: 320 -> 32, 160 -> 32, 80 -> 16,
-    // 40 -> 8); tiles of 128 pixels when 256-pixel tiles would leave the 512 resident workgroup slots under-filled
+    // 40 -> 8); tiles of 128 pixels only when 256-pixel tiles would fill less than three quarters of the 512 resident
+    // workgroup slots (measured per level at B = 4 / 8, profiles/r03_tile_size_ab.jsonl: 240 workgroups -> 128 px wins by
+    // 13 %, 420 / 440 -> 256 px wins by 16-18 %)
     const int tc = g->width % 32 == 0 ? 32 : (g->width % 16 == 0 ? 16 : 8);
     const int64_t n256 = ceil_div((int64_t)g->batch * g->hp, 256 / tc) * ceil_div(g->width, tc) * (cout / 64);
-    const int nrep = ((flags >> 8) & 3) ? ((flags >> 8) & 3) : (n256 >= 768 ? 2 : 1);
+    const int nrep = ((flags >> 8) & 3) ? ((flags >> 8) & 3) : (n256 >= 384 ? 2 : 1);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (in_split) {
         if (relu) return dispatch_tile<true, false, true, 0>(a, tc, nrep, st);
