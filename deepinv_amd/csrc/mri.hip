@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void mri_rows_combine_kernel(const float2* __r
                                                                int ncoil, int maps_batch, int lpb,
                                                                dinv_fft_plan plan, const void* table,
                                                                int centered, float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DINV_DYN_LDS(unsigned char, smem);
     const int N = plan.n;
     const int LS = (N % 2 == 0) ? N + 1 : N;
     const int tid = threadIdx.x;
