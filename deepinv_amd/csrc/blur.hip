@@ -41,7 +41,7 @@ __device__ __forceinline__ int pad_map(int q, int n, int mode) {
 // y[b,c,io,jo] = sum_{u,v} kf[u,v] * xpad[io*s+u, jo*s+v],  kf[u,v] = k[h-1-u, w-1-v]
 __global__ __launch_bounds__(256) void conv2d_pad_kernel(ConvGeom g, const float* __restrict__ x,
                                                          const float* __restrict__ k, float* __restrict__ y) {
-    extern __shared__ float ks[];  // flipped filter of this (b,c)
+    DINV_DYN_LDS(float, ks);  // flipped filter of this (b,c)
     const int bc = blockIdx.z, b = bc / g.C, c = bc % g.C;
     const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * g.h * g.w;
     for (int i = threadIdx.x; i < g.h * g.w; i += 256) ks[i] = kf[g.h * g.w - 1 - i];
@@ -90,7 +90,7 @@ __device__ __forceinline__ Pre preimages(int t, int n, int p0, int p1, int mode)
 __global__ __launch_bounds__(256) void conv2d_pad_transpose_kernel(ConvGeom g, const float* __restrict__ y,
                                                                    const float* __restrict__ k,
                                                                    float* __restrict__ x) {
-    extern __shared__ float ks[];
+    DINV_DYN_LDS(float, ks);
     const int bc = blockIdx.z, b = bc / g.C, c = bc % g.C;
     const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * g.h * g.w;
     for (int i = threadIdx.x; i < g.h * g.w; i += 256) ks[i] = kf[g.h * g.w - 1 - i];

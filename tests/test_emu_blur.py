@@ -1,0 +1,82 @@
+"""csrc/blur.hip on the host emulation (tests/emu): padded true convolution with stride (Blur / Downsampling.A), its exact
+transpose (dot test), and the real <-> half-complex 2-D FFT of BlurFFT, against fp64 references - CPU-only coverage of the
+kernel sources (deepinv/physics/functional/convolution.py:42-164, 689-758; deepinv/physics/blur.py:255-329, 639-657)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import emu_lib as E
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("channels", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("fbatch", ctypes.c_int32), ("fchannels", ctypes.c_int32), ("fh", ctypes.c_int32), ("fw", ctypes.c_int32),
+                ("mode", ctypes.c_int32), ("stride", ctypes.c_int32)]
+
+
+MODES = {"valid": 0, "circular": 1, "reflect": 2, "replicate": 3, "constant": 4}
+
+
+def _ref_conv(x, k, mode, stride):
+    """true convolution (flipped filter) of the padded image, deepinv's `conv2d` (convolution.py:42-107), then [::s, ::s]"""
+    B, C, H, W = x.shape
+    fh, fw = k.shape[-2:]
+    x, k = x.double(), k.double().expand(-1, C, -1, -1) if k.shape[1] != C else k.double()
+    if mode != "valid":
+        ph, pw = fh // 2, fw // 2
+        pad = (pw, pw - (1 - fw % 2), ph, ph - (1 - fh % 2))       # deepinv pads ih = (h-1)//2 .. : the odd / even split below
+        pad = ((fw - 1) // 2, fw // 2, (fh - 1) // 2, fh // 2)
+        x = torch.nn.functional.pad(x, pad, mode=mode if mode != "constant" else "constant", value=0)
+    out = []
+    for b in range(B):
+        kb = k[b if k.shape[0] > 1 else 0]
+        out.append(torch.nn.functional.conv2d(x[b:b + 1], torch.flip(kb, (-2, -1))[:, None], groups=C))
+    y = torch.cat(out, 0)
+    return y[:, :, ::stride, ::stride]
+
+
+@pytest.mark.parametrize("mode", ["valid", "circular", "reflect", "replicate", "constant"])
+@pytest.mark.parametrize("shape", [(2, 3, 12, 15, 1, 1, 3, 3, 1), (1, 2, 16, 16, 1, 2, 5, 5, 2), (2, 1, 20, 12, 2, 1, 4, 4, 4),
+                                   (1, 3, 9, 11, 1, 3, 3, 5, 1)])
+def test_conv2d_and_transpose_emulated(mode, shape):
+    B, C, H, W, fb, fc, fh, fw, s = shape
+    gen = torch.Generator().manual_seed(H * W + fh)
+    x = torch.randn(B, C, H, W, generator=gen)
+    k = torch.randn(fb, fc, fh, fw, generator=gen)
+    l = E.lib()
+    d = ConvDesc(B, C, H, W, fb, fc, fh, fw, MODES[mode], s)
+    ho, wo = ctypes.c_int32(), ctypes.c_int32()
+    E.check(l.dinv_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)))
+    y = torch.full((B, C, ho.value, wo.value), float("nan"))
+    E.check(l.dinv_conv2d(ctypes.byref(d), E.p(x), E.p(k), E.p(y), None))
+    ref = _ref_conv(x, k, mode, s)
+    assert tuple(ref.shape) == tuple(y.shape), (ref.shape, y.shape)
+    assert float((y.double() - ref).norm() / ref.norm()) < 2e-6
+    # exact transpose: <A x, v> = <x, A^T v>
+    v = torch.randn(*y.shape, generator=gen)
+    xt = torch.full((B, C, H, W), float("nan"))
+    E.check(l.dinv_conv2d_transpose(ctypes.byref(d), E.p(v), E.p(k), E.p(xt), None))
+    lhs, rhs = float((y.double() * v.double()).sum()), float((x.double() * xt.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("H,W", [(16, 32), (12, 20), (32, 64), (9, 14)])
+def test_rfft2_irfft2_emulated(H, W):
+    P = 3
+    gen = torch.Generator().manual_seed(H + W)
+    x = torch.randn(P, H, W, generator=gen)
+    l = E.lib()
+    ph, th = E.fft_plan(H)
+    pw, tw = E.fft_plan(W)
+    out = torch.full((P, H, W // 2 + 1, 2), float("nan"))
+    E.check(l.dinv_rfft2(E.p(x), E.p(out), ctypes.c_int64(P), ctypes.byref(ph), E.p(th), ctypes.byref(pw), E.p(tw),
+                         ctypes.c_float(1.0), None))
+    ref = torch.view_as_real(torch.fft.rfft2(x.double()))
+    assert float((out.double() - ref).norm() / ref.norm()) < 2e-6
+    back = torch.full((P, H, W), float("nan"))
+    ws = np.zeros(P * H * (W // 2 + 1) * 8, np.uint8)
+    E.check(l.dinv_irfft2(E.p(out), E.p(back), ctypes.c_int64(P), ctypes.byref(ph), E.p(th), ctypes.byref(pw), E.p(tw),
+                          ctypes.c_float(1.0 / (H * W)), E.p(ws), ctypes.c_size_t(ws.size), None))
+    assert float((back.double() - x.double()).norm() / x.double().norm()) < 2e-6
