@@ -26,7 +26,7 @@ xin = torch.cat((x0, sig0), 1).double().requires_grad_(True)
 gw_ref = {n: p.grad for n, p in ref.named_parameters()}
 
 def run(mode):
-    os.environ["DINV_DRUNET_TRAIN"] = mode
+    model.backend = mode
     model.zero_grad()
     x = x0.to(dev).requires_grad_(True)
     sig = sig0.to(dev).requires_grad_(True)
