@@ -32,6 +32,7 @@ def _l():
         l.dinv_conv3x3_tail.argtypes = [G, vp, vp, vp, i32, i32, vp, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
+        l.dinv_conv3x3_wsplit.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
         l.dinv_conv3x3x3.argtypes = [G, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
@@ -112,6 +113,24 @@ def pack_split2d_weight(w: torch.Tensor) -> torch.Tensor:
     perm = split2d_row_perm().to(packed.device)
     idx = torch.cat((perm, 32 + perm))
     return packed.index_select(6, idx).contiguous()
+
+
+def pack_wsplit_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> Winograd F(2,3) weights along the kernel columns, U0 = g0, U1 = (g0+g1+g2)/2,
+    U2 = (g0-g1+g2)/2, U3 = g2 per kernel row (fp64, rounded once to fp32), two-part bf16 split, packed for
+    csrc/drunet_wsplit.hip as MFMA A fragments: [Cout/64][Cin/16][dy 3][point 4][m 2][plane 2][cblk 2][row 32][ci 8] (bf16),
+    rows of each 32-row tile permuted by `split2d_row_perm`"""
+    cout, cin = w.shape[:2]
+    if cin % 16 or cout % 64:
+        raise ValueError(f"Winograd bf16-split packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
+    g = w.detach().double()                                                     # [co, ci, dy, dx]
+    u = torch.stack((g[..., 0], (g[..., 0] + g[..., 1] + g[..., 2]) / 2, (g[..., 0] - g[..., 1] + g[..., 2]) / 2, g[..., 2])).float()
+    hi = u.bfloat16()
+    lo = (u - hi.float()).bfloat16()
+    planes = torch.stack((hi, lo))                                               # [pl 2, k 4, co, ci, dy 3]
+    planes = planes.reshape(2, 4, cout // 64, 2, 32, cin // 16, 2, 8, 3)         # pl, k, ct, m, r, s, cblk, ci, dy
+    planes = planes.index_select(4, split2d_row_perm().to(planes.device))
+    return planes.permute(2, 5, 8, 1, 3, 0, 6, 4, 7).contiguous()               # ct, s, dy, k, m, pl, cblk, r, ci
 
 
 def pack_split3d_weight(w5: torch.Tensor) -> torch.Tensor:
@@ -301,6 +320,20 @@ def conv3x3_split(g, x, wsplit, cin, cout, y, res1=None, relu=False, x_presplit=
         e1.record()
         fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
         _prof.append((e0, e1, "conv3x3_split2d_kernel", fl, 3.0 * fl))
+
+
+def conv3x3_wsplit(g, x, wws, cin, cout, y, res1=None, relu=False):
+    """y = [relu](conv3x3(x)) (+res1): Winograd F(2,3) along rows on the bf16 matrix cores, two-part operand split
+    (csrc/drunet_wsplit.hip); wws from pack_wsplit_weight; even image width"""
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_l().dinv_conv3x3_wsplit(ctypes.byref(g), ptr(x), ptr(wws), cin, cout, ptr(y), ptr(res1), 4 if relu else 0,
+                                   stream_ptr(y.device)))
+    if _prof is not None:
+        e1.record()
+        fl = 2.0 * 9 * cin * cout * g.batch * g.height * g.width
+        _prof.append((e0, e1, "conv3x3_wsplit_kernel", fl, 2.0 * fl))      # 12 of 18 multiplies, three products each
 
 
 def conv3x3x3_split(g, x, wsplit, cin, cout, y, depth, res1=None, relu=False, x_presplit=False, y_presplit=False, gate=False):

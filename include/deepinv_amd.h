@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 3 = this header (2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 4 = this header (3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -183,6 +183,14 @@ int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w
  * The geometry must come from dinv_act_geom_init of this library version (trailing slack for the halo rows of the last tile). */
 int dinv_conv3x3_split(const dinv_act_geom* g, const void* x, const void* w_split, int32_t cin, int32_t cout, void* y,
                        const float* res1, int32_t flags, dinv_stream_t stream);
+/* The same operator (fp32 in / out; replaces the two 3x3 convolutions of a ResBlock, drunet.py:403-434) as Winograd F(2,3)
+ * along image rows on the bf16 matrix cores with the same two-part operand split: 12 instead of 18 three-product multiplies
+ * per output pixel pair, input channel and kernel row (csrc/drunet_wsplit.hip).  Needs an even image width.
+ * w_wsplit: [cout/64][cin/16][dy 3][point 4][m 2][plane hi/lo][lane 64][8] bf16 holding U0 = g0, U1 = (g0+g1+g2)/2,
+ *   U2 = (g0-g1+g2)/2, U3 = g2 of kernel row dy (formed in fp64, then split), lane = 32 (ci / 8 % 2) + row, rows permuted as
+ *   for dinv_conv3x3_split (deepinv_amd/hip/drunet.py: pack_wsplit_weight).  flags: bit 2 ReLU (no residual then). */
+int dinv_conv3x3_wsplit(const dinv_act_geom* g, const void* x, const void* w_wsplit, int32_t cin, int32_t cout, void* y,
+                        const float* res1, int32_t flags, dinv_stream_t stream);
 /* 3x3x3 convolution (nn.Conv3d in DRUNet(dim=3), drunet.py:39-263) of volumes stored as stacks of depth + 2 slices
  * (g->batch = volumes x (depth + 2), one zero slice at each end of a volume) in ONE launch: the K loop of
  * dinv_conv3x3_split also runs over the three depth taps (tap dz reads the slices shifted by dz - 1), the padding slices of

@@ -122,6 +122,56 @@ def test_split2d_conv_matches_fp64(B, H, W, cin, cout, mode, fmt, tile):
     assert float(full[:, :, :, 0].abs().max()) == 0 and float(full[:, :, :, W + 1:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 12, 20, 16, 64, "plain"), (2, 9, 14, 32, 64, "relu"),
+                                                 (1, 17, 34, 32, 128, "res"), (3, 16, 16, 64, 64, "plain"),
+                                                 (1, 8, 32, 16, 64, "relu"), (2, 40, 48, 16, 128, "res"),
+                                                 (2, 40, 64, 32, 64, "res"), (1, 36, 8, 48, 64, "relu"), (1, 5, 6, 16, 64, "plain")])
+def test_wsplit_conv_matches_fp64(B, H, W, cin, cout, mode):
+    """csrc/drunet_wsplit.hip (Winograd F(2,3) along rows, bf16-split operands, wave = Winograd point, cross-wave exchange in
+    the epilogue) against an fp64 convolution; tile widths 32 / 16 / 8 incl. partial column tiles (W = 20, 14, 34, 6), row
+    tiles that straddle images, odd step counts (cin = 16, 48)"""
+    gen = torch.Generator().manual_seed(H * W + cin)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / (3.0 * cin ** 0.5)
+    r = torch.randn(B, cout, H, W, generator=gen)
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_wsplit_weight
+    g = geom(B, H, W)
+    xa = to_act(x, g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+    ra = to_act(r, g)
+    ya = torch.full((cout // 8, g.cs, 8), float("nan"))
+    ya[:, :g.sl] = 0
+    ya[:, g.sl + g.np:] = 0
+    ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, :, 0] = 0        # frame columns are never written: must stay zero
+    ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, :, W + 1:] = 0
+    wp = pack_wsplit_weight(w)
+    l = E.lib()
+    E.check(l.dinv_conv3x3_wsplit(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya),
+                                  E.p(ra) if mode == "res" else None, 4 if mode == "relu" else 0, None))
+    assert not torch.isnan(ya).any()
+    out = from_act(ya, g, cout)
+    err = float((out.double() - ref).norm() / ref.norm())
+    assert err < 2e-5, err
+    full = ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
+    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, H + 1].abs().max()) == 0
+    assert float(full[:, :, :, 0].abs().max()) == 0 and float(full[:, :, :, W + 1:].abs().max()) == 0
+
+
+def test_wsplit_rejects_odd_width():
+    g = geom(1, 8, 9)
+    l = E.lib()
+    x = torch.zeros((2, g.cs, 8))
+    y = torch.zeros((8, g.cs, 8))
+    w = torch.zeros(64 * 16 * 9 * 4, dtype=torch.bfloat16)
+    assert l.dinv_conv3x3_wsplit(ctypes.byref(g), E.p(x), ctypes.c_void_p(w.data_ptr()), 16, 64, E.p(y), None, 0, None) != 0
+
+
 def wide_range(shape, lo_exp, hi_exp, gen):
     """random signs and mantissas, exponents uniform in [lo_exp, hi_exp]: operands spanning many binades"""
     e = torch.randint(lo_exp, hi_exp + 1, shape, generator=gen).float()
