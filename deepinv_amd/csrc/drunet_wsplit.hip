@@ -60,6 +60,37 @@ __device__ __forceinline__ uint4 as_u4(const f32x16& v, int q) {
     return make_uint4(__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]), __float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 3]));
 }
 
+// two fp32 -> two bf16 (round to nearest even) in one v_cvt_pk_bf16_f32, first value in the low half
+__device__ __forceinline__ unsigned cvt2(float v0, float v1) {
+#ifdef DINV_EMU
+    return f2bf(v0) | (f2bf(v1) << 16);
+#else
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {v0, v1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+#endif
+}
+// split8 of drunet_split_common.hpp with the conversions paired by hand (this file is compiled without SLP vectorisation)
+__device__ __forceinline__ void split8p(const float4& a, const float4& b, uint4& hi, uint4& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = cvt2(v[2 * e], v[2 * e + 1]);
+        l[e] = cvt2(v[2 * e] - __uint_as_float(h[e] << 16), v[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u));
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// keeps the instruction scheduler from sinking a group of global loads down to their first use (it does, to save
+// registers - and the loads then pay their whole latency inside the MFMA stream)
+__device__ __forceinline__ void sched_fence() {
+#ifndef DINV_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 template <bool RELU, int NRES, int TC>
 __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     using T = TileW<TC>;
@@ -84,10 +115,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    // ---- transform tasks of this thread: task q = (cblk, row, pair) of the halo region reads the four pixels 2 pair - 1 ..
-    // 2 pair + 2 (tile coordinates) of one row: slot 0 = task tid (every thread), slot 1 = task 256 + lane (the NTASK - 256
-    // remaining ones, taken by wave `step & 3` so that the extra work rotates over the waves)
-    int xoff0, voff0, xoff1, voff1;
+    // ---- transform tasks: task q = (cblk, row, pair) of the halo region reads the four pixels d0..d3 = columns 2 pair - 1 ..
+    // 2 pair + 2 (tile coordinates) of one row and produces the four points.  Thread tid owns task tid (all four points); the
+    // NTASK - 256 tasks of the last halo rows are cut by POINT: wave k computes V_k of task 256 + lane from the two pixels
+    // that point needs - every wave carries the same vector work (a whole extra task per thread of one wave made that
+    // wave the slowest one of every step)
+    int xoff0, voff0, xoffa, xoffb, voffe;
     {
         const int q = tid;
         const int cb = q / VPL, rem = q - cb * VPL, row = rem / PC, pr = rem - row * PC;
@@ -95,11 +128,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
         voff0 = cb * 4 * VPL + row * PC + pr;
     }
     const bool has1 = 256 + lane < NTASK;
+    const float esgn = k == 1 ? 1.f : -1.f;              // V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3
     {
         const int q = has1 ? 256 + lane : NTASK - 1;     // clamped: lanes without a task load a valid address and write nothing
         const int cb = q / VPL, rem = q - cb * VPL, row = rem / PC, pr = rem - row * PC;
-        xoff1 = (int)(((int64_t)cb * a.g.cs + a.g.sl + (int64_t)(r0 - 1 + row) * a.g.wp + (c0 - 1 + 2 * pr)) * 8);
-        voff1 = cb * 4 * VPL + row * PC + pr;
+        const int base = (int)(((int64_t)cb * a.g.cs + a.g.sl + (int64_t)(r0 - 1 + row) * a.g.wp + (c0 - 1 + 2 * pr)) * 8);
+        xoffa = base + 8 * (k == 0 ? 0 : k == 2 ? 2 : 1);
+        xoffb = base + 8 * (k == 2 ? 1 : k == 3 ? 3 : 2);
+        voffe = (cb * 4 + k) * VPL + row * PC + pr;
     }
     const int64_t step_stride = (int64_t)2 * a.g.cs * 8;      // floats per 16-channel step
 
@@ -114,27 +150,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     // A operand fragments of this wave's point, straight from the packed weights
     const uint4* const wsrc = a.w + (int64_t)ty * nsub * WSUB + k * 256 + lane;
 
-    uint4 d0a, d0b, d1a, d1b, d2a, d2b, d3a, d3b;     // the four pixels of a transform task (8 channels each)
-    auto ldd = [&](int s, int xo) {
-        const float* p = a.x + (int64_t)s * step_stride + xo;
+    uint4 d0a, d0b, d1a, d1b, d2a, d2b, d3a, d3b;     // the four pixels of this thread's task (8 channels each)
+    uint4 eaa, eab, eba, ebb;                         // the two pixels of this wave's point of an extra task
+    auto ldd = [&](int s) {
+        const float* p = a.x + (int64_t)s * step_stride + xoff0;
         d0a = ldu4(p);      d0b = ldu4(p + 4);
         d1a = ldu4(p + 8);  d1b = ldu4(p + 12);
         d2a = ldu4(p + 16); d2b = ldu4(p + 20);
         d3a = ldu4(p + 24); d3b = ldu4(p + 28);
     };
-    auto putv = [&](uint4* vb, int vo, bool wr) {
-        const float4 f0a = as_f4(d0a), f0b = as_f4(d0b), f1a = as_f4(d1a), f1b = as_f4(d1b);
-        const float4 f2a = as_f4(d2a), f2b = as_f4(d2b), f3a = as_f4(d3a), f3b = as_f4(d3b);
-        uint4 h0, l0, h1, l1, h2, l2, h3, l3;
-        split8(sub4(f0a, f2a), sub4(f0b, f2b), h0, l0);
-        split8(add4(f1a, f2a), add4(f1b, f2b), h1, l1);
-        split8(sub4(f2a, f1a), sub4(f2b, f1b), h2, l2);
-        split8(sub4(f1a, f3a), sub4(f1b, f3b), h3, l3);
-        if (wr) {
-            vb[vo] = h0;           vb[vo + 8 * VPL] = l0;
-            vb[vo + VPL] = h1;     vb[vo + 9 * VPL] = l1;
-            vb[vo + 2 * VPL] = h2; vb[vo + 10 * VPL] = l2;
-            vb[vo + 3 * VPL] = h3; vb[vo + 11 * VPL] = l3;
+    auto lde = [&](int s) {
+        const float* p = a.x + (int64_t)s * step_stride;
+        eaa = ldu4(p + xoffa); eab = ldu4(p + xoffa + 4);
+        eba = ldu4(p + xoffb); ebb = ldu4(p + xoffb + 4);
+    };
+    auto putv01 = [&](uint4* vb) {      // points 0 and 1 of the thread's task
+        const float4 f0a = as_f4(d0a), f0b = as_f4(d0b), f1a = as_f4(d1a), f1b = as_f4(d1b), f2a = as_f4(d2a), f2b = as_f4(d2b);
+        uint4 h0, l0, h1, l1;
+        split8p(sub4(f0a, f2a), sub4(f0b, f2b), h0, l0);
+        split8p(add4(f1a, f2a), add4(f1b, f2b), h1, l1);
+        vb[voff0] = h0;           vb[voff0 + 8 * VPL] = l0;
+        vb[voff0 + VPL] = h1;     vb[voff0 + 9 * VPL] = l1;
+    };
+    auto putv23 = [&](uint4* vb) {      // points 2 and 3
+        const float4 f1a = as_f4(d1a), f1b = as_f4(d1b), f2a = as_f4(d2a), f2b = as_f4(d2b), f3a = as_f4(d3a), f3b = as_f4(d3b);
+        uint4 h2, l2, h3, l3;
+        split8p(sub4(f2a, f1a), sub4(f2b, f1b), h2, l2);
+        split8p(sub4(f1a, f3a), sub4(f1b, f3b), h3, l3);
+        vb[voff0 + 2 * VPL] = h2; vb[voff0 + 10 * VPL] = l2;
+        vb[voff0 + 3 * VPL] = h3; vb[voff0 + 11 * VPL] = l3;
+    };
+    auto pute = [&](uint4* vb) {        // this wave's point of the extra task: A + sgn B (exact: sgn = +-1)
+        const float4 fa0 = as_f4(eaa), fa1 = as_f4(eab), fb0 = as_f4(eba), fb1 = as_f4(ebb);
+        uint4 h, l;
+        split8p(make_float4(fmaf(esgn, fb0.x, fa0.x), fmaf(esgn, fb0.y, fa0.y), fmaf(esgn, fb0.z, fa0.z), fmaf(esgn, fb0.w, fa0.w)),
+                make_float4(fmaf(esgn, fb1.x, fa1.x), fmaf(esgn, fb1.y, fa1.y), fmaf(esgn, fb1.z, fa1.z), fmaf(esgn, fb1.w, fa1.w)), h, l);
+        if (has1) {
+            vb[voffe] = h;
+            vb[voffe + 8 * VPL] = l;
         }
     };
     auto lda = [&](int j, uint4& a00, uint4& a01, uint4& a10, uint4& a11) {     // [m][plane] of sub-step j = 3 step + dy
@@ -143,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     };
 
     // one kernel row of a step: 24 MFMAs; the B fragments of pair tile n + 1 are read while the six MFMAs of tile n run;
-    // smallest terms first (Uh*Vl, Ul*Vh, Uh*Vh)
+    // smallest terms first (Uh*Vl, Ul*Vh, Uh*Vh).  (Rotating over four accumulators instead of two measured the same.)
     auto mma = [&](const uint4* vs, const uint4& a00, const uint4& a01, const uint4& a10, const uint4& a11) {
         uint4 B[2][2];
         B[0][0] = vs[bslot[0]]; B[0][1] = vs[8 * VPL + bslot[0]];
@@ -160,38 +213,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
         }
     };
 
-    // ---- prologue: V of step 0, the weights of its first kernel row
+    // ---- prologue: V of step 0, the weights of its first kernel row, the extra-task pixels of step 1
     uint4 p00, p01, p10, p11, q00, q01, q10, q11;     // A fragments: current / next kernel row
     lda(0, p00, p01, p10, p11);
-    ldd(0, xoff0);
-    putv(lds, voff0, true);
-    if (k == 0) {
-        ldd(0, xoff1);
-        putv(lds, voff1, has1);
-    }
+    ldd(0);
+    lde(0);
+    putv01(lds);
+    putv23(lds);
+    pute(lds);
+    lde(nstep > 1 ? 1 : 0);
     __syncthreads();
 
     for (int s = 0; s < nstep; ++s) {
-        const bool more = s + 1 < nstep;
+        // straight-line step: the last steps stage their own channels once more into the idle V stage (no reader) instead of
+        // branching around the loads.  The transform of the next step's V is spread over the three kernel rows (32 / 64 / 64
+        // vector instructions beside 24 MFMAs each): bunched into one row it cost 10 % of the kernel, spread it is free
+        // (profiles/r03_wsplit_variants.jsonl)
+        const int sn = s + 1 < nstep ? s + 1 : s, sn2 = s + 2 < nstep ? s + 2 : nstep - 1;
         const uint4* const vcur = lds + (s & 1) * VSTAGE;
         uint4* const vnext = lds + ((s + 1) & 1) * VSTAGE;
-        const bool extra = more && k == ((s + 1) & 3);
         const int j = 3 * s;
-        // kernel row 0; slot-0 transform of the next step
+        // kernel row 0; the thread's four pixels of the next step are requested; extra-task point (its pixels came in a row ago)
         lda(j + 1, q00, q01, q10, q11);
-        if (more) ldd(s + 1, xoff0);
+        ldd(sn);
+        sched_fence();
         mma(vcur, p00, p01, p10, p11);
-        if (more) putv(vnext, voff0, true);
-        // kernel row 1; slot-1 transform of the next step (one wave)
+        pute(vnext);
+        sched_fence();
+        // kernel row 1; points 0, 1
         lda(j + 2, p00, p01, p10, p11);
-        if (extra) ldd(s + 1, xoff1);
         mma(vcur + PC, q00, q01, q10, q11);
-        if (extra) putv(vnext, voff1, has1);
-        // kernel row 2
-        lda(more ? j + 3 : j + 2, q00, q01, q10, q11);
+        putv01(vnext);
+        sched_fence();
+        // kernel row 2; points 2, 3; the extra-task pixels of the step after the next are requested
+        lda(j + 3 < nsub ? j + 3 : j + 2, q00, q01, q10, q11);
+        lde(sn2);
+        sched_fence();
         mma(vcur + 2 * PC, p00, p01, p10, p11);
+        putv23(vnext);
+        sched_fence();
         p00 = q00; p01 = q01; p10 = q10; p11 = q11;
-        if (more) lds_barrier();     // the next V stage is complete, every read of this one is done
+        lds_barrier();     // the next V stage is complete, every read of this one is done
     }
 
     // ---- epilogue: y(2j) = M0 + M1 + M2, y(2j+1) = M1 - M2 - M3.  Wave w finishes pair tile w; register quads 2q, 2q+1 of a
@@ -204,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     const int img = RR / a.g.hp, rr = RR - img * a.g.hp;
     const bool in = rr >= 1 && rr <= a.g.h;                // frame rows between images stay zero
     const int64_t opix = a.g.sl + (int64_t)RR * a.g.wp + cc;
-    lds_barrier();                                         // every V read is done: the stages become the exchange buffer
+    // (the barrier that ended the last step: every V read is done, the stages become the exchange buffer)
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         float4 rs[NRES >= 1 ? 8 : 1];

@@ -186,6 +186,53 @@ def test_split2d_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode, fmt):
     assert av[:, :, :, 0].abs().max() == 0 and av[:, :, :, W + 1:].abs().max() == 0
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(2, 24, 40, 64, 64, "plain"), (1, 17, 34, 32, 128, "relu"),
+                                                 (2, 16, 16, 128, 64, "res"), (3, 5, 6, 16, 64, "plain"),
+                                                 (1, 160, 160, 128, 128, "relu"), (2, 20, 20, 512, 512, "res"),
+                                                 (70, 4, 6, 32, 128, "plain"), (1, 2, 330, 64, 64, "res"),
+                                                 (2, 320, 320, 64, 64, "res"), (1, 80, 80, 48, 64, "relu")])
+def test_wsplit_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
+    """Winograd F(2,3) along rows on the bf16 matrix cores with the two-part operand split (csrc/drunet_wsplit.hip): three
+    products per Winograd multiply, a few 1e-6 per layer against fp64; tile widths 32 / 16 / 8 incl. partial column tiles, row
+    tiles that straddle images, many tiny images, a single long row, an odd number of 16-channel steps"""
+    from deepinv_amd.hip import drunet as K
+
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)).to(dev)
+    r = torch.randn(B, cout, H, W, generator=g).to(dev)
+    geo = K.geom(B, H, W)
+
+    def to_act(t):
+        a = K.alloc(geo, t.shape[1], dev)
+        av = a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+        av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    xa, ra, ya = to_act(x), to_act(r), K.alloc(geo, cout, dev)
+    ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:W + 1] = float("nan")   # every interior pixel is written
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+    K.conv3x3_wsplit(geo, xa, K.pack_wsplit_weight(w), cin, cout, ya, res1=ra if mode == "res" else None, relu=mode == "relu")
+    av = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+    out = av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W)
+    assert rel_err(out, ref) < 2e-5
+    assert av[:, :, 0].abs().max() == 0 and av[:, :, H + 1:].abs().max() == 0
+    assert av[:, :, :, 0].abs().max() == 0 and av[:, :, :, W + 1:].abs().max() == 0
+
+
+def test_wsplit_conv_rejects_odd_width(dev):
+    from deepinv_amd.hip import drunet as K
+
+    geo = K.geom(1, 8, 9)
+    xa, ya = K.alloc(geo, 16, dev), K.alloc(geo, 64, dev)
+    with pytest.raises(RuntimeError, match="even image width"):
+        K.conv3x3_wsplit(geo, xa, K.pack_wsplit_weight(torch.zeros(64, 16, 3, 3, device=dev)), 16, 64, ya)
+
+
 @pytest.mark.parametrize("case", ["wide", "he_scale"])
 def test_split_worst_case_bound(dev, case):
     """the operand split's worst-case bound element by element on the hardware kernel (the emulated twin of this test,
