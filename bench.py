@@ -181,7 +181,8 @@ def main():
         executed = kp["mfma_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
         all_ms = sum(v["ms"] for v in conv_prof.values())
         all_direct = sum(v["direct_flops"] for v in conv_prof.values())
-        dtype = "f32 in/out; ResBlock convs = bf16 x2 exact operand split (3 products), f32 accumulate"
+        dtype = ("f32 in/out; ResBlock convs = Winograd F(2,3) along rows, every multiply as bf16 x2 exact operand split (3 products), "
+                 "f32 accumulate") if "wsplit" in kname else "f32 in/out; ResBlock convs = bf16 x2 exact operand split (3 products), f32 accumulate"
         # HBM bytes per launch of the dominant kernel: measured by separate rocprofv3 --pmc passes (TCC_EA0_RDREQ x 64 B x 2
         # [gfx950 wide-load correction] + TCC_EA0_WRREQ x 64 B, averaged over the launches of one DRUNet call) and
         # recorded, with the commit and configuration they were taken at, in profiles/pmc_traffic.json
@@ -209,7 +210,9 @@ def main():
                        "global_batch": args.batch, "per_gpu_batch": B_local, "iters": args.iters,
                        "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if world > 1 else "none",
                        "conv_precision": "bf16split", "loop_graph": bool(getattr(model.fixed_point, "use_graph", False))},
-            "roofline": {"bound": "mfma", "kernel": kname + (" (DRUNet 3x3 conv, v_mfma_f32_32x32x16_bf16, split operands)" if bf16
+            "roofline": {"bound": "mfma", "kernel": kname + (" (DRUNet 3x3 conv as Winograd F(2,3) along rows, v_mfma_f32_32x32x16_bf16, split operands)"
+                                                              if "wsplit" in kname else
+                                                              " (DRUNet 3x3 conv, v_mfma_f32_32x32x16_bf16, split operands)" if bf16
                                                               else " (DRUNet 3x3 conv, v_mfma_f32_32x32x2_f32)"),
                          "achieved": round(achieved / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,

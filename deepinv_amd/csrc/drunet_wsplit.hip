@@ -100,7 +100,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     const int l31 = lane & 31, lhi = lane >> 5;
     // XCD-aware order as in drunet_split2d.hip (speed only)
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+#ifdef WS_DIAG_ORDER2
+    const int tl = jx % a.tiles_per_xcd, ty = jx / a.tiles_per_xcd;
+#else
     const int ty = jx % a.ytiles, tl = jx / a.ytiles;
+#endif
     const int tile = xcd * a.tiles_per_xcd + tl;
     if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;
     const int tr_i = tile / a.ntc, tc_i = tile - tr_i * a.ntc;
@@ -153,7 +157,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     uint4 d0a, d0b, d1a, d1b, d2a, d2b, d3a, d3b;     // the four pixels of this thread's task (8 channels each)
     uint4 eaa, eab, eba, ebb;                         // the two pixels of this wave's point of an extra task
     auto ldd = [&](int s) {
+#ifdef WS_DIAG_D_L1
+        const float* p = a.x + (int64_t)(s & 1) * step_stride + (xoff0 & 0xffff);
+#else
         const float* p = a.x + (int64_t)s * step_stride + xoff0;
+#endif
         d0a = ldu4(p);      d0b = ldu4(p + 4);
         d1a = ldu4(p + 8);  d1b = ldu4(p + 12);
         d2a = ldu4(p + 16); d2b = ldu4(p + 20);
@@ -191,7 +199,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
         }
     };
     auto lda = [&](int j, uint4& a00, uint4& a01, uint4& a10, uint4& a11) {     // [m][plane] of sub-step j = 3 step + dy
+#ifdef WS_DIAG_A_L1
+        const uint4* p = a.w + k * 256 + lane + (int64_t)(j & 1) * WSUB;
+#else
         const uint4* p = wsrc + (int64_t)j * WSUB;
+#endif
         a00 = p[0]; a01 = p[64]; a10 = p[128]; a11 = p[192];
     };
 
@@ -213,9 +225,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
         }
     };
 
-    // ---- prologue: V of step 0, the weights of its first kernel row, the extra-task pixels of step 1
-    uint4 p00, p01, p10, p11, q00, q01, q10, q11;     // A fragments: current / next kernel row
-    lda(0, p00, p01, p10, p11);
+    // ---- prologue: V of step 0, the weights of its first two kernel rows, the extra-task pixels of step 1
+    // A fragments [m][plane] of kernel rows 0 / 1 / 2: row dy of a step uses set dy and, as its first act, requests the row two
+    // sub-steps ahead into the set the previous row has just finished with (the 512-channel layers' weights do not stay in
+    // the 4 MB L2 next to the streaming activations: one row of lead, ~0.9 us, did not cover those misses)
+    uint4 a0_00, a0_01, a0_10, a0_11, a1_00, a1_01, a1_10, a1_11, a2_00, a2_01, a2_10, a2_11;
+    lda(0, a0_00, a0_01, a0_10, a0_11);
+    lda(1, a1_00, a1_01, a1_10, a1_11);
     ldd(0);
     lde(0);
     putv01(lds);
@@ -227,32 +243,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     for (int s = 0; s < nstep; ++s) {
         // straight-line step: the last steps stage their own channels once more into the idle V stage (no reader) instead of
         // branching around the loads.  The transform of the next step's V is spread over the three kernel rows (32 / 64 / 64
-        // vector instructions beside 24 MFMAs each): bunched into one row it cost 10 % of the kernel, spread it is free
-        // (profiles/r03_wsplit_variants.jsonl)
+        // vector instructions beside 24 MFMAs each): bunched into one row it cost 10 % of the kernel
         const int sn = s + 1 < nstep ? s + 1 : s, sn2 = s + 2 < nstep ? s + 2 : nstep - 1;
         const uint4* const vcur = lds + (s & 1) * VSTAGE;
         uint4* const vnext = lds + ((s + 1) & 1) * VSTAGE;
         const int j = 3 * s;
         // kernel row 0; the thread's four pixels of the next step are requested; extra-task point (its pixels came in a row ago)
-        lda(j + 1, q00, q01, q10, q11);
+        lda(j + 2, a2_00, a2_01, a2_10, a2_11);
         ldd(sn);
         sched_fence();
-        mma(vcur, p00, p01, p10, p11);
+        mma(vcur, a0_00, a0_01, a0_10, a0_11);
         pute(vnext);
         sched_fence();
         // kernel row 1; points 0, 1
-        lda(j + 2, p00, p01, p10, p11);
-        mma(vcur + PC, q00, q01, q10, q11);
+        lda(j + 3 < nsub ? j + 3 : j, a0_00, a0_01, a0_10, a0_11);
+        sched_fence();
+        mma(vcur + PC, a1_00, a1_01, a1_10, a1_11);
         putv01(vnext);
         sched_fence();
         // kernel row 2; points 2, 3; the extra-task pixels of the step after the next are requested
-        lda(j + 3 < nsub ? j + 3 : j + 2, q00, q01, q10, q11);
+        lda(j + 4 < nsub ? j + 4 : j + 1, a1_00, a1_01, a1_10, a1_11);
         lde(sn2);
         sched_fence();
-        mma(vcur + 2 * PC, p00, p01, p10, p11);
+        mma(vcur + 2 * PC, a2_00, a2_01, a2_10, a2_11);
         putv23(vnext);
         sched_fence();
-        p00 = q00; p01 = q01; p10 = q10; p11 = q11;
         lds_barrier();     // the next V stage is complete, every read of this one is done
     }
 
