@@ -24,6 +24,8 @@
 //     0.33 ds_read_b128 per MFMA (direct kernel: 0.67) and no weight stage at all - LDS is nearly idle.
 //   * epilogue: the four waves exchange M_k through LDS (one 32-cout tile at a time, lane-linear 16-byte accesses), wave w
 //     finishes pair tile w: both output pixels of a pair are one lane's 64 contiguous bytes per channel block.
+#include <type_traits>
+
 #include "drunet_split_common.hpp"
 
 using namespace dinv;
@@ -240,36 +242,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     lde(nstep > 1 ? 1 : 0);
     __syncthreads();
 
-    for (int s = 0; s < nstep; ++s) {
-        // straight-line step: the last steps stage their own channels once more into the idle V stage (no reader) instead of
-        // branching around the loads.  The transform of the next step's V is spread over the three kernel rows (32 / 64 / 64
-        // vector instructions beside 24 MFMAs each): bunched into one row it cost 10 % of the kernel
-        const int sn = s + 1 < nstep ? s + 1 : s, sn2 = s + 2 < nstep ? s + 2 : nstep - 1;
+    // one 16-channel step.  While its 72 MFMAs run, the V stage of the next step is built: the transform is spread over the
+    // three kernel rows (32 / 64 / 64 vector instructions beside 24 MFMAs each; bunched into one row it cost 10 % of the
+    // kernel).  The LAST step of a tile has nothing to stage and requests no weights beyond its own rows (a global load costs
+    // the issuing wave far more than its issue slot, so at 64 input channels - four steps - re-staging a dummy step and
+    // clamped dummy weight loads were a fifth of all loads)
+    auto step = [&](int s, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         const uint4* const vcur = lds + (s & 1) * VSTAGE;
         uint4* const vnext = lds + ((s + 1) & 1) * VSTAGE;
         const int j = 3 * s;
         // kernel row 0; the thread's four pixels of the next step are requested; extra-task point (its pixels came in a row ago)
         lda(j + 2, a2_00, a2_01, a2_10, a2_11);
-        ldd(sn);
+        if constexpr (!LAST) ldd(s + 1);
         sched_fence();
         mma(vcur, a0_00, a0_01, a0_10, a0_11);
-        pute(vnext);
+        if constexpr (!LAST) pute(vnext);
         sched_fence();
         // kernel row 1; points 0, 1
-        lda(j + 3 < nsub ? j + 3 : j, a0_00, a0_01, a0_10, a0_11);
-        sched_fence();
+        if constexpr (!LAST) {
+            lda(j + 3, a0_00, a0_01, a0_10, a0_11);
+            sched_fence();
+        }
         mma(vcur + PC, a1_00, a1_01, a1_10, a1_11);
-        putv01(vnext);
+        if constexpr (!LAST) putv01(vnext);
         sched_fence();
         // kernel row 2; points 2, 3; the extra-task pixels of the step after the next are requested
-        lda(j + 4 < nsub ? j + 4 : j + 1, a1_00, a1_01, a1_10, a1_11);
-        lde(sn2);
-        sched_fence();
+        if constexpr (!LAST) {
+            lda(j + 4, a1_00, a1_01, a1_10, a1_11);
+            lde(s + 2 < nstep ? s + 2 : s + 1);      // (second-to-last step: unused, clamped instead of a branch - a
+            sched_fence();                           // branch here costs registers, and the kernel has none to spare)
+        }
         mma(vcur + 2 * PC, a2_00, a2_01, a2_10, a2_11);
-        putv23(vnext);
+        if constexpr (!LAST) putv23(vnext);
         sched_fence();
-        lds_barrier();     // the next V stage is complete, every read of this one is done
-    }
+        lds_barrier();     // the next V stage is complete, every read of this one is done (last step: the stages become the
+                           // exchange buffer of the epilogue)
+    };
+    for (int s = 0; s + 1 < nstep; ++s) step(s, std::false_type{});
+    step(nstep - 1, std::true_type{});
 
     // ---- epilogue: y(2j) = M0 + M1 + M2, y(2j+1) = M1 - M2 - M3.  Wave w finishes pair tile w; register quads 2q, 2q+1 of a
     // 32-cout tile m are channels 0..7 of block cb0 + 4m + 2q + lhi (row permutation of pack_wsplit_weight)
