@@ -102,11 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     const int l31 = lane & 31, lhi = lane >> 5;
     // XCD-aware order as in drunet_split2d.hip (speed only)
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-#ifdef WS_DIAG_ORDER2
-    const int tl = jx % a.tiles_per_xcd, ty = jx / a.tiles_per_xcd;
-#else
     const int ty = jx % a.ytiles, tl = jx / a.ytiles;
-#endif
     const int tile = xcd * a.tiles_per_xcd + tl;
     if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;
     const int tr_i = tile / a.ntc, tc_i = tile - tr_i * a.ntc;
@@ -159,11 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     uint4 d0a, d0b, d1a, d1b, d2a, d2b, d3a, d3b;     // the four pixels of this thread's task (8 channels each)
     uint4 eaa, eab, eba, ebb;                         // the two pixels of this wave's point of an extra task
     auto ldd = [&](int s) {
-#ifdef WS_DIAG_D_L1
-        const float* p = a.x + (int64_t)(s & 1) * step_stride + (xoff0 & 0xffff);
-#else
         const float* p = a.x + (int64_t)s * step_stride + xoff0;
-#endif
         d0a = ldu4(p);      d0b = ldu4(p + 4);
         d1a = ldu4(p + 8);  d1b = ldu4(p + 12);
         d2a = ldu4(p + 16); d2b = ldu4(p + 20);
@@ -201,11 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
         }
     };
     auto lda = [&](int j, uint4& a00, uint4& a01, uint4& a10, uint4& a11) {     // [m][plane] of sub-step j = 3 step + dy
-#ifdef WS_DIAG_A_L1
-        const uint4* p = a.w + k * 256 + lane + (int64_t)(j & 1) * WSUB;
-#else
         const uint4* p = wsrc + (int64_t)j * WSUB;
-#endif
         a00 = p[0]; a01 = p[64]; a10 = p[128]; a11 = p[192];
     };
 

@@ -9,11 +9,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import deepinv_amd.hip as _hip  # noqa: E402
-
-VARIANT = sys.argv[2] if len(sys.argv) > 2 else ""
-if VARIANT:     # throw-away diagnostic builds (scripts/r03/build_ws_variants.sh)
-    _hip.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", f"libdeepinv_amd_{VARIANT}.so")
 from deepinv_amd.hip import drunet as K  # noqa: E402
 from bench_ops import timeit  # noqa: E402
 
@@ -30,7 +25,7 @@ for lvl, c in enumerate((64, 128, 256, 512)):
     w = torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5)
     w2, ww = K.pack_split2d_weight(w), K.pack_wsplit_weight(w)
     fl = 2.0 * 9 * c * c * B * H * H
-    row = {"lvl": lvl, "B": B, "c": c, "H": H, "variant": VARIANT or "product"}
+    row = {"lvl": lvl, "B": B, "c": c, "H": H}
     try:
         # error of conv2 (x -> y + r) of both kernels against fp64 on the first two images
         nb = min(B, 2)
@@ -59,4 +54,4 @@ for lvl, c in enumerate((64, 128, 256, 512)):
     except Exception as e:  # noqa: BLE001
         row["error"] = repr(e)[:300]
     print(json.dumps(row), flush=True)
-print(json.dumps({"B": B, "variant": VARIANT or "product", "resblock_convs_ms_per_drunet": {k: round(v * 1e3, 2) for k, v in tot.items()}}))
+print(json.dumps({"B": B, "resblock_convs_ms_per_drunet": {k: round(v * 1e3, 2) for k, v in tot.items()}}))

@@ -10,6 +10,6 @@ python - <<'PY'
 import json
 for l in open('gpurun_out/r03_wsplit3.jsonl'):
     d=json.loads(l)
-    if 'lvl' in d: print(d['variant'], d['B'], d['lvl'], 'direct', d.get('direct_conv1_ms'), d.get('direct_conv2_ms'), 'ws', d.get('wsplit_conv1_ms'), d.get('wsplit_conv2_ms'), 'zero', d.get('wsplit_conv2_zero_data_ms'), d.get('err_wsplit'), d.get('error'))
+    if 'lvl' in d: print(d['B'], d['lvl'], 'direct', d.get('direct_conv1_ms'), d.get('direct_conv2_ms'), 'ws', d.get('wsplit_conv1_ms'), d.get('wsplit_conv2_ms'), 'zero', d.get('wsplit_conv2_zero_data_ms'), d.get('err_wsplit'), d.get('error'))
     else: print(d)
 PY

@@ -2,9 +2,6 @@
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
-import deepinv_amd.hip as _hip
-if len(sys.argv) > 4:
-    _hip.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", f"libdeepinv_amd_{sys.argv[4]}.so")
 from deepinv_amd.hip import drunet as K
 lvl, B = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
