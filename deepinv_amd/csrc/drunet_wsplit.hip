@@ -11,8 +11,9 @@
 // = 12 multiplies per pair, channel pair and kernel row instead of 18: 1.5x fewer MFMAs.  U is formed in fp64 on the host
 // and split (hi = bf16, lo = bf16 of the rest) when packed; V is formed in fp32 from the staged pixels and split on the
 // fly; every product is Uh*Vl + Ul*Vh + Uh*Vh with fp32 accumulation in v_mfma_f32_32x32x16_bf16, as in the direct kernel.
-// Error: the same 2^-16 per operand, relative to |U| (x) |V| instead of |g| (x) |d|: 5.8e-6 per layer against an fp64
-// convolution on random data (direct form: 4.4e-6; tests/test_emu_drunet.py, tests/test_drunet_gpu.py).
+// Error: the same 2^-16 per operand, relative to |U| (x) |V| instead of |g| (x) |d|: 4.0e-6 per layer against an fp64
+// convolution on random data on the hardware (direct form: 3.1e-6; profiles/r03_wsplit_variants.jsonl), 2e-5 asserted in
+// tests/test_emu_drunet.py and tests/test_drunet_gpu.py.
 //
 // Work decomposition (one workgroup = 4 waves = 256 output pixels = 128 pairs x 64 couts, two workgroups per CU):
 //   * wave k owns Winograd point k for the whole tile: accumulators M_k[2 cout tiles of 32][4 pair tiles of 32] = 128
@@ -24,6 +25,12 @@
 //     0.33 ds_read_b128 per MFMA (direct kernel: 0.67) and no weight stage at all - LDS is nearly idle.
 //   * epilogue: the four waves exchange M_k through LDS (one 32-cout tile at a time, lane-linear 16-byte accesses), wave w
 //     finishes pair tile w: both output pixels of a pair are one lane's 64 contiguous bytes per channel block.
+// Measured (MI355X, B = 32, conv1 / conv2 of a ResBlock, direct kernel in brackets): 0.66 / 0.73 (0.83 / 0.73), 0.54 / 0.58
+// (0.70 / 0.64), 0.48 / 0.49 (0.65 / 0.59), 0.45 / 0.47 (0.65 / 0.60) ms per launch at the four DRUNet levels; the matrix pipe is
+// busy 50 % of the cycles (profiles/pmc/r03_conv_wsplit_sq.csv).  Diagnostic builds: a quarter of the time is the
+// price of feeding the V stage, a sixth the fragment loads - as issue cost inside the in-order waves (forcing the loads to hit
+// L1, a longer lead, one load per MFMA gap, halving the activation requests through DPP neighbour exchange: all within 0-5 %);
+// the epilogue exchange and the barrier are free; four accumulators in rotation instead of two change nothing.
 #include <type_traits>
 
 #include "drunet_split_common.hpp"
