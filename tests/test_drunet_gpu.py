@@ -265,6 +265,46 @@ def test_split_worst_case_bound(dev, case):
         assert rel_err(out, ref) < 5e-6
 
 
+@pytest.mark.parametrize("case", ["wide", "he_scale"])
+def test_wsplit_worst_case_bound(dev, case):
+    """worst-case bound of the Winograd operand-split kernel on the hardware (emulated twin with the derivation:
+    tests/test_emu_drunet.py::test_wsplit_worst_case): |y - y_exact| <= (3 * 2^-16 + 2^-20) sum_k (|U_k| conv |V_k|) over the
+    three Winograd points of an output pixel, for activations spanning 2^-20 .. 2^8 and weights 2^-12 .. 2^2; He-scaled
+    weights and N(0,1) data stay at a few 1e-6"""
+    from deepinv_amd.hip import drunet as K
+
+    gen = torch.Generator().manual_seed(12)
+    B, H, W, cin, cout = 2, 64, 96, 128, 128
+
+    def wide(shape, lo, hi):
+        e = torch.randint(lo, hi + 1, shape, generator=gen).float()
+        return (1 + torch.rand(shape, generator=gen)) * torch.exp2(e) * (torch.randint(0, 2, shape, generator=gen) * 2 - 1).float()
+
+    if case == "wide":
+        x, w = wide((B, cin, H, W), -20, 8), wide((cout, cin, 3, 3), -12, 2)
+    else:
+        x, w = torch.randn(B, cin, H, W, generator=gen), torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    x, w = x.to(dev), w.to(dev)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    g64 = w.double()
+    U = torch.stack((g64[..., 0], (g64[..., 0] + g64[..., 1] + g64[..., 2]) / 2, (g64[..., 0] - g64[..., 1] + g64[..., 2]) / 2,
+                     g64[..., 2])).abs()
+    xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1))
+    d0, d1, d2, d3 = xp[..., 0:W:2], xp[..., 1:W + 1:2], xp[..., 2:W + 2:2], xp[..., 3:W + 3:2]
+    V = [(d0 - d2).abs(), (d1 + d2).abs(), (d2 - d1).abs(), (d1 - d3).abs()]
+    M = [torch.nn.functional.conv2d(V[k], U[k].unsqueeze(-1)) for k in range(4)]
+    mag = torch.stack((M[0] + M[1] + M[2], M[1] + M[2] + M[3]), -1).reshape(B, cout, H, W)
+    geo = K.geom(B, H, W)
+    xa, ya = K.alloc(geo, cin, dev), K.alloc(geo, cout, dev)
+    xa[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:W + 1] = x.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+    K.conv3x3_wsplit(geo, xa, K.pack_wsplit_weight(w), cin, cout, ya)
+    av = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+    out = av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W).double()
+    assert bool(((out - ref).abs() <= (3 * 2.0 ** -16 + 2.0 ** -20) * mag).all()), float(((out - ref).abs() / mag).max())
+    if case == "he_scale":
+        assert rel_err(out, ref) < 8e-6
+
+
 def test_drunet_default_precision_matches_oracle(dev):
     import deepinv_amd as dinv
 

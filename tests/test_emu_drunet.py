@@ -213,6 +213,52 @@ def test_split_worst_case(case):
         assert float((out - ref).norm() / ref.norm()) < 5e-6
 
 
+def winograd_magnitude(x, w):
+    """sum over the three Winograd points of an output pixel of |U_k| conv |V_k| (fp64): the quantity the operand-split error
+    of csrc/drunet_wsplit.hip is relative to.  Even columns use points 0, 1, 2, odd columns 1, 2, 3."""
+    B, C, H, W = x.shape
+    g = w.double()
+    U = torch.stack((g[..., 0], (g[..., 0] + g[..., 1] + g[..., 2]) / 2, (g[..., 0] - g[..., 1] + g[..., 2]) / 2, g[..., 2])).abs()
+    xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1))
+    d0, d1, d2, d3 = xp[..., 0:W:2], xp[..., 1:W + 1:2], xp[..., 2:W + 2:2], xp[..., 3:W + 3:2]
+    V = [(d0 - d2).abs(), (d1 + d2).abs(), (d2 - d1).abs(), (d1 - d3).abs()]
+    M = [torch.nn.functional.conv2d(V[k], U[k].unsqueeze(-1)) for k in range(4)]         # rows only: kernel [Co, Ci, 3, 1]
+    return torch.stack((M[0] + M[1] + M[2], M[1] + M[2] + M[3]), -1).reshape(B, -1, H, W)
+
+
+@pytest.mark.parametrize("case", ["wide", "he_scale"])
+def test_wsplit_worst_case(case):
+    """The worst-case bound of the Winograd operand-split kernel, element by element.  Every multiply U_k V_k is evaluated as
+    Uh Vl + Ul Vh + Uh Vh with U, V = high part + low part + (at most 2^-16 of themselves), so each output obeys
+    |y - y_exact| <= 3 * 2^-16 * sum_k (|U_k| conv |V_k|) + the fp32 roundings of V, of the accumulation and of the output
+    transform (bounded here by 2^-20 of the same sum) - the bound of the direct kernel with |U| (x) |V| in the place of
+    |w| (x) |x|.  `wide`: activations spanning 2^-20 .. 2^8, weights 2^-12 .. 2^2; `he_scale`: O(1)-gain weights and N(0,1)
+    data, where the typical error must stay at the few-1e-6 level."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_wsplit_weight
+    gen = torch.Generator().manual_seed(12)
+    B, H, W, cin, cout = 2, 16, 32, 64, 64
+    if case == "wide":
+        x, w = wide_range((B, cin, H, W), -20, 8, gen), wide_range((cout, cin, 3, 3), -12, 2, gen)
+    else:
+        x, w = torch.randn(B, cin, H, W, generator=gen), torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    mag = winograd_magnitude(x, w)
+    g = geom(B, H, W)
+    xa = to_act(x, g)
+    ya = torch.zeros(cout // 8, g.cs, 8)
+    l = E.lib()
+    wp = pack_wsplit_weight(w)
+    E.check(l.dinv_conv3x3_wsplit(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya), None, 0, None))
+    out = from_act(ya, g, cout).double()
+    bound = (3 * 2.0 ** -16 + 2.0 ** -20) * mag
+    assert bool(((out - ref).abs() <= bound).all()), float(((out - ref).abs() / mag).max())
+    assert float(((out - ref).abs() / mag).max()) < 3 * 2.0 ** -16
+    if case == "he_scale":
+        assert float((out - ref).norm() / ref.norm()) < 8e-6
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout", [(1, 8, 12, 16, 64), (2, 10, 6, 32, 128), (3, 16, 16, 64, 64)])
 def test_bf16_split_down2x2_matches_fp64(B, H, W, cin, cout):
     """2x2 stride-2 convolution of drunet_bf16s.hip (downsample_strideconv, drunet.py:524-552) on the host emulation"""
