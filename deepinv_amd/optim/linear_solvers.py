@@ -1,12 +1,26 @@
 """The other Krylov solvers behind ``LinearPhysics.prox_l2 / A_dagger(solver=...)``: LSQR, BiCGStab, MINRES
 (reference deepinv/optim/linear/{lsqr,bicgstab,minres}.py; same signatures, stopping rules and per-sample treatment of
 the batch dimension).  They are written on torch tensors - the work is in the operator applications, which are the HIP
-kernels of the physics; the recurrences only touch image-sized vectors a handful of times per iteration."""
+kernels of the physics; the recurrences only touch image-sized vectors a handful of times per iteration.
+
+No host synchronisation per iteration: the reference's data-dependent branches (`if torch.all(...)`, `if torch.any(...)`,
+`.item()`: 7 per LSQR iteration, 1 per BiCGStab / MINRES iteration) are evaluated on the device.  A stopping test raises a
+device flag that freezes the iterate (`torch.where`), so the result is exactly what the reference's `break` leaves; the host
+reads the flag every `CHECK_EVERY` iterations only (at most `CHECK_EVERY - 1` operator applications are issued past
+convergence), as `conjugate_gradient` does (optim/linear.py)."""
 from __future__ import annotations
 
 from typing import Callable
 
 import torch
+
+
+CHECK_EVERY = 4   # the host looks at the device-side convergence flag every this many iterations
+
+
+def _poll(done, i, max_iter):
+    """True when the host should stop: polled every CHECK_EVERY iterations and at the last one"""
+    return (i % CHECK_EVERY == CHECK_EVERY - 1 or i == int(max_iter) - 1) and bool(done)
 
 
 def _reduce_dims(t, parallel_dim):
@@ -68,18 +82,23 @@ def lsqr(A: Callable, AT: Callable, b, eta=0.0, x0=None, tol=1e-6, conlim=1e8, m
     if torch.any(alpha * beta == 0):
         return x, acond
     z, cs2, sn2, xxnorm = 0.0, -1.0, 0.0, 0.0
-    converged = False
+    anorm = torch.zeros((), device=dev, dtype=bnorm.dtype)
+    done = torch.zeros((), dtype=torch.bool, device=dev)
+    safe = lambda t: torch.where(t > 0, t, torch.ones_like(t))
     for itn in range(int(max_iter)):
-        # next pair of Lanczos vectors
-        u = A(v) - mul_b(u, alpha)
-        beta = nrm(u)
-        if torch.all(beta > 0):
-            u = mul_b(u, 1 / beta)
-            anorm = torch.sqrt(anorm ** 2 + alpha ** 2 + beta ** 2 + eta)
-            v = AT(u) - mul_x(v, beta)
-            alpha = nrm(v)
-            if torch.all(alpha > 0):
-                v = mul_x(v, 1 / alpha)
+        # next pair of Lanczos vectors.  The reference normalises only while every sample's beta (alpha) is positive
+        # (`if torch.all(beta > 0)`): the same decision, taken on the device
+        u_new = A(v) - mul_b(u, alpha)
+        beta_new = nrm(u_new)
+        ok_b = (beta_new > 0).all()
+        u_new = torch.where(ok_b, mul_b(u_new, 1 / safe(beta_new)), u_new)
+        anorm_new = torch.where(ok_b, torch.sqrt(anorm ** 2 + alpha ** 2 + beta_new ** 2 + eta), anorm)
+        v_new = AT(u_new) - mul_x(v, beta_new)
+        alpha_new = nrm(v_new)
+        ok_a = (alpha_new > 0).all()
+        v_new = torch.where(ok_a, mul_x(v_new, 1 / safe(alpha_new)), v_new)
+        u, beta, anorm = u_new, beta_new, anorm_new
+        v, alpha = torch.where(ok_b, v_new, v), torch.where(ok_b, alpha_new, alpha)
         # rotation that removes the damping term, then the one that removes the sub-diagonal
         if damped:
             rb1 = torch.sqrt(rhobar ** 2 + eta)
@@ -91,7 +110,7 @@ def lsqr(A: Callable, AT: Callable, b, eta=0.0, x0=None, tol=1e-6, conlim=1e8, m
         theta, rhobar = sn * alpha, -cs * alpha
         phi, phibar = cs * phibar, sn * phibar
         dk = mul_x(w, 1 / rho)
-        x = x + mul_x(w, phi / rho)
+        x = torch.where(done, x, x + mul_x(w, phi / rho))      # frozen once the stopping test has fired
         w = v + mul_x(w, -theta / rho)
         ddnorm = ddnorm + nrm(dk) ** 2
         # estimate of ||x|| (kept for parity of the recurrences) and the stopping quantities
@@ -100,37 +119,39 @@ def lsqr(A: Callable, AT: Callable, b, eta=0.0, x0=None, tol=1e-6, conlim=1e8, m
         gamma = torch.sqrt(gambar ** 2 + theta ** 2)
         cs2, sn2, z = gambar / gamma, theta / gamma, rhs / gamma
         xxnorm = xxnorm + z ** 2
-        acond = anorm * torch.sqrt(ddnorm).mean()
+        acond = torch.where(done, acond, anorm * torch.sqrt(ddnorm).mean())
         rnorm = torch.sqrt(phibar ** 2 + psi ** 2)
-        if torch.all(rnorm <= tol * bnorm):
-            converged = True
+        done = done | (rnorm <= tol * bnorm).all() | (acond > conlim).any()
+        if _poll(done, itn, max_iter):
             if verbose:
-                print("LSQR converged at iteration", itn)
+                print("LSQR stopped (tolerance or condition number limit) at iteration <=", itn)
             break
-        if torch.any(acond > conlim):
-            converged = True
-            if verbose:
-                print(f"LSQR reached condition number limit {conlim} at iteration", itn)
-            break
-    if not converged and verbose:
-        print("LSQR did not converge")
+    else:
+        if verbose:
+            print("LSQR did not converge")
     return x, acond.sqrt()
 
 
 def _givens(a, b):
-    """numerically careful plane rotation (c, s, r) with c a + s b = r (Choi's sym-ortho, as scipy / lsqr.py:229-262)"""
+    """numerically careful plane rotation (c, s, r) with c a + s b = r (Choi's sym-ortho, as scipy / lsqr.py:229-262).  The
+    reference picks one of its four formulas for the whole batch with `torch.any` (a host sync each); here every element
+    takes the formula its own (a, b) calls for - the same rotation, chosen without leaving the device."""
     a, b = torch.broadcast_tensors(torch.as_tensor(a), torch.as_tensor(b))
-    if torch.any(b == 0):
-        return torch.sign(a), 0, a.abs()
-    if torch.any(a == 0):
-        return 0, torch.sign(b), b.abs()
-    if torch.any(b.abs() > a.abs()):
-        tau = a / b
-        s = torch.sign(b) / torch.sqrt(1 + tau * tau)
-        return s * tau, s, b / s
-    tau = b / a
-    c = torch.sign(a) / torch.sqrt(1 + tau * tau)
-    return c, c * tau, a / c
+    one = torch.ones_like(a)
+    big_b = b.abs() > a.abs()
+    tau = torch.where(big_b, a / torch.where(b == 0, one, b), b / torch.where(a == 0, one, a))
+    root = torch.sqrt(1 + tau * tau)
+    s3 = torch.sign(b) / root          # |b| > |a|: tau = a / b
+    c4 = torch.sign(a) / root          # else:      tau = b / a
+    c = torch.where(big_b, s3 * tau, c4)
+    sn = torch.where(big_b, s3, c4 * tau)
+    r = torch.where(big_b, b / torch.where(s3 == 0, one, s3), a / torch.where(c4 == 0, one, c4))
+    zero = torch.zeros_like(a)
+    b0, a0 = b == 0, (a == 0) & (b != 0)
+    c = torch.where(b0, torch.sign(a), torch.where(a0, zero, c))
+    sn = torch.where(b0, zero, torch.where(a0, torch.sign(b), sn))
+    r = torch.where(b0, a.abs(), torch.where(a0, b.abs(), r))
+    return c, sn, r
 
 
 def _dot(a, b, dim):
@@ -151,7 +172,7 @@ def bicgstab(A: Callable, b, init=None, max_iter=1e2, tol=1e-5, parallel_dim=0, 
     tol2 = _dot(b, b, dim).real * tol ** 2
     tiny = torch.finfo(b.dtype).eps
     safe_div = lambda num, den: torch.where(den.abs() > tiny, num / den, torch.zeros_like(num))
-    done = False
+    done = torch.zeros((), dtype=torch.bool, device=b.device)
     for i in range(int(max_iter)):
         y = right_precon(left_precon(p))
         v = A(y)
@@ -162,20 +183,21 @@ def bicgstab(A: Callable, b, init=None, max_iter=1e2, tol=1e-5, parallel_dim=0, 
         t = A(zz)
         ls, lt = left_precon(s), left_precon(t)
         omega = safe_div(_dot(lt, ls, dim), _dot(lt, lt, dim))
-        x = h + omega * zz
+        x = torch.where(done, x, h + omega * zz)      # frozen once the stopping test has fired
         r = s - omega * t
-        if torch.all(_dot(r, r, dim).real < tol2):
-            done = True
+        done = done | (_dot(r, r, dim).real < tol2).all()
+        if _poll(done, i, max_iter):
             if verbose:
-                print("BiCGSTAB Converged at iteration", i)
+                print("BiCGSTAB Converged at iteration <=", i)
             break
         rho_next = _dot(r, shadow, dim)
         ok = (rho.abs() > tiny) & (omega.abs() > tiny)
         beta = torch.where(ok, (rho_next / rho) * (alpha / omega), torch.zeros_like(rho_next))
         p = r + beta * (p - omega * v)
         rho = rho_next
-    if not done and verbose:
-        print("BiCGSTAB did not converge")
+    else:
+        if verbose:
+            print("BiCGSTAB did not converge")
     return x
 
 
@@ -201,7 +223,7 @@ def minres(A: Callable, b, init=None, max_iter=1e2, tol=1e-5, eps=1e-6, parallel
     c_old, s_old, c_cur, s_cur = one, torch.zeros_like(one), one, torch.zeros_like(one)
     d_old, d_cur = torch.zeros_like(sol), torch.zeros_like(sol)   # search directions (columns of Q R^-1)
     eta_k = beta
-    unconverged = True
+    done = torch.zeros((), dtype=torch.bool, device=b.device)
     i = 0
     for i in range(int(max_iter)):
         Aq = A(q_cur)
@@ -220,18 +242,21 @@ def minres(A: Callable, b, init=None, max_iter=1e2, tol=1e-5, eps=1e-6, parallel
         diag = diag * c_new + s_new * beta_next
         d_new = (q_cur - delta * d_cur - eps_k * d_old) / diag
         step = d_new * eta_k * c_new
-        sol = sol + step
-        if (torch.linalg.vector_norm(step, dim=dim, ord=2).unsqueeze(-1)
-                / torch.linalg.vector_norm(sol, dim=dim, ord=2).unsqueeze(-1)).max().item() < tol:
-            unconverged = False
+        sol_new = sol + step
+        rel = (torch.linalg.vector_norm(step, dim=dim, ord=2).unsqueeze(-1)
+               / torch.linalg.vector_norm(sol_new, dim=dim, ord=2).unsqueeze(-1)).max()
+        sol = torch.where(done, sol, sol_new)      # frozen once the stopping test has fired
+        done = done | (rel < tol)
+        if _poll(done, i, max_iter):
             if verbose:
-                print("MINRES converged at iteration", i + 1)
+                print("MINRES converged at iteration <=", i + 1)
             break
         eta_k = -eta_k * s_new
         z_old, z_cur, q_cur, beta = z_cur, Aq, q_next, beta_next
         c_old, s_old, c_cur, s_cur = c_cur, s_cur, c_new, s_new
         d_old, d_cur = d_cur, d_new
+    else:
+        if verbose:
+            print(f"MINRES did not converge in {i} iterations!")
     sol = sol.masked_fill(null_rhs, 0)
-    if unconverged and verbose:
-        print(f"MINRES did not converge in {i} iterations!")
     return sol * scale

@@ -40,6 +40,28 @@ def test_pnp_hqs_tomography_with_cg(dev):
     assert rel_err(rec, ref) < 1e-3   # CG stops on a tolerance: iteration counts may differ by one
 
 
+@pytest.mark.parametrize("solver", ["lsqr", "BiCGStab", "minres"])
+def test_prox_l2_other_solvers_on_the_radon_kernels(dev, solver):
+    """`prox_l2(solver=...)` through LSQR / BiCGStab / MINRES (optim/linear_solvers.py: stopping tests decided on the device,
+    the host polls a flag every few iterations) on CUDA tensors with the Radon kernels as operator: the minimiser of
+    gamma/2 |Ax - y|^2 + 1/2 |x - z|^2 agrees with the CG solution of the same problem (the CG path is pinned against the
+    oracle by test_pnp_hqs_tomography_with_cg; the recurrences themselves against the reference's goldens on the host)"""
+    import deepinv_amd as dinv
+
+    W, nang, B = 48, 40, 2
+    g = torch.Generator().manual_seed(1)
+    x, z = torch.rand(B, 1, W, W, generator=g).to(dev), torch.rand(B, 1, W, W, generator=g).to(dev)
+    phys = dinv.physics.Tomography(angles=nang, img_width=W, normalize=True, device=dev)
+    y = phys.A(x)
+    with torch.no_grad():
+        out = phys.prox_l2(z, y, gamma=0.7, solver=solver, max_iter=200, tol=1e-7)
+        ref = phys.prox_l2(z, y, gamma=0.7, solver="CG", max_iter=300, tol=1e-8)
+    assert rel_err(out, ref) < 1e-4
+    # and it IS a minimiser: the gradient gamma A^T(Ax - y) + x - z vanishes
+    grad = 0.7 * phys.A_adjoint(phys.A(out) - y) + out - z
+    assert float(grad.norm() / z.norm()) < 1e-4
+
+
 def test_unfolded_pgd_3d_multicoil_autograd(dev):
     """config-4 shape in miniature: gradients flow through the fused MRI kernels (backward(A) = A^T)"""
     import deepinv_amd as dinv
