@@ -103,7 +103,7 @@ __device__ __forceinline__ void sched_fence() {
 template <bool RELU, int NRES, int TC>
 __global__ __launch_bounds__(256, 2) void conv3x3_wsplit_kernel(WsArgs a) {
     using T = TileW<TC>;
-    constexpr int PC = T::PC, TR = T::TR, AR = T::AR, VPL = T::VPL, VSTAGE = T::VSTAGE, NTASK = T::NTASK;
+    constexpr int PC = T::PC, TR = T::TR, VPL = T::VPL, VSTAGE = T::VSTAGE, NTASK = T::NTASK;
     DINV_DYN_LDS(uint4, lds);   // two V stages; reused by the epilogue exchange
     const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;     // wave = Winograd point
     const int l31 = lane & 31, lhi = lane >> 5;
