@@ -90,3 +90,64 @@ def test_split2d_weight_pack_layout_and_products():
     a2, b2 = split(a, 2), split(b, 2)
     three = a2[1] @ b2[0] + a2[0] @ b2[1] + a2[0] @ b2[0]
     assert rel(three) < 2e-5 and rel(a2[0] @ b2[0]) > 1e-3
+
+
+def test_wsplit_weight_pack_layout_and_algebra():
+    """pack_wsplit_weight: [Cout/64][Cin/16][dy 3][point 4][m 2][plane 2][cblk 2][row 32][ci 8] holds the two bf16 parts of the
+    F(2,3) weights U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2 of kernel row dy (rows of a 32-row tile permuted
+    like pack_split2d_weight), and the identity csrc/drunet_wsplit.hip relies on reproduces the 3x3 correlation (fp64):
+    V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3;  y(2j) = M0+M1+M2, y(2j+1) = M1-M2-M3 with M_k = sum_dy U_k[dy] V_k[row+dy]."""
+    from deepinv_amd.hip.drunet import pack_wsplit_weight, split2d_row_perm
+
+    g = torch.Generator().manual_seed(5)
+    cout, cin = 128, 32
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    pk = pack_wsplit_weight(w)
+    assert pk.shape == (cout // 64, cin // 16, 3, 4, 2, 2, 2, 32, 8) and pk.dtype == torch.bfloat16
+    gd = w.double()
+    U = torch.stack((gd[..., 0], (gd[..., 0] + gd[..., 1] + gd[..., 2]) / 2, (gd[..., 0] - gd[..., 1] + gd[..., 2]) / 2, gd[..., 2]))
+    perm = split2d_row_perm()
+    for (co, ci, dy, k) in ((0, 0, 0, 0), (70, 9, 2, 1), (127, 31, 1, 2), (33, 16, 0, 3)):
+        ct, m, r = co // 64, (co % 64) // 32, co % 32
+        row = int((perm == r).nonzero()[0, 0])          # MFMA row that carries cout r of its 32-row tile
+        s, cb, c8 = ci // 16, (ci % 16) // 8, ci % 8
+        hi, lo = pk[ct, s, dy, k, m, 0, cb, row, c8].double(), pk[ct, s, dy, k, m, 1, cb, row, c8].double()
+        u = U[k, co, ci, dy]
+        assert abs(float(hi + lo - u)) <= 2.0 ** -16 * abs(float(u)) + 1e-30
+    # the algebra on one row of pairs (valid correlation of a 3-row strip with an even number of output columns)
+    Wd = 10
+    d = torch.randn(cin, 3, Wd + 2, generator=g, dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(d[None], gd[7:8])[0, 0, 0]                 # [Wd]
+    d0, d1, d2, d3 = d[..., 0:Wd:2], d[..., 1:Wd + 1:2], d[..., 2:Wd + 2:2], d[..., 3:Wd + 3:2]
+    V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)                                       # [cin, 3, Wd/2] each
+    M = [(U[k, 7][:, :, None] * V[k]).sum((0, 1)) for k in range(4)]
+    y = torch.stack((M[0] + M[1] + M[2], M[1] - M[2] - M[3]), -1).reshape(-1)
+    assert torch.allclose(y, ref, atol=1e-10)
+    with pytest.raises(ValueError):
+        pack_wsplit_weight(torch.zeros(64, 24, 3, 3))
+
+
+def test_res_block_dispatch_even_and_odd_widths(monkeypatch):
+    """bf16-split precision: the Winograd operand-split kernel takes the ResBlock convolutions wherever the level's width is
+    even, the direct operand-split kernel (pre-split temporary) otherwise; without the packs, the fp32 kernels (no GPU needed:
+    the launch wrappers are replaced by recorders)"""
+    import types
+    from deepinv_amd.models import drunet as D
+
+    calls = []
+    monkeypatch.setattr(D.K, "conv3x3_wsplit", lambda g, x, w, ci, co, y, res1=None, relu=False: calls.append(("wsplit", relu, res1 is not None)))
+    monkeypatch.setattr(D.K, "conv3x3_split", lambda g, x, w, ci, co, y, res1=None, relu=False, x_presplit=False, y_presplit=False,
+                        gate=False: calls.append(("split", relu, res1 is not None, x_presplit, y_presplit)))
+    model = D.DRUNet.__new__(D.DRUNet)
+    model._conv_fp32 = lambda g, pk, x, y, relu=False, res1=None: calls.append(("fp32", relu, res1 is not None))
+    pk = ((None, 64, 64), None, None, "s2d", "wsp")
+    x = t = y = object()
+    model._res_block(types.SimpleNamespace(width=40), pk, pk, x, t, y)
+    assert calls == [("wsplit", True, False), ("wsplit", False, True)]
+    calls.clear()
+    model._res_block(types.SimpleNamespace(width=5), pk, pk, x, t, y)
+    assert calls == [("split", True, False, False, True), ("split", False, True, True, False)]
+    calls.clear()
+    none = ((None, 64, 64), None, None, None, None)
+    model._res_block(types.SimpleNamespace(width=40), none, none, x, t, y)
+    assert calls == [("fp32", True, False), ("fp32", False, True)]
