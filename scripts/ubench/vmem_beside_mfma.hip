@@ -1,0 +1,95 @@
+// Microbenchmark for the open question of DESIGN.md 3.2 (Winograd bf16-split conv): what does one global_load_dwordx4 (1 KB per
+// wave) cost the wave that issues it in the middle of a v_mfma_f32_32x32x16_bf16 stream?  The conv kernel loads its A fragments
+// straight from L2 (12 loads per 72 MFMAs and wave) and builds its V stage from 12 more; diagnostic builds priced the first at a
+// sixth and the second at a quarter of the kernel although neither bandwidth nor latency explains it.  This program measures
+// the time per MFMA of a pure MFMA stream with L loads per 12 MFMAs interleaved, for one and two waves per SIMD and for an
+// L1-, L2- and HBM-sized working set, loads waited for one iteration late (two register sets) so that their latency is hidden.
+// build: hipcc -O3 --offload-arch=gfx950 vmem_beside_mfma.hip -o vmem_beside_mfma ; run: ./vmem_beside_mfma
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(a), "v"(b))
+#define LOAD(DST, PTR) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory")
+
+// L loads per 12 MFMAs, spread evenly; NT = 256 (one wave per SIMD) or 512 (two)
+template <int L, int NT>
+__global__ __launch_bounds__(NT) void k(const u32x4* src, float* out, int iters, unsigned mask) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + threadIdx.x + i); b[i] = (short)(0x3f00 + 3 * i); }
+    u32x4 s0[L > 0 ? L : 1], s1[L > 0 ? L : 1];
+    unsigned sink = 0;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned idx = (blockIdx.x * 64 + wave * 8) * 64 + lane;      // in 16-byte units: a wave reads 1 KB contiguous
+    for (int i = 0; i < (L > 0 ? L : 1); ++i) s0[i] = s1[i] = u32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                MFMA(acc[m & 3]);
+                if (L > 0 && (m * L) / 12 != ((m + 1) * L) / 12) {       // the (m*L/12)-th load of this iteration goes behind MFMA m
+                    const int li = (m * L) / 12;
+                    const u32x4* p = src + (idx & mask);
+                    idx += 64 * 13;
+                    if (half == 0) LOAD(s0[li], p); else LOAD(s1[li], p);
+                }
+            }
+            // the loads of the PREVIOUS half must have landed: at most this half's L loads stay in flight
+            if (L > 0) {
+                if (L == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if (L == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (L == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (L == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (L == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < L; ++i) sink ^= half == 0 ? s1[i].x : s0[i].x;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = (float)sink;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][9];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+}
+
+template <int L, int NT>
+static void run(const u32x4* src, float* out, size_t span_bytes, const char* name) {
+    const int iters = 4000, blocks = 256;      // one block per CU: 256 threads = one wave per SIMD, 512 = two
+    const unsigned mask = (unsigned)(span_bytes / 16 - 1);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<L, NT>), dim3(blocks), dim3(NT), 0, 0, src, out, 200, mask);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<L, NT>), dim3(blocks), dim3(NT), 0, 0, src, out, iters, mask);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    // MFMAs per SIMD: waves per SIMD x iters x 12
+    const double per_simd = (double)(NT / 256) * iters * 12;
+    printf("{\"loads_per_12_mfma\": %d, \"block\": %d, \"span\": \"%s\", \"ms\": %.4f, \"ns_per_mfma_slot\": %.3f}\n", L, NT, name, ms,
+           ms * 1e6 / per_simd);
+}
+
+int main() {
+    const size_t bytes = (size_t)1 << 30;
+    u32x4* src; float* out;
+    hipMalloc(&src, bytes); hipMalloc(&out, 512 * 512 * sizeof(float));
+    hipMemset(src, 1, bytes);
+    struct { size_t b; const char* n; } spans[] = {{(size_t)1 << 14, "16KB (L1)"}, {(size_t)1 << 21, "2MB (L2)"}, {(size_t)1 << 30, "1GB (HBM)"}};
+    for (auto sp : spans) {
+        run<0, 256>(src, out, sp.b, sp.n); run<1, 256>(src, out, sp.b, sp.n); run<2, 256>(src, out, sp.b, sp.n);
+        run<4, 256>(src, out, sp.b, sp.n); run<6, 256>(src, out, sp.b, sp.n);
+        run<0, 512>(src, out, sp.b, sp.n); run<2, 512>(src, out, sp.b, sp.n); run<4, 512>(src, out, sp.b, sp.n);
+    }
+    return 0;
+}
