@@ -15,8 +15,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(a), "v"(b))
 #define LOAD(DST, PTR) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory")
 
-// L loads per 12 MFMAs, spread evenly; NT = 256 (one wave per SIMD) or 512 (two)
-template <int L, int NT>
+// L loads per 12 MFMAs, spread evenly; NT = 256 (one wave per SIMD) or 512 (two); LS = lane stride in 16-byte units (1: a wave
+// reads 1 KB contiguous, like the conv's weight fragments; 4: 16 bytes out of every 64, like its four-pixel activation windows)
+template <int L, int NT, int LS = 1>
 __global__ __launch_bounds__(NT) void k(const u32x4* src, float* out, int iters, unsigned mask) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(NT) void k(const u32x4* src, float* out, int iters,
     u32x4 s0[L > 0 ? L : 1], s1[L > 0 ? L : 1];
     unsigned sink = 0;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned idx = (blockIdx.x * 64 + wave * 8) * 64 + lane;      // in 16-byte units: a wave reads 1 KB contiguous
+    unsigned idx = (blockIdx.x * 64 + wave * 8) * 64 * LS + lane * LS;      // in 16-byte units
     for (int i = 0; i < (L > 0 ? L : 1); ++i) s0[i] = s1[i] = u32x4{0, 0, 0, 0};
     for (int it = 0; it < iters; it += 2) {
 #pragma unroll
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(NT) void k(const u32x4* src, float* out, int iters,
                 if (L > 0 && (m * L) / 12 != ((m + 1) * L) / 12) {       // the (m*L/12)-th load of this iteration goes behind MFMA m
                     const int li = (m * L) / 12;
                     const u32x4* p = src + (idx & mask);
-                    idx += 64 * 13;
+                    idx += 64 * 13 * LS + (LS > 1 ? 1 : 0);
                     if (half == 0) LOAD(s0[li], p); else LOAD(s1[li], p);
                 }
             }
@@ -60,24 +61,24 @@ __global__ __launch_bounds__(NT) void k(const u32x4* src, float* out, int iters,
     out[blockIdx.x * NT + threadIdx.x] = s;
 }
 
-template <int L, int NT>
+template <int L, int NT, int LS = 1>
 static void run(const u32x4* src, float* out, size_t span_bytes, const char* name) {
     const int iters = 4000, blocks = 256;      // one block per CU: 256 threads = one wave per SIMD, 512 = two
     const unsigned mask = (unsigned)(span_bytes / 16 - 1);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<L, NT>), dim3(blocks), dim3(NT), 0, 0, src, out, 200, mask);
+    hipLaunchKernelGGL((k<L, NT, LS>), dim3(blocks), dim3(NT), 0, 0, src, out, 200, mask);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<L, NT>), dim3(blocks), dim3(NT), 0, 0, src, out, iters, mask);
+    hipLaunchKernelGGL((k<L, NT, LS>), dim3(blocks), dim3(NT), 0, 0, src, out, iters, mask);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     // MFMAs per SIMD: waves per SIMD x iters x 12
     const double per_simd = (double)(NT / 256) * iters * 12;
-    printf("{\"loads_per_12_mfma\": %d, \"block\": %d, \"span\": \"%s\", \"ms\": %.4f, \"ns_per_mfma_slot\": %.3f}\n", L, NT, name, ms,
-           ms * 1e6 / per_simd);
+    printf("{\"loads_per_12_mfma\": %d, \"block\": %d, \"lane_stride_bytes\": %d, \"span\": \"%s\", \"ms\": %.4f, \"ns_per_mfma_slot\": %.3f}\n",
+           L, NT, 16 * LS, name, ms, ms * 1e6 / per_simd);
 }
 
 int main() {
@@ -90,6 +91,7 @@ int main() {
         run<0, 256>(src, out, sp.b, sp.n); run<1, 256>(src, out, sp.b, sp.n); run<2, 256>(src, out, sp.b, sp.n);
         run<4, 256>(src, out, sp.b, sp.n); run<6, 256>(src, out, sp.b, sp.n);
         run<0, 512>(src, out, sp.b, sp.n); run<2, 512>(src, out, sp.b, sp.n); run<4, 512>(src, out, sp.b, sp.n);
+        run<2, 256, 4>(src, out, sp.b, sp.n); run<4, 256, 4>(src, out, sp.b, sp.n); run<2, 512, 4>(src, out, sp.b, sp.n); run<4, 512, 4>(src, out, sp.b, sp.n);
     }
     return 0;
 }
