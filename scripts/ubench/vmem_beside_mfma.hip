@@ -5,6 +5,7 @@
 // the time per MFMA of a pure MFMA stream with L loads per 12 MFMAs interleaved, for one and two waves per SIMD and for an
 // L1-, L2- and HBM-sized working set, loads waited for one iteration late (two register sets) so that their latency is hidden.
 // build: hipcc -O3 --offload-arch=gfx950 vmem_beside_mfma.hip -o vmem_beside_mfma ; run: ./vmem_beside_mfma
+// (first attempt on the last GPU seconds of round 3: exited after 1 s without output - not yet debugged on hardware)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -75,17 +76,21 @@ static void run(const u32x4* src, float* out, size_t span_bytes, const char* nam
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) { printf("{\"error\": \"%s\"}\n", hipGetErrorString(err)); fflush(stdout); return; }
     // MFMAs per SIMD: waves per SIMD x iters x 12
     const double per_simd = (double)(NT / 256) * iters * 12;
     printf("{\"loads_per_12_mfma\": %d, \"block\": %d, \"lane_stride_bytes\": %d, \"span\": \"%s\", \"ms\": %.4f, \"ns_per_mfma_slot\": %.3f}\n",
            L, NT, 16 * LS, name, ms, ms * 1e6 / per_simd);
+    fflush(stdout);
 }
 
 int main() {
     const size_t bytes = (size_t)1 << 30;
     u32x4* src; float* out;
-    hipMalloc(&src, bytes); hipMalloc(&out, 512 * 512 * sizeof(float));
+    if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&out, 512 * 512 * sizeof(float)) != hipSuccess) { printf("{\"error\": \"hipMalloc\"}\n"); return 1; }
     hipMemset(src, 1, bytes);
+    hipDeviceSynchronize();
     struct { size_t b; const char* n; } spans[] = {{(size_t)1 << 14, "16KB (L1)"}, {(size_t)1 << 21, "2MB (L2)"}, {(size_t)1 << 30, "1GB (HBM)"}};
     for (auto sp : spans) {
         run<0, 256>(src, out, sp.b, sp.n); run<1, 256>(src, out, sp.b, sp.n); run<2, 256>(src, out, sp.b, sp.n);
