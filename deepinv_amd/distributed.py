@@ -316,11 +316,18 @@ class DistributedProcessing:
             for i0 in range(0, len(mine), step):
                 group = mine[i0:i0 + step]
                 batch = torch.cat([T.window(xp, k) for k in group], dim=0)       # windows ride the batch axis
-                rep = lambda a: (a.repeat(len(group), *([1] * (a.ndim - 1)))        # noqa: E731  per-sample arguments
-                                 if isinstance(a, torch.Tensor) and a.ndim >= 1 and a.shape[0] == B and B > 1 else a)
-                if B == 1 and any(isinstance(a, torch.Tensor) and a.ndim >= 1 and a.shape[0] == 1 and a.numel() > 1
-                                  for a in (*args, *kwargs.values())):
-                    pass   # [1, ...] maps broadcast over the windows exactly as they did over the single sample
+                def rep(a):
+                    """arguments ride along: spatial maps ([B or 1, C, *image dims], e.g. a noise-level map) are cut into
+                    the same windows as the signal, other per-sample tensors ([B, ...]) are repeated per window, everything
+                    else ([1, ...] tensors, scalars) broadcasts over the windows as it did over the samples"""
+                    if not isinstance(a, torch.Tensor) or a.ndim < 1:
+                        return a
+                    if a.ndim == x.ndim and a.shape[2:] == x.shape[2:] and a.shape[0] in (1, B):
+                        ap = T.pad(a.expand(B, *a.shape[1:]).contiguous())
+                        return torch.cat([T.window(ap, k) for k in group], dim=0)
+                    if a.shape[0] == B and B > 1:
+                        return a.repeat(len(group), *([1] * (a.ndim - 1)))
+                    return a
                 res = self.processor(batch, *[rep(a) for a in args], **{k: rep(v) for k, v in kwargs.items()})
                 for j, k in enumerate(group):
                     T.place(out, k, res[j * B:(j + 1) * B])

@@ -187,11 +187,21 @@ def pack_up_weight(w: torch.Tensor) -> torch.Tensor:
     return w.detach().float().permute(2, 3, 0, 1).reshape(4, cin // 8, 8, cout).permute(0, 1, 3, 2).contiguous()
 
 
-# Packed weights of the training / 3-D paths are cached per (source tensor storage, version): an unfolded network calls the
-# denoiser `max_iter` times per training step with the same weights and every layer needs a pack (a dozen small torch ops) per
-# call otherwise - more host time than the kernels take.  An entry keeps its source tensor alive, so the address cannot be
-# handed to another tensor while the entry exists; an in-place optimizer step bumps the version counter.
+# Packed weights of the training / 3-D paths are cached per source tensor: an unfolded network calls the denoiser
+# `max_iter` times per training step with the same weights and every layer needs a pack (a dozen small torch ops) per
+# call otherwise - more host time than the kernels take.  One entry per (kind, storage address, shape, sub): the entry
+# remembers the tensor's version counter, and a call that finds another version REPLACES the entry (an optimizer step
+# bumps the counter of every parameter, so the packs of the previous step are dropped right there instead of piling up).
+# An entry keeps its source tensor alive, so the address cannot be handed to another tensor while the entry exists.
+# Not detected: in-place updates through `p.data` (hand-written SGD / EMA: `.data` ops do not bump the counter) and
+# inference-mode tensors (no counter) - call `clear_pack_cache()` after such an update (load_state_dict, torch.optim and
+# `deepinv_amd.training.Trainer` need nothing: they bump the counter / call it).
 _PACKS: dict = {}
+
+
+def clear_pack_cache():
+    """drop every cached weight pack (after in-place weight updates the version counter does not see)"""
+    _PACKS.clear()
 
 
 def cached_pack(kind, w, make, sub=0):
@@ -199,12 +209,12 @@ def cached_pack(kind, w, make, sub=0):
         ver = w._version
     except RuntimeError:      # inference tensors carry no version counter
         ver = -1
-    key = (kind, w.data_ptr(), ver, tuple(w.shape), sub)
+    key = (kind, w.data_ptr(), tuple(w.shape), sub)
     hit = _PACKS.get(key)
-    if hit is None:
-        if len(_PACKS) > 4096:
+    if hit is None or hit[1] != ver:
+        if hit is None and len(_PACKS) > 4096:
             _PACKS.clear()
-        hit = _PACKS[key] = (make(), w)
+        hit = _PACKS[key] = (make(), ver, w)
     return hit[0]
 
 

@@ -1,14 +1,15 @@
-"""DRUNet denoiser with an MFMA (fp32 matrix-core) inference path.
+"""DRUNet denoiser on the hand-written HIP kernels (csrc/drunet*.hip) - inference, training and ``dim=3``.
 
 Module tree and parameter names are identical to the reference (deepinv/models/drunet.py:39-101:
 ``m_head``, ``m_down{1,2,3}``, ``m_body``, ``m_up{3,2,1}``, ``m_tail``; ResBlock ``res.0``/``res.2``)
-so reference ``state_dict``s / ``.pth`` checkpoints load unchanged.
+so reference ``state_dict``s / ``.pth`` checkpoints load unchanged.  The ``nn.Conv*`` modules only hold the
+parameters: no forward of this class runs a PyTorch-ROCm (MIOpen) convolution, and an architecture the kernels do
+not cover raises instead of falling back (the PyTorch graph of the same module lives in ``tests/torch_drunet.py``,
+where it serves as an independent GPU reference).
 
-* inference (``torch.no_grad`` / eval, 2-D, default architecture) -> 64 hand-written HIP launches
-  (csrc/drunet.hip): 3x3 convs as implicit GEMM on ``v_mfma_f32_32x32x2_f32`` with ReLU, residual
-  and U-Net skip adds fused into load/epilogue; activations stay in padded channel planes.
-* training (autograd needed: ``deepinv.unfolded``) or ``dim=3`` -> the same modules run through
-  PyTorch-ROCm autograd (plumbing; hand-written conv backward is listed under "next").
+* inference (``torch.no_grad`` / eval, 2-D): 64 HIP launches, activations stay in padded channel-blocked planes;
+* gradients requested (``deepinv.unfolded``): ``models/drunet_train.py`` (forward + backward as one autograd node);
+* ``dim=3``: ``models/drunet3d.py``.
 """
 from __future__ import annotations
 
@@ -113,9 +114,6 @@ class DRUNet(Denoiser):
         self.m_tail = C(nc[0], out_channels, 3, 1, 1, bias=False)
         self.dim = dim
         self.conv_precision = DEFAULT_CONV_PRECISION
-        # "hip": the hand-written kernels (inference, training, dim = 3); "torch": the same module through PyTorch-ROCm ops
-        # (used by the tests as an independent GPU reference; never the default)
-        self.backend = "hip"
         # forward pass of the TRAINING node: "fp32" keeps the ReLU masks identical to an fp32 reference,
         # "bf16split" runs the inference kernels
         self.train_forward_precision = "fp32"
@@ -129,19 +127,6 @@ class DRUNet(Denoiser):
         self._engine = None
         if device is not None:
             self.to(device)
-
-    # ------------------------------------------------------------------ reference-shaped torch graph
-    def forward_unet_torch(self, x0):
-        """drunet.py:200-210 through PyTorch-ROCm autograd (training / 3-D)."""
-        x1 = self.m_head(x0)
-        x2 = self.m_down1(x1)
-        x3 = self.m_down2(x2)
-        x4 = self.m_down3(x3)
-        x = self.m_body(x4)
-        x = self.m_up3(x + x4)
-        x = self.m_up2(x + x3)
-        x = self.m_up1(x + x2)
-        return self.m_tail(x + x1)
 
     def _noise_map(self, x, sigma):
         """drunet.py:226-249"""
@@ -159,11 +144,11 @@ class DRUNet(Denoiser):
 
     def _use_hip(self, x):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return self.dim == 2 and not needs_grad and self.backend == "hip"
+        return self.dim == 2 and not needs_grad
 
     def _use_hip_train(self):
         """gradients requested: the hand-written backward (models/drunet_train.py) for the 2-D architectures it covers"""
-        return drunet_train.supported(self) and self.backend == "hip"
+        return drunet_train.supported(self)
 
     def _precision(self):
         if self.conv_precision not in CONV_PRECISIONS:
@@ -175,12 +160,13 @@ class DRUNet(Denoiser):
             raise HipExtensionError("deepinv_amd.models.DRUNet runs only on a HIP device; there is no CPU fallback")
         if self._use_hip(x):
             run = lambda inp: self._hip_forward(inp[:, :-1], inp[:, -1:])
-        elif drunet3d.supported(self) and self.backend == "hip":
+        elif drunet3d.supported(self):
             run = lambda inp: drunet3d.forward3d(self, inp)             # volumes as stacks of slices on the 2-D kernels
         elif self._use_hip_train():
             run = lambda inp: drunet_train.forward_train(self, inp)     # forward AND backward on the HIP kernels
-        else:
-            run = self.forward_unet_torch
+        else:   # no second backend: what the HIP kernels do not cover is an error, not a PyTorch-ROCm graph
+            raise NotImplementedError(f"DRUNet(dim={self.dim}, nc={self.nc}) with gradients: only 4-level architectures are "
+                                      "covered by the hand-written HIP forward / backward (models/drunet_train.py, drunet3d.py)")
         xin = torch.cat((x, self._noise_map(x, sigma)), 1)
         safe = all(s % 8 == 0 and s > 31 for s in xin.shape[2:])
         if safe:

@@ -40,8 +40,10 @@ def _r16(c):
 
 
 _POOL: dict = {}        # (device, channels, level shape) -> released activation buffers
-_POOL_MAX_BYTES = 64 << 30
+POOL_MAX_BYTES = 16 << 30      # cap of the free list (config 4's training step recycles about 6 GiB)
+CHECK_RECYCLED = False         # debugging aid (the GPU test switches it on): verify the invariant below on every reuse
 _pool_bytes = 0
+_pool_sig = None               # (device, B, D, H, W) of the last call: another problem shape drops the whole list
 
 
 class Vol:
@@ -60,14 +62,27 @@ class Vol:
             global _pool_bytes
             self.t = free.pop()
             _pool_bytes -= self.t.numel() * 4
+            if CHECK_RECYCLED:
+                self._check_clean(channels)
         else:
             self.t = torch.zeros((_r64(channels) // 8, lv.g.cs, 8), device=device, dtype=torch.float32)
+
+    def _check_clean(self, channels):
+        """the invariant recycling rests on: frames, padding slices, guard planes, slack and padded channel blocks of a
+        released buffer are exactly zero (only interior voxels of real channel blocks may hold anything)"""
+        lv, t = self.lv, self.t.clone()
+        b, d, h, w = lv.B, lv.D, lv.H, lv.W
+        vol = t[:, lv.guard + lv.g.sl: lv.guard + lv.g.sl + lv.g.np].view(t.shape[0], b, d + 2, h + 2, -1, 8)
+        vol[:(int(channels) + 7) // 8, :, 1:-1, 1:h + 1, 1:w + 1] = 0
+        bad = int(torch.count_nonzero(t))
+        if bad:
+            raise AssertionError(f"recycled activation buffer {self.key}: {bad} non-zero values outside the interior")
 
     def __del__(self):
         global _pool_bytes
         try:
             t, key = self.t, self.key
-            if _pool_bytes + t.numel() * 4 <= _POOL_MAX_BYTES:
+            if _pool_bytes + t.numel() * 4 <= POOL_MAX_BYTES:
                 _POOL.setdefault(key, []).append(t)
                 _pool_bytes += t.numel() * 4
         except Exception:       # interpreter shutdown
@@ -151,7 +166,8 @@ def add(lv, a: Vol, b: Vol) -> Vol:
 
 
 def release_buffers():
-    """drop the recycled activation buffers (they are kept between calls; 64 GiB cap)"""
+    """drop the recycled activation buffers (kept between calls of the SAME problem shape, at most POOL_MAX_BYTES; a call
+    with another shape drops them by itself)"""
     global _pool_bytes
     _POOL.clear()
     _pool_bytes = 0
@@ -187,6 +203,10 @@ class DRUNet3dFunction(torch.autograd.Function):
             raise ValueError("3-D DRUNet on the HIP kernels needs depth, height and width to be multiples of 8")
         train = any(ctx.needs_input_grad[1:])
         f32 = train and getattr(model, "train_forward_precision", "fp32") == "fp32"
+        global _pool_sig
+        if _pool_sig != (dev, B, D, H, Wd):       # buffers of another problem shape would never be reused: free them
+            release_buffers()
+            _pool_sig = (dev, B, D, H, Wd)
         lv = [Level(B, D >> i, H >> i, Wd >> i) for i in range(4)]
         W = {n: p.detach().float() for n, p in zip(names, params)}      # true shapes; each kernel pads what it needs
         # pack the input volume: [B, C, D, H, W] -> slices [B (D+2), C, H, W] with zero end slices

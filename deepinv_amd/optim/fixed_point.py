@@ -30,8 +30,13 @@ class FixedPoint(nn.Module):
         self.call_ctx = None
         # device-side early stop (optimizers.py:703-739 without the per-iteration host sync): `conv_crit_fn(X_prev, X)`
         # returns the criterion as a device scalar, `on_converged(flag)` receives the device flag at the end of the call
+        # `thres_conv` may be a callable: the owner's threshold is then read live at every call (a user who changes
+        # `model.thres_conv` after construction gets the new value on the device path too)
         self.conv_crit_fn, self.thres_conv, self.on_converged = conv_crit_fn, thres_conv, on_converged
         self.poll_every = 4
+
+    def _thres(self):
+        return self.thres_conv() if callable(self.thres_conv) else self.thres_conv
 
     def single_iteration(self, X, it, *args, **kwargs):
         """fixed_point.py:363-406"""
@@ -76,7 +81,7 @@ class FixedPoint(nn.Module):
         """early_stop can be decided on the device when nothing else needs the host each iteration"""
         import torch
 
-        return (self.early_stop and self.conv_crit_fn is not None and self.thres_conv is not None and not compute_metrics
+        return (self.early_stop and self.conv_crit_fn is not None and self._thres() is not None and not compute_metrics
                 and self.backtracking_config is None and not torch.is_grad_enabled() and X is not None
                 and all(isinstance(t, torch.Tensor) and t.is_cuda for t in X["est"]))
 
@@ -94,7 +99,7 @@ class FixedPoint(nn.Module):
                 cost = torch.where(done, X_prev["cost"], cost)
             X_new = {"est": est, "cost": cost}
         if it > 1:
-            c = self.conv_crit_fn(X_prev, X_new) < self.thres_conv
+            c = self.conv_crit_fn(X_prev, X_new) < self._thres()
             done = c if done is None else (done | c)
         return X_new, done
 

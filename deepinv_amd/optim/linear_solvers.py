@@ -135,7 +135,10 @@ def lsqr(A: Callable, AT: Callable, b, eta=0.0, x0=None, tol=1e-6, conlim=1e8, m
 def _givens(a, b):
     """numerically careful plane rotation (c, s, r) with c a + s b = r (Choi's sym-ortho, as scipy / lsqr.py:229-262).  The
     reference picks one of its four formulas for the whole batch with `torch.any` (a host sync each); here every element
-    takes the formula its own (a, b) calls for - the same rotation, chosen without leaving the device."""
+    takes the formula its own (a, b) calls for, chosen without leaving the device.  Intentional difference: in a batch
+    that mixes zero and non-zero entries (or |b| > |a| with |b| <= |a|) the reference applies ONE branch to all elements,
+    so single elements of such a batch get the rotation from another (equally valid, differently rounded) formula
+    there; the rotations agree to rounding and the golden test holds at 1e-7."""
     a, b = torch.broadcast_tensors(torch.as_tensor(a), torch.as_tensor(b))
     one = torch.ones_like(a)
     big_b = b.abs() > a.abs()

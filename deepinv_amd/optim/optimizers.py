@@ -103,8 +103,11 @@ class BaseOptim(Reconstructor):
             init_metrics_fn=self.init_metrics_fn, init_iterate_fn=self.init_iterate_fn,
             update_metrics_fn=self.update_metrics_fn, max_iter=max_iter, early_stop=early_stop,
             backtracking_config=self.backtracking_config, verbose=verbose,
-            show_progress_bar=show_progress_bar, conv_crit_fn=self.conv_crit, thres_conv=thres_conv,
-            on_converged=self._set_converged)
+            show_progress_bar=show_progress_bar,
+            # device-side early stop only for the stock criterion: a subclass that overrides check_conv_fn keeps the host
+            # path (its override is what decides); the threshold is read live
+            conv_crit_fn=self.conv_crit if type(self).check_conv_fn is BaseOptim.check_conv_fn else None,
+            thres_conv=self._get_thres_conv, on_converged=self._set_converged)
 
     # ---- per-iteration lookups (optimizers.py:464-500)
     def update_params_fn(self, it):
@@ -183,6 +186,9 @@ class BaseOptim(Reconstructor):
             self.params_algo["stepsize"] = [self.backtracking_config.eta * stepsize]
             return False
         return True
+
+    def _get_thres_conv(self):
+        return self.thres_conv       # (a bound method, not a lambda: copy.deepcopy re-binds it to the copy)
 
     def conv_crit(self, X_prev, X):
         """the convergence criterion as a tensor (a device scalar on the HIP path; optimizers.py:703-739)"""

@@ -102,8 +102,12 @@ class Trainer:
         if self.ckpt_pretrained is not None:
             ck = torch.load(self.ckpt_pretrained, map_location=self.device)
             self.model.load_state_dict(ck["state_dict"])
-            if "optimizer" in ck and self.optimizer is not None:
+            if ck.get("optimizer") is not None and self.optimizer is not None:
                 self.optimizer.load_state_dict(ck["optimizer"])
+            if ck.get("scheduler") is not None and self.scheduler is not None:     # trainer.py:592-593
+                self.scheduler.load_state_dict(ck["scheduler"])
+            self.train_loss_history = list(ck.get("loss", self.train_loss_history))
+            self.eval_metric_history = list(ck.get("eval_metrics", self.eval_metric_history))
             self.epoch_start = ck.get("epoch", -1) + 1
         if train and self.optimizer is None:
             raise ValueError("an optimizer is needed for training")
@@ -208,7 +212,7 @@ class Trainer:
             with torch.no_grad():
                 for m in self.metrics:
                     v = m(x_net, x)
-                    logs[getattr(m, "__name__", m.__class__.__name__).strip("_")] = float(torch.as_tensor(v).float().mean())
+                    logs[self._metric_name(m)] = float(torch.as_tensor(v).float().mean())
         return x_net, logs
 
     def step(self, epoch, train_ite=None, train=True, last_batch=False):
@@ -232,16 +236,29 @@ class Trainer:
         if self.save_path is None:
             return
         os.makedirs(self.save_path, exist_ok=True)
-        torch.save({"epoch": epoch, "state_dict": self.model.state_dict(),
-                    "optimizer": self.optimizer.state_dict() if self.optimizer else None}, os.path.join(self.save_path, filename))
+        # the reference's fields (trainer.py:1192-1198): epoch, state_dict, loss history, optimizer, scheduler, eval metrics
+        torch.save({"epoch": epoch, "state_dict": self.model.state_dict(), "loss": list(self.train_loss_history),
+                    "optimizer": self.optimizer.state_dict() if self.optimizer else None,
+                    "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None,
+                    "eval_metrics": list(self.eval_metric_history)}, os.path.join(self.save_path, filename))
+
+    def _metric_name(self, m):
+        return getattr(m, "__name__", m.__class__.__name__).strip("_")
+
+    def _eval_value(self, logs):
+        """the value model selection runs on: the FIRST metric's logged value (not a hard-wired "psnr")"""
+        return logs.get(self._metric_name(self.metrics[0]), 0.0)
+
+    def _better(self, val, best):
+        """metrics with `lower_better = True` (the reference's Metric attribute) improve downwards"""
+        return val < best if getattr(self.metrics[0], "lower_better", False) else val > best
 
     def train(self):
         self.setup_train()
         best, since_best = None, 0
         for epoch in range(self.epoch_start, self.epochs):
             self.current_train_iterators = [iter(loader) for loader in self.train_dataloader]
-            batches = min(min(len(loader) - int(getattr(loader, "drop_last", False) and False) for loader in self.train_dataloader),
-                          self.max_batch_steps)
+            batches = min(min(len(loader) for loader in self.train_dataloader), self.max_batch_steps)
             self.model.train()
             meter = _Avg()
             for i in range(batches):
@@ -256,7 +273,7 @@ class Trainer:
             if self.eval_dataloader and (epoch + 1) % self.eval_interval == 0:
                 val = self._evaluate(epoch)
                 self.eval_metric_history.append(val)
-                if best is None or val > best:
+                if best is None or self._better(val, best):
                     best, since_best = val, 0
                     self.save_model("ckp_best.pth.tar", epoch)
                 else:
@@ -274,21 +291,23 @@ class Trainer:
         try:
             for _ in range(min(len(loader) for loader in self.eval_dataloader)):
                 _, logs = self.step(epoch, train=False)
-                vals.append(logs.get("psnr", 0.0))
+                vals.append(self._eval_value(logs))
         finally:
             self.G = saved_G
         return float(np.mean(vals)) if vals else 0.0
 
     def test(self, test_dataloader, **kwargs):
-        """average of the metrics over a test set (trainer.py:1494-1600): {"PSNR": ..., "PSNR_std": ...}"""
+        """average of the first metric over a test set (trainer.py:1494-1600): {"<NAME>": ..., "<NAME>_std": ...}, the name
+        upper-cased as the reference prints it ("PSNR" for the default metric)"""
         self.eval_dataloader = test_dataloader
         self.setup_train(train=False)
         self.current_eval_iterators = [iter(loader) for loader in self.eval_dataloader]
         vals = []
         for _ in range(min(len(loader) for loader in self.eval_dataloader)):
             _, logs = self.step(0, train=False)
-            vals.append(logs.get("psnr", 0.0))
-        return {"PSNR": float(np.mean(vals)), "PSNR_std": float(np.std(vals))}
+            vals.append(self._eval_value(logs))
+        name = self._metric_name(self.metrics[0]).upper()
+        return {name: float(np.mean(vals)), name + "_std": float(np.std(vals))}
 
 
 def train(model, physics, optimizer, train_dataloader, epochs=100, losses=None, eval_dataloader=None, *args, **kwargs):

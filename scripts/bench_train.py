@@ -1,5 +1,5 @@
 """One training step (forward + backward) of unfolded PnP-PGD with a DRUNet prior on 2-D multi-coil MRI:
-the hand-written DRUNet backward (DRUNet.backend = "hip", models/drunet_train.py) vs the PyTorch-ROCm graph (MIOpen).
+the hand-written DRUNet backward (models/drunet_train.py) vs the PyTorch-ROCm graph (MIOpen).
 Usage: python scripts/bench_train.py [B] [iters]"""
 import json
 import os
@@ -36,7 +36,11 @@ def step():
 
 
 for mode, prec in (("torch", ""), ("hip", "fp32"), ("hip", "bf16split")):
-    den.backend = mode
+    den.__dict__.pop("forward", None)
+    if mode == "torch":     # the PyTorch-ROCm graph of the same module lives with the tests (the product has no such path)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from torch_drunet import torch_forward
+        den.forward = lambda xx, ss, _d=den: torch_forward(_d, xx, ss)
     if prec:
         den.train_forward_precision = prec
     step()

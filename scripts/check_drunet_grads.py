@@ -1,4 +1,4 @@
-"""DRUNet gradients of the two GPU paths (DINV_DRUNET_TRAIN=torch: PyTorch-ROCm graph / MIOpen; hip: models/drunet_train.py)
+"""DRUNet gradients of the two GPU paths (tests/torch_drunet.py: PyTorch-ROCm graph / MIOpen; the product: models/drunet_train.py)
 against an fp64 CPU run of the same module: image + noise-map gradient and the worst / median weight-gradient error.
 Usage: python scripts/check_drunet_grads.py [resblock gain, e.g. 1.0]   (DINV_DRUNET_TRAIN_PRECISION=bf16s for the
 inference kernels in the forward pass: shows the ReLU-mask flips discussed in models/drunet_train.py)"""
@@ -6,6 +6,8 @@ import copy, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepinv_amd as dinv
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from torch_drunet import forward_unet_torch, torch_forward   # the PyTorch graph of the module is test infrastructure
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -22,11 +24,13 @@ sig0 = 0.05 + 0.1 * torch.rand(B, 1, H, W, generator=g)
 v = torch.randn(B, 2, H, W, generator=g)
 ref = copy.deepcopy(model).cpu().double()
 xin = torch.cat((x0, sig0), 1).double().requires_grad_(True)
-(ref.forward_unet_torch(xin) * v.double()).sum().backward()
+(forward_unet_torch(ref, xin) * v.double()).sum().backward()
 gw_ref = {n: p.grad for n, p in ref.named_parameters()}
 
 def run(mode):
-    model.backend = mode
+    model.__dict__.pop("forward", None)
+    if mode == "torch":
+        model.forward = lambda xx, ss: torch_forward(model, xx, ss)
     model.zero_grad()
     x = x0.to(dev).requires_grad_(True)
     sig = sig0.to(dev).requires_grad_(True)

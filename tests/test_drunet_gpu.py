@@ -40,7 +40,8 @@ def test_drunet_torch_training_path_matches_hip(dev):
     with torch.no_grad():
         a = model(x, 0.1)
     xin = torch.cat((x, torch.full((1, 1, 64, 64), 0.1, device=dev)), 1)
-    b = model.forward_unet_torch(xin)
+    from torch_drunet import forward_unet_torch
+    b = forward_unet_torch(model, xin)
     assert rel_err(a, b) < 1e-4
 
 
@@ -354,12 +355,20 @@ def test_tile_parallel_drunet_single_rank(dev):
     assert rel_err(y, ref) < 1e-5
 
 
+def _backend(model, mode):
+    """mode "hip": the product; "torch": the PyTorch-ROCm graph of the same module (tests/torch_drunet.py)"""
+    import contextlib
+
+    from torch_drunet import torch_backend
+    return torch_backend(model) if mode == "torch" else contextlib.nullcontext(model)
+
+
 def _grad_run(model, x0, sig0, v, mode, monkeypatch=None):
-    model.backend = mode
     model.zero_grad()
     x = x0.clone().requires_grad_(True)
     sig = sig0.clone().requires_grad_(True)
-    y = model(x, sig)
+    with _backend(model, mode):
+        y = model(x, sig)
     (y * v).sum().backward()
     return y.detach(), x.grad, sig.grad, {n: p.grad.clone() for n, p in model.named_parameters()}
 
@@ -439,9 +448,9 @@ def test_drunet_hip_backward_frozen_weights_and_unsafe_shape(dev):
     y = model(x, 0.07)
     y.square().sum().backward()
     g_hip = x.grad.clone()
-    model.backend = "torch"
     x2 = x.detach().clone().requires_grad_(True)
-    model(x2, 0.07).square().sum().backward()
+    with _backend(model, "torch"):
+        model(x2, 0.07).square().sum().backward()
     assert rel_err(g_hip, x2.grad) < 1e-4
 
 
@@ -460,18 +469,17 @@ def test_drunet3d_hip_matches_torch_graph(dev, monkeypatch):
     sig0 = (0.05 + 0.1 * torch.rand(B, 1, D, H, W, generator=g)).to(dev)
     v = torch.randn(B, 2, D, H, W, generator=g).to(dev)
     with torch.no_grad():
-        model.backend = "torch"
-        y_ref = model(x0, sig0)
-        model.backend = "hip"
+        with _backend(model, "torch"):
+            y_ref = model(x0, sig0)
         y_inf = model(x0, sig0)            # bf16-split kernels
     assert rel_err(y_inf, y_ref) < 1e-4
 
     def run(mode):
-        model.backend = mode
         model.zero_grad()
         x = x0.clone().requires_grad_(True)
         sig = sig0.clone().requires_grad_(True)
-        y = model(x, sig)
+        with _backend(model, mode):
+            y = model(x, sig)
         (y * v).sum().backward()
         return y.detach(), x.grad, sig.grad, {n: p.grad.clone() for n, p in model.named_parameters()}
 
@@ -492,11 +500,14 @@ def test_drunet3d_hip_matches_torch_graph(dev, monkeypatch):
         for t in bufs:
             vol = t[:, lv.guard + lv.g.sl: lv.guard + lv.g.sl + lv.g.np].view(t.shape[0], b, d + 2, h + 2, -1, 8)
             vol[:(ch + 7) // 8, :, 1:-1, 1:h + 1, 1:w + 1] = float("nan")     # (blocks of padded channels stay zero)
+    monkeypatch.setattr(M3, "CHECK_RECYCLED", True)    # every reuse asserts: nothing but interiors is non-zero
     y_h2, gx_h2, gs_h2, gw_h2 = run("hip")
     assert torch.equal(y_h2, y_h) and torch.equal(gx_h2, gx_h) and torch.equal(gs_h2, gs_h)
     assert all(torch.equal(gw_h2[n], gw_h[n]) for n in gw_h)
     with torch.no_grad():
         assert torch.equal(model(x0, sig0), y_inf)
+        model(x0[:, :, :8].contiguous(), sig0[:, :, :8].contiguous())      # another problem shape drops the old buffers
+    assert all(k[3] <= 8 for k in M3._POOL)
     M3.release_buffers()
     assert not M3._POOL
 

@@ -128,3 +128,39 @@ def test_cfg5_downsampling_diffpir_256(dev, monkeypatch):
     # distance to the reference's sample is the REFERENCE's rounding error: `out_err_vs_exact` in the fixture
     assert rel_err(sub(out, st), d["out"]) < max(TOL, 2.0 * float(d["out_err_vs_exact"]))
     assert rel_err(sub(out, st), d["out_exact"]) < TOL       # ... and against the fp64 evaluation of the same sample path
+
+
+@pytest.mark.parametrize("gain_tag", ["", "_gain"])
+def test_cfg2_multicoil_pnp_pgd_320(dev, gain_tag):
+    """The HEADLINE configuration (BASELINE configs[1]) against the REAL reference (tests/golden/cfg2_named.npz, written by
+    make_golden_r4.py through deepinv.physics.MultiCoilMRI and deepinv.optim.PGD): 8-coil 320x320 MultiCoilMRI A / A_adjoint
+    and the 50-iteration PnP-PGD reconstruction with DRUNet(2->2), batch 32 exactly as bench.py builds it (unit 0 is the
+    fixture's slice), in BOTH arithmetic settings of the denoiser - once with the reference's weight initialisation
+    (ResBlock gain 0.2) and once with O(1)-gain ResBlock convolutions, where the ResBlock kernels' rounding is not hidden
+    behind the identity path"""
+    import deepinv_amd as dinv
+    from bench import make_problem
+    from oracle import drunet_cpu as OD
+
+    d = load("cfg2_named")
+    st, iters = int(d["stride"]), int(d["iters"])
+    B, H, W, coils = 32, 320, 320, 8
+    physics, x, y, _, _ = make_problem(dinv, B, 0, H, W, coils, dev)
+    if gain_tag == "":
+        y0 = physics.A(x)
+        assert rel_err(sub(y0[:1], st), d["y"]) < TOL
+        assert bool(((y0 == 0) == (physics.mask[:, :, None].expand_as(y0) == 0)).all())       # bit-exact mask indexing
+        assert rel_err(sub(physics.A_adjoint(y)[:1], st), d["yadj"]) < TOL
+    gain = None if gain_tag == "" else float(d["res_gain"])
+    den = dinv.models.DRUNet(2, 2, pretrained=None).to(dev).eval()
+    den.load_state_dict(OD.init_state_dict(2, 2, seed=int(d["drunet_seed"]), res_gain=gain))
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=1.0, g_param=0.05,
+                           max_iter=iters, early_stop=False)
+    from deepinv_amd.models.drunet import CONV_PRECISIONS
+    for prec in CONV_PRECISIONS:
+        den.conv_precision = prec
+        with torch.no_grad():
+            rec = model(y, physics)
+        assert torch.isfinite(rec).all()
+        err = rel_err(sub(rec[:1], st), d["rec" + gain_tag])
+        assert err < TOL, (prec, gain_tag, err)
