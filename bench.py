@@ -8,7 +8,9 @@ A / A_adjoint GB/s against the HBM roofline.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one full 50-iteration PnP-PGD reconstruction of the global batch (inputs already
-resident in HBM).  Multi-GPU: the batch is sharded in contiguous slabs, one process per GPU,
+resident in HBM).  The headline leg (`value`) runs the denoiser with fp32 multiplies on the fp32 matrix
+cores (the reference's arithmetic type); the bf16-split throughput setting is a companion leg
+(`value_bf16split`).  Multi-GPU: the batch is sharded in contiguous slabs, one process per GPU,
 reconstructions combined by one RCCL all-gather per step (inside the timed region);
 total work is fixed as N grows ("scaling": "strong", the north_star's >=6x@8 target).
 Prints ONE JSON line on rank 0.
@@ -64,7 +66,8 @@ def main():
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--coils", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the companion timing with fp32 multiplies")
+    ap.add_argument("--no-split-leg", "--no-fp32-leg", dest="no_split_leg", action="store_true",
+                    help="skip the companion timing of the bf16-split throughput setting")
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the operator rows of configs 3-5")
     args = ap.parse_args()
@@ -122,19 +125,30 @@ def main():
             dt = float(t.item())
         return o, dt, prof
 
+    # The headline leg runs the denoiser in the reference's arithmetic type: fp32 multiplies on the fp32 matrix cores
+    # (conv_precision = "fp32": Winograd F(4x4,3x3) for the ResBlock convolutions).  The companion leg is the throughput
+    # setting with narrower multiplies (bf16 x2 operand split, 16 significand bits per operand): fewer steps, its own
+    # ms_per_step, reported under *_bf16split and never as `value`.
+    denoiser.conv_precision = "fp32"
     out, elapsed, conv_prof = timed(args.warmup, args.steps)
     assert torch.isfinite(out).all()
-    # companion leg in the reference's arithmetic type: fp32 multiplies on the fp32 matrix cores (the ONE precision switch
-    # of the denoiser, models/drunet.py); fewer steps, its own ms_per_step, printed next to the headline
-    fp32_leg = None
-    if not args.no_fp32_leg:
-        denoiser.conv_precision = "fp32"
-        n32 = max(2, args.steps // 4)
-        out32, el32, prof32 = timed(1, n32)
+    split_leg = None
+    if not args.no_split_leg:
         denoiser.conv_precision = "bf16split"
-        fp32_leg = {"value_fp32": round(args.batch * n32 / el32, 4), "ms_per_step_fp32": round(el32 / n32 * 1e3, 2),
-                    "steps_fp32": n32, "dtype_fp32": "f32 (v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) for the ResBlock convs)",
-                    "rel_diff_bf16split_vs_fp32": float(f"{float((out - out32).norm() / out32.norm()):.3e}")}
+        n2 = max(2, args.steps // 4)
+        out2, el2, prof2 = timed(1, n2)
+        denoiser.conv_precision = "fp32"
+        k2, p2 = max(prof2.items(), key=lambda kv: kv[1]["ms"])
+        split_leg = {"value_bf16split": round(args.batch * n2 / el2, 4), "ms_per_step_bf16split": round(el2 / n2 * 1e3, 2),
+                     "steps_bf16split": n2,
+                     "dtype_bf16split": "f32 in/out; ResBlock convs = Winograd F(2,3) along rows, every multiply as bf16 x2 exact "
+                                        "operand split (3 products: 16 significand bits per operand), f32 accumulate",
+                     "roofline_bf16split": {"kernel": k2, "achieved": round(p2["direct_flops"] / (p2["ms"] * 1e-3) / 1e12, 2),
+                                            "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                                            "frac": round(p2["direct_flops"] / (p2["ms"] * 1e-3) / MFMA_BF16_PEAK, 4),
+                                            "executed": round(p2["mfma_flops"] / (p2["ms"] * 1e-3) / 1e12, 2),
+                                            "avg_launch_ms": round(p2["ms"] / max(p2["launches"], 1), 4)},
+                     "rel_diff_bf16split_vs_fp32": float(f"{float((out2 - out).norm() / out.norm()):.3e}")}
 
     # ---- operator GB/s (outside the timed region)
     ops = []
@@ -160,29 +174,46 @@ def main():
             row.pop("frac_hbm_peak")    # meaningless for this operator
         ops.append(row)
 
+    def loop_row(name, cfg, batch, fn, gflop, unit, precision):
+        """one whole reconstruction loop of another BASELINE config at its per-GPU shard: wall time of the second of two runs"""
+        with torch.no_grad():
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+        ops.append({"op": name, "config": cfg, "batch": batch, "ms": round(t * 1e3, 1), unit: round(batch / t, 3),
+                    "denoiser_TFLOP_per_s": round(gflop / t / 1e3, 1), "conv_precision": precision,
+                    "finite": bool(torch.isfinite(o).all())})
+
     alg = (B_local * 2 * H * W + B_local * 2 * args.coils * H * W) * 4 + args.coils * H * W * 8 + 2 * H * W * 4
     op_row("MultiCoilMRI.A", "cfg2", B_local, lambda: physics.A(x_true), alg)
     op_row("MultiCoilMRI.A_adjoint", "cfg2", B_local, lambda: physics.A_adjoint(y), alg)
     op_row("MultiCoilMRI.A_adjoint_A", "cfg2", B_local, lambda: physics.A_adjoint_A(x_true), 2 * B_local * 2 * H * W * 4
            + args.coils * H * W * 8 + 2 * H * W * 4)
     if world == 1 and not args.no_other_configs:
-        other_config_ops(dinv, device, op_row, lambda: ops[-1])
+        other_config_ops(dinv, device, op_row, lambda: ops[-1], loop_row)
 
     if rank == 0:
         slices_per_s = args.batch * args.steps / elapsed
         # dominant kernel = the one with the largest share of the timed region
         kname, kp = max(conv_prof.items(), key=lambda kv: kv[1]["ms"]) if conv_prof else ("none", None)
-        bf16 = "split" in kname or "bf16" in kname   # bf16-split convolution: priced against the bf16 matrix peak
-        peak = MFMA_BF16_PEAK if bf16 else MFMA_F32_PEAK
+        peak = MFMA_F32_PEAK        # the headline leg multiplies in fp32 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32)
         # roofline.achieved = ALGORITHMIC flops (direct 3x3 convolution: 2*9*Cin*Cout*B*H*W per launch, SURVEY 8d) / HIP-event
-        # time of the launches; the flops the kernel EXECUTES on the matrix pipe (three bf16 products per multiply; 16/36 of
-        # the direct count per 2x2 tile for fp32 Winograd) are reported next to it as `executed`
+        # time of the launches.  A Winograd kernel EXECUTES fewer multiplies than that count (36 instead of 144 per 4x4 output
+        # tile and channel pair for F(4x4,3x3), 16 instead of 36 per 2x2 tile for F(2x2,3x3)), so `frac` = algorithmic / peak
+        # can exceed 1; what the kernel really issues on the matrix pipe is `executed` / `frac_executed` (how well the pipe is used)
         achieved = kp["direct_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
         executed = kp["mfma_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
         all_ms = sum(v["ms"] for v in conv_prof.values())
         all_direct = sum(v["direct_flops"] for v in conv_prof.values())
-        dtype = ("f32 in/out; ResBlock convs = Winograd F(2,3) along rows, every multiply as bf16 x2 exact operand split (3 products), "
-                 "f32 accumulate") if "wsplit" in kname else "f32 in/out; ResBlock convs = bf16 x2 exact operand split (3 products), f32 accumulate"
+        kdesc = {"conv3x3_wino4_kernel": "DRUNet 3x3 conv as Winograd F(4x4,3x3), v_mfma_f32_32x32x2_f32",
+                 "conv3x3_wino_kernel": "DRUNet 3x3 conv as Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32",
+                 "conv3x3_kernel": "DRUNet 3x3 conv, direct, v_mfma_f32_32x32x2_f32"}.get(kname, kname)
+        dtype = ("f32: every multiply and accumulate in fp32 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32); ResBlock convs as "
+                 + ("Winograd F(4x4,3x3)" if kname == "conv3x3_wino4_kernel" else "Winograd F(2x2,3x3)" if kname == "conv3x3_wino_kernel"
+                    else "direct 3x3") + ", U = G g G^T formed in fp64 and rounded once")
         # HBM bytes per launch of the dominant kernel: measured by separate rocprofv3 --pmc passes (TCC_EA0_RDREQ x 64 B x 2
         # [gfx950 wide-load correction] + TCC_EA0_WRREQ x 64 B, averaged over the launches of one DRUNet call) and
         # recorded, with the commit and configuration they were taken at, in profiles/pmc_traffic.json
@@ -209,14 +240,12 @@ def main():
                                    "DRUNet(2->2, random init), global batch %d" % args.batch,
                        "global_batch": args.batch, "per_gpu_batch": B_local, "iters": args.iters,
                        "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if world > 1 else "none",
-                       "conv_precision": "bf16split", "loop_graph": bool(getattr(model.fixed_point, "use_graph", False))},
-            "roofline": {"bound": "mfma", "kernel": kname + (" (DRUNet 3x3 conv as Winograd F(2,3) along rows, v_mfma_f32_32x32x16_bf16, split operands)"
-                                                              if "wsplit" in kname else
-                                                              " (DRUNet 3x3 conv, v_mfma_f32_32x32x16_bf16, split operands)" if bf16
-                                                              else " (DRUNet 3x3 conv, v_mfma_f32_32x32x2_f32)"),
+                       "conv_precision": "fp32", "loop_graph": bool(getattr(model.fixed_point, "use_graph", False))},
+            "roofline": {"bound": "mfma", "kernel": f"{kname} ({kdesc})",
                          "achieved": round(achieved / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "flops": "algorithmic: direct 3x3 convolution, 2*9*Cin*Cout*B*H*W per launch",
+                         "flops": "algorithmic: direct 3x3 convolution, 2*9*Cin*Cout*B*H*W per launch (a Winograd kernel executes "
+                                  "fewer: see executed / frac_executed)",
                          "executed": round(executed / 1e12, 2), "frac_executed": round(executed / peak, 4),
                          "launches": kp["launches"] if kp else 0,
                          "avg_launch_ms": round(kp["ms"] / max(kp["launches"], 1), 4) if kp else 0.0,
@@ -225,14 +254,85 @@ def main():
                          "kernels": {k: {"ms": round(v["ms"], 2), "launches": v["launches"]} for k, v in conv_prof.items()}},
             "operators": ops,
         }
-        if fp32_leg:
-            res.update(fp32_leg)
+        if split_leg:
+            res.update(split_leg)
+        if world == 1:
+            res["layer_rel_err_vs_fp64"] = layer_errors(device)
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
             res["cpu_baseline"] = cpu_baseline(denoiser, maps, mask, H, W, args.coils, args.iters, y_cpu=y.cpu(), x_gpu=out.cpu())
             res["parity_rel_err_50it"] = res["cpu_baseline"].pop("parity_rel_err_max")
             res["parity_slices"] = res["cpu_baseline"].pop("parity_slices")
+            if split_leg:
+                res["parity_rel_err_50it_bf16split"] = float(f"{float((out2[:1].cpu().double() - res['cpu_baseline']['_rec0'].double()).norm() / res['cpu_baseline']['_rec0'].double().norm()):.3e}")
+            res["cpu_baseline"].pop("_rec0", None)
+            ug = unit_gain_parity(dinv, model, denoiser, y, physics, args.iters)
+            if ug:
+                res["parity_unit_gain_50it"] = ug
         print(json.dumps(res))
     ctx.__exit__(None, None, None)
+
+
+def layer_errors(device, B=4, H=80, C=256):
+    """relative l2 error of ONE ResBlock convolution (level-2 shape of the headline configuration: 256 channels, 80x80) of
+    every kernel against an fp64 evaluation of the same convolution, random normal inputs and weights"""
+    from deepinv_amd.hip import drunet as K
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, C, H, H, generator=g).to(device)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).to(device)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    geo = K.geom(B, H, H)
+    xa = K.alloc(geo, C, device)
+    xa[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:H + 1] = x.view(B, -1, 8, H, H).permute(1, 0, 3, 4, 2)
+    out = {}
+
+    def err(run):
+        ya = K.alloc(geo, C, device)
+        run(ya)
+        y = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:H + 1].permute(1, 0, 4, 2, 3).reshape(B, C, H, H)
+        return float(f"{float((y.double() - ref).norm() / ref.norm()):.3e}")
+
+    wd, ci, co = K.pack_conv3x3_weight(w)
+    out["fp32_direct (conv3x3_kernel)"] = err(lambda ya: K.conv3x3(geo, xa, wd, ci, co, ya))
+    w2 = K.pack_winograd_weight(w)
+    out["fp32_winograd_F(2x2,3x3) (conv3x3_wino_kernel)"] = err(lambda ya: K.conv3x3_winograd(geo, xa, w2, C, C, ya))
+    w4 = K.pack_winograd4_weight(w)
+    out["fp32_winograd_F(4x4,3x3) (conv3x3_wino4_kernel)"] = err(lambda ya: K.conv3x3_winograd4(geo, xa, w4, C, C, ya))
+    ws = K.pack_split2d_weight(w)
+    out["bf16x2_direct (conv3x3_split2d_kernel)"] = err(lambda ya: K.conv3x3_split(geo, xa, ws, C, C, ya))
+    ww = K.pack_wsplit_weight(w)
+    out["bf16x2_winograd_F(2,3) (conv3x3_wsplit_kernel)"] = err(lambda ya: K.conv3x3_wsplit(geo, xa, ww, C, C, ya))
+    return out
+
+
+def unit_gain_parity(dinv, model, denoiser, y, physics, iters):
+    """50-iteration parity with O(1)-gain ResBlock convolutions against the REAL reference: the denoiser takes the weights of
+    tests/golden/cfg2_named.npz (made by tests/golden/make_golden_r4.py through deepinv itself on slice 0 of this very batch),
+    the loop runs on the whole batch in both arithmetic settings, slice 0 is compared with the fixture's strided subsample.
+    (checker only: the fixture and the seeded weight generator are test infrastructure)"""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "cfg2_named.npz")
+    if not os.path.exists(path) or iters != 50:
+        return None
+    from oracle import drunet_cpu as OD
+    d = np.load(path)
+    st = int(d["stride"])
+    keep = {k: v.detach().clone() for k, v in denoiser.state_dict().items()}
+    prec = denoiser.conv_precision
+    res = {"res_gain": float(d["res_gain"]), "reference": "deepinv v0.4.1 (tests/golden/cfg2_named.npz), slice 0"}
+    try:
+        for tag, gain in (("gain_0.2", None), ("unit_gain", float(d["res_gain"]))):
+            denoiser.load_state_dict(OD.init_state_dict(2, 2, seed=int(d["drunet_seed"]), res_gain=gain))
+            ref = torch.from_numpy(np.asarray(d["rec" + ("" if gain is None else "_gain")])).double()
+            for p in ("fp32", "bf16split"):
+                denoiser.conv_precision = p
+                with torch.no_grad():
+                    rec = model(y, physics)[:1].detach().cpu().reshape(-1)[::st].double()
+                res[f"{tag}_{p}"] = float(f"{float((rec - ref).norm() / ref.norm()):.3e}")
+    finally:
+        denoiser.load_state_dict(keep)
+        denoiser.conv_precision = prec
+    return res
 
 
 def drunet3d_forward_flops(den, vol):
@@ -251,7 +351,7 @@ def drunet3d_forward_flops(den, vol):
     return total
 
 
-def other_config_ops(dinv, device, op_row, ops_last):
+def other_config_ops(dinv, device, op_row, ops_last, loop_row):
     """operator rows of BASELINE configs[2..4] at their per-GPU shard shapes (SURVEY 8d byte counts);
     the Radon rows also carry bilinear samples/s (that operator is gather-rate bound, not HBM bound)"""
     g = torch.Generator().manual_seed(0)
@@ -269,7 +369,19 @@ def other_config_ops(dinv, device, op_row, ops_last):
     op_row("Tomography.A_adjoint", "cfg3", B, lambda: phys.A_adjoint(y), alg, n=5, Gsamples_per_s=smp / 1e9,
            lds_model_TB_per_s=smp * 16 / 1e12)
     op_row("Tomography.fbp", "cfg3", B, lambda: phys.A_dagger(y, fbp=True), alg + 2 * B * G * A * 4, n=5)
-    del phys, y
+    # cfg3's loop at its per-GPU shard: FBP-initialised PnP-HQS, 30 iterations (prox by CG), DRUNet(1->1), DPIR-style schedules
+    # stretched to 30 iterations; DRUNet 1109 GFLOP per 512x512 call
+    import numpy as np
+    torch.manual_seed(0)
+    den3 = dinv.models.DRUNet(1, 1, pretrained=None).to(device).eval()
+    s30 = np.logspace(np.log10(49 / 255.0), np.log10(0.02), 30).astype("float32")
+    st30 = ((s30 / 0.02) ** 2 / 0.23).astype("float32")
+    hqs = dinv.optim.HQS(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den3), stepsize=list(map(float, st30)),
+                         g_param=list(map(float, s30)), max_iter=30, early_stop=False,
+                         custom_init=lambda yy, p: p.A_dagger(yy, fbp=True))
+    loop_row("FBP + PnP-HQS 30 it (CG prox) + DRUNet(1->1): loop", "cfg3", B, lambda: hqs(y, phys), 30 * 1109.0 * B,
+             unit="images_per_s", precision=den3.conv_precision)
+    del phys, y, den3, hqs
     # the same geometry with fan-beam rays (first-generation gather kernels: stated, not tuned)
     fphys = dinv.physics.Tomography(angles=A, img_width=W, circle=False, normalize=False, fan_beam=True, device=device)
     fy = fphys.A(x)
@@ -325,6 +437,15 @@ def other_config_ops(dinv, device, op_row, ops_last):
     op_row("Downsampling.A", "cfg5", B, lambda: phys.A(x), alg)
     op_row("Downsampling.A_adjoint", "cfg5", B, lambda: phys.A_adjoint(y), alg)
     op_row("Downsampling.prox_l2", "cfg5", B, lambda: phys.prox_l2(z, y, 0.7), 2 * B * 3 * 256 * 256 * 4 + B * 3 * 64 * 64 * 4)
+    # cfg5's loop at its per-GPU shard: DiffPIR, 100 steps, DRUNet(3->3) (277.6 GFLOP per 256x256 call), closed-form prox
+    torch.manual_seed(0)
+    den5 = dinv.models.DRUNet(3, 3, pretrained=None).to(device).eval()
+    nphys = dinv.physics.Downsampling(img_size=img, filter="bicubic", factor=4, padding="circular", device=device,
+                                      noise_model=dinv.physics.GaussianNoise(0.05))
+    sampler = dinv.sampling.DiffPIR(den5, dinv.optim.L2(), sigma=0.05, max_iter=100, zeta=0.1, lambda_=7.0, device=device)
+    yn = nphys(x)
+    loop_row("DiffPIR 100 steps + DRUNet(3->3): loop", "cfg5", B, lambda: sampler(yn, nphys, seed=0), 100 * 277.6 * B,
+             unit="images_per_s", precision=den5.conv_precision)
 
 
 def _pgd_cpu(sd, maps, mask, y, iters):
@@ -454,7 +575,7 @@ def cpu_baseline(denoiser, maps, mask, H, W, coils, iters, y_cpu, x_gpu, parity_
     else:
         whole.update(value=round(1.0 / (per_it * iters), 5), unit="slices/s", sample="one process fills the usable cores")
     errs = {i: float((x_gpu[i:i + 1].double() - xk.double()).norm() / xk.double().norm()) for i, xk in recs.items()}
-    return {"value": round(1.0 / (per_it * iters), 5), "unit": "slices/s", "cores": threads, "host_cores": cores,
+    return {"_rec0": recs[0], "value": round(1.0 / (per_it * iters), 5), "unit": "slices/s", "cores": threads, "host_cores": cores,
             "usable_cores": usable, "kind": "port", "threads_calibration_s_per_denoiser_call": calib,
             "samples_s_per_iteration": [round(v, 4) for v in samples],
             "sample": f"slice 0 of the batch: median of 3 timed samples ({iters} it once, {short} it twice), "

@@ -1,6 +1,7 @@
 // Shared helpers of the DRUNet convolution kernels (drunet.hip, drunet_wino.hip).
 #pragma once
 #include "common.hpp"
+#include <atomic>
 
 namespace dinv_drunet {
 
@@ -57,6 +58,13 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// hide a per-lane value from the optimizer (it can then neither re-materialise nor re-associate what it was computed from)
+#ifdef DINV_EMU
+#define DINV_OPAQUE(x) asm volatile("" : "+r"(x))
+#else
+#define DINV_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -92,6 +100,37 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MREP][2], int n, 
             st4(y + ((int64_t)(cb0 + 4 * m + g) * cs + opix) * 8 + 4 * lhi, v);
         }
     }
+}
+
+// exact unsigned division by a runtime constant (Granlund-Montgomery round-up multiplier): n / d for all 32-bit n
+struct FastDiv {
+    uint32_t m, s1, s2;
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        const uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDiv f;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+
+// compute units per XCD of the current device (32 on MI355X: 256 CUs in 8 XCDs)
+inline int cus_per_xcd(int dev) {
+    static std::atomic<int> cache[64];
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        v = n / 8;
+        cache[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 inline int check_geom(const dinv_act_geom* g) {

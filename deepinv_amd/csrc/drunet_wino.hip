@@ -43,24 +43,6 @@ constexpr int RP = 12;                 // LDS pitch of one staged pixel: 8 chann
 constexpr int NTHR = 512;
 constexpr int EXCH = 8 * 4 * 2 * 2 * 256;   // floats of the epilogue exchange buffer (128 KB)
 
-// exact unsigned division by a runtime constant (Granlund-Montgomery round-up multiplier): n / d for all 32-bit n
-struct FastDiv {
-    uint32_t m, s1, s2;
-    __device__ __forceinline__ uint32_t div(uint32_t n) const {
-        const uint32_t t = __umulhi(m, n);
-        return (t + ((n - t) >> s1)) >> s2;
-    }
-};
-inline FastDiv make_fastdiv(uint32_t d) {
-    uint32_t l = 0;
-    while ((1ull << l) < d) ++l;
-    FastDiv f;
-    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.s1 = l < 1 ? l : 1;
-    f.s2 = l > 0 ? l - 1 : 0;
-    return f;
-}
-
 struct WinoArgs {
     Geom g;
     const float* x;
@@ -493,19 +475,6 @@ void conv3x3_wino_kernel(WinoArgs a) {
     ++tile_k;
 #endif
     }   // tile loop
-}
-
-// compute units per XCD of the current device (32 on MI355X: 256 CUs in 8 XCDs)
-int cus_per_xcd(int dev) {
-    static std::atomic<int> cache[64];
-    int v = cache[dev & 63].load(std::memory_order_relaxed);
-    if (v == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        v = n / 8;
-        cache[dev & 63].store(v, std::memory_order_relaxed);
-    }
-    return v;
 }
 
 template <int TH, int TW, bool RELU, int NRES>

@@ -82,10 +82,14 @@ def _conv_adj(y, filt, padding, stride, H, W):
 
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, filt, padding, stride):
+    def forward(x, filt, padding, stride):
+        return _conv_fwd(x, filt, padding, stride)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x, filt, padding, stride = inputs
         ctx.save_for_backward(filt)
         ctx.cfg = (padding, stride, x.shape[-2], x.shape[-1])
-        return _conv_fwd(x, filt, padding, stride)
 
     @staticmethod
     def backward(ctx, g):
@@ -96,10 +100,14 @@ class _Conv(torch.autograd.Function):
 
 class _ConvT(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, filt, padding, stride, H, W):
+    def forward(y, filt, padding, stride, H, W):
+        return _conv_adj(y, filt, padding, stride, H, W)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        _, filt, padding, stride, _, _ = inputs
         ctx.save_for_backward(filt)
         ctx.cfg = (padding, stride)
-        return _conv_adj(y, filt, padding, stride, H, W)
 
     @staticmethod
     def backward(ctx, g):
@@ -170,9 +178,13 @@ class _Rfft2(torch.autograd.Function):
     """ortho rfft2; its backward is the *adjoint* (not the inverse) of the real-to-half-complex map."""
 
     @staticmethod
-    def forward(ctx, x, norm):
-        ctx.cfg = (norm, x.shape[-2], x.shape[-1])
+    def forward(x, norm):
         return _rfft2_raw(x, norm)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x, norm = inputs
+        ctx.cfg = (norm, x.shape[-2], x.shape[-1])
 
     @staticmethod
     def backward(ctx, g):
@@ -189,9 +201,13 @@ class _Rfft2(torch.autograd.Function):
 
 class _Irfft2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xc, s, norm):
-        ctx.cfg = (norm, s)
+    def forward(xc, s, norm):
         return _irfft2_raw(xc, s, norm)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        _, s, norm = inputs
+        ctx.cfg = (norm, s)
 
     @staticmethod
     def backward(ctx, g):

@@ -17,6 +17,11 @@ class ActGeom(ctypes.Structure):
 
 
 _declared = False
+# tuning constants of the fp32 setting (module attributes, no environment knobs): output tile of the Winograd kernel the
+# ResBlock convolutions take (4: csrc/drunet_wino4.hip, 2: csrc/drunet_wino.hip) and the fewest workgroup tiles (64 couts x
+# 32 tile positions) a launch must have for the F(4x4,3x3) kernel (one persistent workgroup per CU: 256 on MI355X)
+FP32_WINOGRAD_TILE = 4
+WINOGRAD4_MIN_TILES = 192
 
 
 def _l():
@@ -31,6 +36,9 @@ def _l():
         l.dinv_conv3x3.argtypes = [G, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
         l.dinv_conv3x3_tail.argtypes = [G, vp, vp, vp, i32, i32, vp, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
+        l.dinv_conv3x3_winograd4.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp, ctypes.c_size_t, vp]
+        l.dinv_conv3x3_winograd4_workspace_bytes.restype = ctypes.c_size_t
+        l.dinv_conv3x3_winograd4_workspace_bytes.argtypes = []
         l.dinv_conv3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_wsplit.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
@@ -149,6 +157,32 @@ def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
     u = (G @ w.detach().double() @ G.t()).float().reshape(cout // 64, 64, cin // 8, 8, 16)
     return u.permute(0, 2, 3, 1, 4).contiguous()
+
+
+def winograd4_matrices(dtype=torch.float64, device=None):
+    """(B^T, G, A^T) of Winograd F(4x4, 3x3) (interpolation points 0, +-1, +-2, inf; Lavin & Gray 2016):
+    Y = A^T [ (G g G^T) . (B^T d B) ] A for a 6x6 input patch d and a 3x3 filter g"""
+    bt = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
+                       [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=dtype, device=device)
+    g = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+                      [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=dtype, device=device)
+    at = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]],
+                      dtype=dtype, device=device)
+    return bt, g, at
+
+
+def pack_winograd4_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> U = G g G^T of Winograd F(4x4,3x3) (fp64, rounded once to fp32), packed for
+    csrc/drunet_wino4.hip as the MFMA A fragments of the wave that uses them:
+    [Cout/64][Cin/8][wave = 4 c2 + q][k 9][lane = 32 h + r][m 4] holds U[point 9 q + k][cout 64 ct + 32 c2 + r][cin 8 cb + 4 h + m];
+    needs Cin % 16 == 0 and Cout % 64 == 0"""
+    cout, cin = w.shape[:2]
+    if cin % 16 or cout % 64:
+        raise ValueError(f"winograd F(4,3) packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
+    _, G, _ = winograd4_matrices(device=w.device)
+    u = (G @ w.detach().double() @ G.t()).float()                       # [co, ci, 6, 6]
+    u = u.reshape(cout // 64, 2, 32, cin // 8, 2, 4, 4, 9)              # ct, c2, r, cb, h, m, q, k
+    return u.permute(0, 3, 1, 6, 7, 4, 2, 5).contiguous()               # ct, cb, c2, q, k, h, r, m
 
 
 def pack_down_weight(w: torch.Tensor) -> torch.Tensor:
@@ -367,6 +401,34 @@ def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):
         tiles = g.batch * ((g.height + 1) // 2) * ((g.width + 1) // 2)
         _prof.append((e0, e1, "conv3x3_wino_kernel", 2.0 * 9 * cin * cout * g.batch * g.height * g.width,
                       2.0 * 16 * cin * cout * tiles))
+
+
+_W4_WS: dict = {}
+
+
+def winograd4_workspace(device) -> torch.Tensor:
+    """the per-device workspace of dinv_conv3x3_winograd4's tail split (zero-filled once; the library keeps its ticket words
+    zero between launches; launches on one stream are ordered, so one buffer serves every layer)"""
+    key = torch.device(device)
+    ws = _W4_WS.get(key)
+    if ws is None:
+        ws = _W4_WS[key] = torch.zeros(_l().dinv_conv3x3_winograd4_workspace_bytes(), device=device, dtype=torch.uint8)
+    return ws
+
+
+def conv3x3_winograd4(g, x, wino4, cin, cout, y, res1=None, relu=False, workspace=None):
+    """y = [relu](conv3x3(x)) (+res1) via Winograd F(4x4,3x3) on the fp32 matrix cores (csrc/drunet_wino4.hip); wino4 from
+    pack_winograd4_weight; height and width multiples of 4; `workspace` (winograd4_workspace(device)) enables the tail split"""
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_l().dinv_conv3x3_winograd4(ctypes.byref(g), ptr(x), ptr(wino4), cin, cout, ptr(y), ptr(res1), int(relu),
+                                      ptr(workspace), 0 if workspace is None else workspace.numel(), stream_ptr(y.device)))
+    if _prof is not None:
+        e1.record()
+        tiles = g.batch * (g.height // 4) * (g.width // 4)
+        _prof.append((e0, e1, "conv3x3_wino4_kernel", 2.0 * 9 * cin * cout * g.batch * g.height * g.width,
+                      2.0 * 36 * cin * cout * tiles))
 
 
 def down2x2(gi, go, x, w, cin, cout, y):

@@ -22,9 +22,12 @@ def _c2c_axis(buf: torch.Tensor, axis: int, inverse: bool, centered: bool, scale
 
 class _FftN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, dims, inverse, centered, norm):
+    def setup_context(ctx, inputs, output):
+        ctx.cfg = tuple(inputs[1:])
+
+    @staticmethod
+    def forward(x, dims, inverse, centered, norm):
         require_hip(x)
-        ctx.cfg = (dims, inverse, centered, norm)
         out = x.to(torch.complex64).contiguous().clone()
         view = torch.view_as_real(out)  # same storage; kernels see interleaved fp32 pairs
         for d in dims:

@@ -122,11 +122,15 @@ class _MriForward(torch.autograd.Function):
     respect to `coil_maps` and `mask` (the reference gets them from autograd, e.g. for learned sampling patterns)
     are assembled from the same kernels: dL/dM = sum g * F(S x),  dL/dS_n = F^H(M g_n) * conj(x)."""
 
+    # (forward / setup_context form: usable under torch.func transforms - the reference's adjoint_function is torch.func.vjp)
     @staticmethod
-    def forward(ctx, x, maps, mask, coil_dim):
-        ctx.save_for_backward(x, maps, mask)
-        ctx.coil_dim = coil_dim
+    def forward(x, maps, mask, coil_dim):
         return _forward_raw(x, maps, mask, coil_dim)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x, maps, mask, ctx.coil_dim = inputs
+        ctx.save_for_backward(x, maps, mask)
 
     @staticmethod
     def backward(ctx, g):
@@ -145,10 +149,13 @@ class _MriAdjoint(torch.autograd.Function):
     """x = sum_n conj(S_n) F^H(M y_n); dL/dM = sum F(S g) * y,  dL/dS_n = conj(g) * F^H(M y_n)."""
 
     @staticmethod
-    def forward(ctx, y, maps, mask, coil_dim):
-        ctx.save_for_backward(y, maps, mask)
-        ctx.coil_dim = coil_dim
+    def forward(y, maps, mask, coil_dim):
         return _adjoint_raw(y, maps, mask, coil_dim)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        y, maps, mask, ctx.coil_dim = inputs
+        ctx.save_for_backward(y, maps, mask)
 
     @staticmethod
     def backward(ctx, g):
@@ -187,10 +194,13 @@ class _MriNormal(torch.autograd.Function):
     """A^T A is self-adjoint: the backward of the fused normal operator is the same kernel chain."""
 
     @staticmethod
-    def forward(ctx, x, maps, mask, coil_dim):
-        ctx.save_for_backward(maps, mask)
-        ctx.coil_dim = coil_dim
+    def forward(x, maps, mask, coil_dim):
         return _normal_raw(x, maps, mask, coil_dim)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        _, maps, mask, ctx.coil_dim = inputs
+        ctx.save_for_backward(maps, mask)
 
     @staticmethod
     def backward(ctx, g):

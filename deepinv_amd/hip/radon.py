@@ -159,9 +159,12 @@ def _adj(y, geo: RadonGeometry, norm, scale=1.0):
 
 class _RadonFwd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, geo, norm):
-        ctx.geo, ctx.norm = geo, norm
+    def forward(x, geo, norm):
         return _fwd(x, geo, norm)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        _, ctx.geo, ctx.norm = inputs
 
     @staticmethod
     def backward(ctx, g):
@@ -170,9 +173,12 @@ class _RadonFwd(torch.autograd.Function):
 
 class _RadonAdj(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, geo, norm):
-        ctx.geo, ctx.norm = geo, norm
+    def forward(y, geo, norm):
         return _adj(y, geo, norm)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        _, ctx.geo, ctx.norm = inputs
 
     @staticmethod
     def backward(ctx, g):
@@ -201,9 +207,12 @@ class _ApplyRadon(torch.autograd.Function):
     autograd backward is the other (an *inexact* adjoint pair by design)."""
 
     @staticmethod
-    def forward(ctx, x, geo, scale, adjoint):
-        ctx.geo, ctx.scale, ctx.adjoint = geo, scale, adjoint
+    def forward(x, geo, scale, adjoint):
         return iradon_backproject(x, geo, scale) if adjoint else _fwd(x, geo, None, scale)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        _, ctx.geo, ctx.scale, ctx.adjoint = inputs
 
     @staticmethod
     def backward(ctx, g):
@@ -288,9 +297,12 @@ def _fan_adj(y, geo: FanGeometry, norm):
 
 class _FanFwd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, geo, norm):
-        ctx.geo, ctx.norm = geo, norm
+    def forward(x, geo, norm):
         return _fan_fwd(x, geo, norm)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        _, ctx.geo, ctx.norm = inputs
 
     @staticmethod
     def backward(ctx, g):
@@ -299,9 +311,12 @@ class _FanFwd(torch.autograd.Function):
 
 class _FanAdj(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, geo, norm):
-        ctx.geo, ctx.norm = geo, norm
+    def forward(y, geo, norm):
         return _fan_adj(y, geo, norm)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        _, ctx.geo, ctx.norm = inputs
 
     @staticmethod
     def backward(ctx, g):
@@ -341,7 +356,11 @@ class _Ramp(torch.autograd.Function):
     """the ramp kernel h is symmetric, so the filter is self-adjoint"""
 
     @staticmethod
-    def forward(ctx, y):
+    def setup_context(ctx, inputs, output):
+        pass
+
+    @staticmethod
+    def forward(y):
         dev = require_hip(y)
         y = f32c(y)
         B, C, N, A = y.shape

@@ -28,8 +28,8 @@ from .base import Denoiser
 # The ONE precision switch of the denoiser: how the 56 ResBlock 3x3 convolutions multiply.
 #   "bf16split": every fp32 operand as two bf16 parts, three products on the bf16 matrix cores, fp32 accumulation
 #                (csrc/drunet_split2d.hip; <= 2^-16 per operand, 2-4e-6 per layer, DRUNet output within 1e-4 of the fp32 path)
-#   "fp32":      fp32 multiplies on the fp32 matrix cores (Winograd F(2x2,3x3) kernel, direct kernel for the shapes it does
-#                not take) - the reference's arithmetic type
+#   "fp32":      fp32 multiplies on the fp32 matrix cores (Winograd F(4x4,3x3) kernel; F(2x2,3x3) / direct kernels for the
+#                shapes it does not take) - the reference's arithmetic type
 # Default for new models: `deepinv_amd.models.drunet.DEFAULT_CONV_PRECISION`; per model: `model.conv_precision = "fp32"`.
 CONV_PRECISIONS = ("bf16split", "fp32")
 DEFAULT_CONV_PRECISION = "bf16split"
@@ -200,7 +200,8 @@ class DRUNet(Denoiser):
             s2d = K.pack_split2d_weight(w) if (split and ok) else None
             wino = K.pack_winograd_weight(w) if (not split and ok and w.shape[1] >= 32) else None
             wsp = K.pack_wsplit_weight(w) if (split and ok) else None
-            return (p64, p32, wino, s2d, wsp)
+            wino4 = K.pack_winograd4_weight(w) if (not split and ok) else None
+            return (p64, p32, wino, s2d, wsp, wino4)
 
         e["head"] = c3(self.m_head)
         e["tail"] = c3(self.m_tail)
@@ -249,7 +250,13 @@ class DRUNet(Denoiser):
         return p64
 
     def _conv_fp32(self, g, pk, x, y, relu=False, res1=None):
-        """one ResBlock convolution in fp32 arithmetic: Winograd F(2x2,3x3) kernel, else the direct MFMA kernel"""
+        """one ResBlock convolution in fp32 arithmetic: Winograd F(4x4,3x3) kernel (csrc/drunet_wino4.hip) where the image
+        sides are multiples of 4 and the launch has enough 64-cout x 32-tile workgroup tiles to occupy the chip, else the
+        F(2x2,3x3) kernel, else the direct MFMA kernel"""
+        if (pk[5] is not None and K.FP32_WINOGRAD_TILE == 4 and g.height % 4 == 0 and g.width % 4 == 0
+                and -(-g.batch * (g.height // 4) * (g.width // 4) // 32) * (pk[0][2] // 64) >= K.WINOGRAD4_MIN_TILES):
+            K.conv3x3_winograd4(g, x, pk[5], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=K.winograd4_workspace(x.device))
+            return
         if pk[2] is not None:
             K.conv3x3_winograd(g, x, pk[2], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
             return

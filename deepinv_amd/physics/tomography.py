@@ -63,9 +63,7 @@ class Tomography(LinearPhysics):
             normalize = True
         self.normalize = False
         if normalize:
-            if torch.device(device).type != "cuda":
-                raise RuntimeError("Tomography(normalize=True) runs the power method on the HIP kernels: construct "
-                                   "it with device='cuda' (or normalize=False and load `operator_norm` later)")
+            # (the power method runs on the HIP kernels: on a CPU device their wrappers raise, there is no CPU path)
             x0 = torch.randn((1, img_width, img_width), generator=torch.Generator(device).manual_seed(0),
                              device=device)[None]
             operator_norm = self.compute_norm(x0, squared=False, verbose=False)

@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 4 = this header (3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 5 = this header (4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -165,6 +165,21 @@ int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const float* x2, c
  * relu and res1 are mutually exclusive (ResBlock conv1 / conv2, drunet.py:403-434). */
 int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w_wino, int32_t cin, int32_t cout,
                           float* y, const float* res1, int32_t relu, dinv_stream_t stream);
+/* Same operator through Winograd F(4x4,3x3) on the fp32 matrix cores: 36 fp32 multiplies per 4x4 output tile and (cin, cout)
+ * instead of 144 (4x fewer MFMA flops than the direct form, 1.78x fewer than dinv_conv3x3_winograd), fp32 accumulation; the
+ * transforms add 2-3e-6 relative per layer against an fp64 convolution (csrc/drunet_wino4.hip: U straight from L2 as MFMA
+ * fragments, V = B^T d B computed once per workgroup through LDS, 64 couts x 32 tiles x 36 points per workgroup).
+ * w_wino4: U = G g G^T per (cout, cin) packed [cout/64][cin/8][wave 8][point 9][lane 64][4]
+ *   (deepinv_amd/hip/drunet.py: pack_winograd4_weight); cin % 16 == 0, cout % 64 == 0, height % 4 == 0, width % 4 == 0;
+ * relu and res1 are mutually exclusive (ResBlock conv1 / conv2, drunet.py:403-434).
+ * workspace (optional, may be NULL): dinv_conv3x3_winograd4_workspace_bytes() bytes of device memory, ZERO-FILLED once by the
+ *   caller and then left to the library (it keeps its ticket words zero between launches).  With a workspace the tiles of the
+ *   last, incomplete round of workgroups are cut into 2 / 4 / 8 parts along the input channels so that every compute unit
+ *   works on them: the parts write partial outputs, the part that finishes last adds them in part order (deterministic). */
+size_t dinv_conv3x3_winograd4_workspace_bytes(void);
+int dinv_conv3x3_winograd4(const dinv_act_geom* g, const float* x, const float* w_wino4, int32_t cin, int32_t cout,
+                           float* y, const float* res1, int32_t relu, void* workspace, size_t workspace_bytes,
+                           dinv_stream_t stream);
 /* Same operator on the BF16 matrix cores with a two-part exact operand split (x = xh + xl with xh = bf16(x),
  * xl = bf16(x - xh); three products ah*bl + al*bh + ah*bh, fp32 accumulate): per output
  * |y - y_exact| <= 3 * 2^-16 * (|w| conv |x|), 2-4e-6 relative per layer on random data (csrc/drunet_split2d.hip: 2-D pixel

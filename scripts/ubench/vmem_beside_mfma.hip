@@ -13,8 +13,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#define MFMA(ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(a), "v"(b))
-#define LOAD(DST, PTR) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory")
+// compiler-counted forms (the first version issued the loads from inline asm with "=v" outputs: hipcc does not count such loads,
+// reused their destination registers for addresses, and the late data faulted the kernel - cdna_hip_programming.md 5.7 item 1);
+// every MFMA / load group is pinned by a scheduling barrier, the waits are the compiler's (first use one half-iteration later)
+#define MFMA(ACC) do { ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, ACC, 0, 0, 0); } while (0)
+#define LOAD(DST, PTR) do { DST = *(PTR); } while (0)
 
 // L loads per 12 MFMAs, spread evenly; NT = 256 (one wave per SIMD) or 512 (two); LS = lane stride in 16-byte units (1: a wave
 // reads 1 KB contiguous, like the conv's weight fragments; 4: 16 bytes out of every 64, like its four-pixel activation windows)
@@ -42,21 +45,15 @@ __global__ __launch_bounds__(NT) void k(const u32x4* src, float* out, int iters,
                     idx += 64 * 13 * LS + (LS > 1 ? 1 : 0);
                     if (half == 0) LOAD(s0[li], p); else LOAD(s1[li], p);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // the loads of the PREVIOUS half must have landed: at most this half's L loads stay in flight
+            // the loads of the PREVIOUS half are consumed here: at most this half's L loads stay in flight
             if (L > 0) {
-                if (L == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else if (L == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (L == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else if (L == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (L == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < L; ++i) sink ^= half == 0 ? s1[i].x : s0[i].x;
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float s = (float)sink;
     for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][9];
     out[blockIdx.x * NT + threadIdx.x] = s;

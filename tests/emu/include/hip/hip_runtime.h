@@ -59,6 +59,8 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 0;
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount = 256; };
+constexpr int hipDeviceAttributeMultiprocessorCount = 0;
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 16; return hipSuccess; }   // 2 "CUs" per XCD: short tile lists per workgroup
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
 
 // ------------------------------------------------------------------ the fiber scheduler
@@ -223,6 +225,7 @@ inline int emu_readfirstlane(int v) { return __shfl(v, 0, 64); }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 // buffer resources (range-checked loads / stores: offsets >= num_records are dropped / read as zero)
 struct __amdgpu_buffer_rsrc_t { char* base; unsigned num; };
 inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) { return {(char*)p, (unsigned)num}; }

@@ -1,0 +1,173 @@
+"""The drop-in claim, tested against the REAL deepinv (build container only: marker `reference`).
+
+The product's operator objects (deepinv_amd.physics.*) are handed to the reference's own code - its optimizers
+(deepinv.optim.PGD / HQS, deepinv.unfolded.unfolded_builder) and the bodies of its own property tests
+(deepinv/tests/test_physics.py: adjointness :717-735, operator norm :882-927, pseudo-inverse :946-968, Blur == BlurFFT
+:1338-1381) with `deepinv.physics.{MRI, MultiCoilMRI, Tomography, Blur, BlurFFT, Downsampling}` swapped for the product's
+classes.  There is no GPU here: the product's ctypes binding is pointed at the host emulation of its kernel sources
+(tests/emu_backend.py), so what runs is the product's Python layer + the product's kernel code, driven by the reference."""
+import importlib.util
+import os
+import warnings
+
+import pytest
+import torch
+
+from oracle.ref_shim import REFERENCE_ROOT, import_reference, reference_available
+
+pytestmark = [pytest.mark.reference, pytest.mark.skipif(not reference_available(), reason="needs /root/reference")]
+SWAPPED = ("MRI", "MultiCoilMRI", "Tomography", "Blur", "BlurFFT", "Downsampling")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    dinv = import_reference()
+    spec = importlib.util.spec_from_file_location("ref_test_physics", os.path.join(REFERENCE_ROOT, "deepinv", "tests", "test_physics.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return dinv, mod
+
+
+@pytest.fixture
+def swapped(ref, monkeypatch):
+    """the reference package and its physics test module with the six operator classes replaced by the product's"""
+    import deepinv_amd as A
+    from emu_backend import emu_backend
+
+    dinv, mod = ref
+    with emu_backend():
+        for name in SWAPPED:
+            monkeypatch.setattr(dinv.physics, name, getattr(A.physics, name))
+        monkeypatch.setattr(mod, "MRI", A.physics.MRI)
+        monkeypatch.setattr(mod, "MultiCoilMRI", A.physics.MultiCoilMRI)
+        yield dinv, mod
+
+
+def rng():
+    return torch.Generator("cpu").manual_seed(0)
+
+
+LINEAR = ["MRI", "3DMRI", "MultiCoilMRI", "3DMultiCoilMRI", "2DParallelBeamCT", "2DFanBeamCT", "fftdeblur", "deblur_valid",
+          "deblur_circular", "deblur_reflect", "deblur_replicate", "deblur_constant", "super_resolution_valid",
+          "super_resolution_circular", "super_resolution_reflect", "super_resolution_replicate", "super_resolution_constant"]
+
+
+@pytest.mark.parametrize("name", LINEAR)
+def test_reference_adjointness_body(swapped, name):
+    """deepinv/tests/test_physics.py:717-735 (adjointness_test < 1e-3, and the reference's autograd adjoint_function through
+    the product's A) with the product's operator behind find_operator"""
+    dinv, mod = swapped
+    import deepinv_amd as A
+    physics = mod.find_operator(name, torch.device("cpu"))[0]
+    assert type(physics).__module__.startswith("deepinv_amd."), type(physics)
+    mod.test_operators_adjointness(name, torch.device("cpu"), rng())
+
+
+@pytest.mark.parametrize("name", ["MRI", "MultiCoilMRI", "2DParallelBeamCT", "fftdeblur", "deblur_circular", "super_resolution_circular"])
+def test_reference_norm_body(swapped, name):
+    """deepinv/tests/test_physics.py:882-927: compute_sqnorm warns exactly once when it does not converge and lands within
+    1e-2 of the reference value"""
+    dinv, mod = swapped
+    mod.test_operators_norm(name, False, torch.device("cpu"), rng())
+
+
+@pytest.mark.parametrize("name", ["MRI", "MultiCoilMRI", "2DParallelBeamCT", "fftdeblur", "deblur_circular", "super_resolution_circular"])
+def test_reference_pseudo_inverse_body(swapped, name):
+    """deepinv/tests/test_physics.py:946-968: A_dagger(y, solver="lsqr", tol, max_iter, verbose) recovers the range component"""
+    dinv, mod = swapped
+    mod.test_pseudo_inverse(name, torch.device("cpu"), rng(), False)
+
+
+@pytest.mark.parametrize("img_size,filter_size,filter_type", [((1, 32, 32), (1, 5, 5), "random"), ((3, 33, 33), (1, 6, 6), "directional"),
+                                                              ((1, 32, 33), (1, 6, 5), "random")])
+def test_reference_blur_equals_blurfft_body(swapped, img_size, filter_size, filter_type):
+    """deepinv/tests/test_physics.py:1338-1381: Blur(padding="circular") and BlurFFT agree to 1e-5 (smaller images than the
+    reference's 64x64: the kernels run in emulation)"""
+    dinv, mod = swapped
+    mod.test_blur(img_size, filter_size, filter_type, torch.device("cpu"))
+
+
+def _mri_problem(A, coils=4, H=32, W=32, B=2):
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(B, 2, H, W, generator=g)
+    maps = torch.randn(1, coils, H, W, dtype=torch.complex64, generator=g)
+    maps = maps / maps.abs().pow(2).sum(dim=1, keepdim=True).sqrt()
+    mask = A.utils.radial_mask(H, W, 10)
+    return x, maps, mask
+
+
+def test_reference_pgd_runs_over_product_multicoil_mri(ref):
+    """deepinv.optim.PGD (optimizers.py:1596-1734) with the reference's own L2 / PnP(DRUNet) driving the PRODUCT's MultiCoilMRI:
+    same reconstruction as with the reference's operator"""
+    import deepinv_amd as A
+    from emu_backend import emu_backend
+    from oracle import drunet_cpu as OD
+
+    dinv, _ = ref
+    x, maps, mask = _mri_problem(A)
+    den = dinv.models.DRUNet(in_channels=2, out_channels=2, pretrained=None)
+    den.load_state_dict(OD.init_state_dict(2, 2, seed=5))
+    den.eval()
+    p_ref = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, 32, 32), device="cpu")
+    y = p_ref.A(x)
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=1.0, g_param=0.05, max_iter=4,
+                           early_stop=False)
+    with torch.no_grad():
+        rec_ref = model(y, p_ref)
+        with emu_backend():
+            p_amd = A.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, 32, 32), device="cpu")
+            assert float((p_amd.A(x) - y).norm() / y.norm()) < 1e-6
+            rec = model(y, p_amd)
+    assert float((rec - rec_ref).norm() / rec_ref.norm()) < 1e-5
+
+
+def test_reference_hqs_runs_over_product_tomography(ref):
+    """deepinv.optim.HQS (optimizers.py:1459-1593; prox of L2 = the PRODUCT's Tomography.prox_l2 / its CG) with a TV-free
+    Tikhonov prior: same reconstruction as with the reference's operator"""
+    import deepinv_amd as A
+    from emu_backend import emu_backend
+
+    dinv, _ = ref
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(1, 1, 16, 16, generator=g)
+    p_ref = dinv.physics.Tomography(angles=12, img_width=16, circle=False, normalize=True, device="cpu")
+    y = p_ref.A(x)
+    model = dinv.optim.HQS(data_fidelity=dinv.optim.L2(), prior=dinv.optim.Tikhonov(), stepsize=1.0, lambda_reg=0.1, max_iter=3,
+                           early_stop=False)
+    with torch.no_grad():
+        rec_ref = model(y, p_ref)
+        with emu_backend():
+            p_amd = A.physics.Tomography(angles=12, img_width=16, circle=False, normalize=True, device="cpu")
+            assert abs(float(p_amd.operator_norm) - float(p_ref.operator_norm)) < 1e-4 * float(p_ref.operator_norm)
+            rec = model(y, p_amd)
+    assert float((rec - rec_ref).norm() / rec_ref.norm()) < 1e-4
+
+
+def test_reference_unfolded_builder_trains_through_product_mri(ref):
+    """deepinv.unfolded.unfolded_builder (unfolded.py:9-226) over the PRODUCT's MultiCoilMRI: loss and the gradients of the
+    trainable step size / g_param equal those obtained with the reference's operator (autograd through the product's
+    torch.autograd.Function: backward = the adjoint kernel)"""
+    import deepinv_amd as A
+    from emu_backend import emu_backend
+
+    dinv, _ = ref
+    x, maps, mask = _mri_problem(A, coils=3, H=16, W=16, B=1)
+
+    def run(physics):
+        torch.manual_seed(0)
+        prior = dinv.optim.PnP(dinv.models.DnCNN(in_channels=2, out_channels=2, depth=3, nf=8, pretrained=None))
+        model = dinv.unfolded.unfolded_builder("PGD", data_fidelity=dinv.optim.L2(), prior=prior,
+                                               params_algo={"stepsize": 0.9, "g_param": 0.05}, max_iter=3,
+                                               trainable_params=["stepsize", "g_param"])
+        y = physics.A(x)
+        loss = (model(y, physics) - x).pow(2).mean()
+        loss.backward()
+        return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l_ref, g_ref = run(dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, 16, 16), device="cpu"))
+    with emu_backend():
+        l_amd, g_amd = run(A.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, 16, 16), device="cpu"))
+    assert abs(l_amd - l_ref) < 1e-5 * abs(l_ref)
+    assert set(g_amd) == set(g_ref)
+    for n in g_ref:
+        assert float((g_amd[n] - g_ref[n]).norm() / g_ref[n].norm().clamp_min(1e-12)) < 1e-4, n

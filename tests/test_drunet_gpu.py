@@ -117,19 +117,82 @@ def test_winograd_conv_rejects_unsupported_channel_counts(dev):
         K.conv3x3_winograd(geo, x, torch.zeros(1, 3, 8, 64, 16, device=dev), 24, 64, y)
 
 
-def test_drunet_fp32_precision_matches_oracle(dev):
-    """the ONE precision switch: conv_precision = "fp32" (fp32 multiplies: Winograd F(2x2,3x3) / direct MFMA kernels)"""
-    import deepinv_amd as dinv
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 64, 64, 64, 64), (3, 40, 40, 128, 128), (1, 80, 80, 64, 128), (2, 20, 20, 512, 512),
+                                              (1, 36, 52, 64, 64), (5, 12, 12, 64, 64), (1, 320, 320, 64, 64), (1, 24, 40, 32, 64),
+                                              (2, 16, 16, 48, 64), (3, 4, 4, 16, 64), (70, 4, 8, 32, 128), (1, 4, 332, 64, 64),
+                                              (32, 40, 40, 64, 128)])
+@pytest.mark.parametrize("mode", ["plain", "relu", "res"])
+def test_winograd4_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
+    """Winograd F(4x4,3x3) ResBlock convolution on the fp32 matrix cores (csrc/drunet_wino4.hip) against an fp64 conv2d of the
+    same op (1e-5: fp32 multiplies, the transforms add a few fp32 roundings, 2-3e-6 measured) and against the direct MFMA
+    kernel: every rectangle shape, partial rectangles, position groups that straddle images, several tiles per workgroup"""
+    from deepinv_amd.hip import drunet as K
 
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)).to(dev)
+    r = torch.randn(B, cout, H, W, generator=g).to(dev)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+    geo = K.geom(B, H, W)
+
+    def to_act(t):
+        a = K.alloc(geo, t.shape[1], dev)
+        av = a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+        av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    def from_act(a, c):
+        av = a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+        return av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, c, H, W)
+
+    xa, ra = to_act(x), to_act(r)
+    ya, yd = K.alloc(geo, cout, dev), K.alloc(geo, cout, dev)
+    K.conv3x3_winograd4(geo, xa, K.pack_winograd4_weight(w), cin, cout, ya, res1=ra if mode == "res" else None, relu=mode == "relu")
+    wd, ci, co = K.pack_conv3x3_weight(w)
+    K.conv3x3(geo, xa, wd, ci, co, yd, res1=ra if mode == "res" else None, relu=mode == "relu")
+    out, direct = from_act(ya, cout), from_act(yd, cout)
+    assert rel_err(out, ref) < 1e-5
+    assert rel_err(out, direct) < 1e-5
+    full = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)     # the zero frame is never written
+    assert full[:, :, 0].abs().max() == 0 and full[:, :, H + 1:].abs().max() == 0
+    assert full[:, :, :, 0].abs().max() == 0 and full[:, :, :, W + 1:].abs().max() == 0
+
+
+def test_winograd4_conv_rejects_unsupported_shapes(dev):
+    from deepinv_amd.hip import drunet as K
+
+    with pytest.raises(ValueError):
+        K.pack_winograd4_weight(torch.zeros(64, 24, 3, 3, device=dev))
+    geo = K.geom(1, 10, 8)
+    x, y = K.alloc(geo, 16, dev), K.alloc(geo, 64, dev)
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        K.conv3x3_winograd4(geo, x, torch.zeros(64 * 16 * 36, device=dev), 16, 64, y)
+
+
+@pytest.mark.parametrize("tile", [4, 2])
+def test_drunet_fp32_precision_matches_oracle(dev, tile, monkeypatch):
+    """the ONE precision switch: conv_precision = "fp32" (fp32 multiplies on the fp32 matrix cores: Winograd F(4x4,3x3), or
+    F(2x2,3x3) / direct MFMA kernels); batch 32 so that every level clears the F(4x4) kernel's tile threshold"""
+    import deepinv_amd as dinv
+    from deepinv_amd.hip import drunet as K
+
+    monkeypatch.setattr(K, "FP32_WINOGRAD_TILE", tile)
     sd = OD.init_state_dict(2, 2, seed=1)
     model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
     model.load_state_dict(sd)
     model.eval()
     model.conv_precision = "fp32"
-    x = torch.rand(2, 2, 64, 96, generator=torch.Generator().manual_seed(0))
+    x = torch.rand(32, 2, 64, 96, generator=torch.Generator().manual_seed(0))
+    K.profile_begin()
     with torch.no_grad():
         out = model(x.to(dev), 0.05)
-    assert rel_err(out, OD.drunet(sd, x, 0.05)) < 1e-4
+    prof = K.profile_end()
+    assert ("conv3x3_wino4_kernel" in prof) == (tile == 4) and (tile == 4 or "conv3x3_wino_kernel" in prof)
+    assert rel_err(out[:2], OD.drunet(sd, x[:2], 0.05)) < 1e-4
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,mode", [(2, 24, 40, 64, 64, "plain"), (1, 17, 33, 32, 128, "relu"),

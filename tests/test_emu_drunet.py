@@ -603,3 +603,61 @@ def test_conv3x3_fp32_direct(cout):
     E.check(E.lib().dinv_conv3x3(ctypes.byref(g), E.p(xa), None, E.p(wpk), C, cout, cout, mt, E.p(ya), None, None, 0, None))
     ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
     assert float((from_act(ya, g, cout).double() - ref).norm() / ref.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 16, 32, 16, 64, "plain"), (2, 8, 8, 32, 64, "relu"), (1, 16, 16, 32, 128, "res"),
+                                                 (3, 8, 12, 16, 64, "res"), (1, 20, 36, 16, 64, "relu"), (5, 8, 8, 16, 64, "plain"),
+                                                 (20, 16, 16, 16, 128, "res"), (2, 32, 64, 48, 64, "relu"),
+                                                 (3, 16, 16, 176, 128, "plain")])     # > 3 MB of U: cout tile outermost
+@pytest.mark.parametrize("split", [False, True])
+def test_winograd4_conv_matches_fp64(B, H, W, cin, cout, mode, split):
+    """csrc/drunet_wino4.hip (Winograd F(4x4,3x3) on the fp32 matrix cores: U fragments straight from memory, V through LDS,
+    wave = 9 points of a cout half, two-round exchange in the epilogue) against an fp64 convolution: every rectangle shape
+    (4x8 / 4x4 / 2x2 tiles), partial rectangles (W = 12, 36, H = 20), position groups that straddle images, several tiles per
+    workgroup (the emulated device has 2 compute units per XCD), two cout tiles; with a workspace the tiles of the last
+    incomplete round are cut along the input channels (partial outputs + ticket + ordered combine)"""
+    gen = torch.Generator().manual_seed(H * W + cin)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / (3.0 * cin ** 0.5)
+    r = torch.randn(B, cout, H, W, generator=gen)
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_winograd4_weight
+    g = geom(B, H, W)
+    xa = to_act(x, g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    if mode == "relu":
+        ref = ref.relu()
+    if mode == "res":
+        ref = ref + r.double()
+    ra = to_act(r, g)
+    ya = torch.zeros((cout // 8, g.cs, 8))
+    ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, 1:H + 1, 1:W + 1] = float("nan")   # only interiors are written
+    wp = pack_winograd4_weight(w)
+    l = E.lib()
+    l.dinv_conv3x3_winograd4_workspace_bytes.restype = ctypes.c_size_t
+    ws = torch.zeros(l.dinv_conv3x3_winograd4_workspace_bytes(), dtype=torch.uint8) if split else None
+    for _ in range(2 if split else 1):      # twice: the second launch finds the ticket words reset by the first
+        if split:
+            ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, 1:H + 1, 1:W + 1] = float("nan")
+        E.check(l.dinv_conv3x3_winograd4(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya),
+                                         E.p(ra) if mode == "res" else None, 1 if mode == "relu" else 0, E.p(ws),
+                                         ctypes.c_size_t(0 if ws is None else ws.numel()), None))
+    assert not torch.isnan(ya).any()
+    out = from_act(ya, g, cout)
+    err = float((out.double() - ref).norm() / ref.norm())
+    assert err < 1e-5, err
+    full = ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)
+    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, H + 1].abs().max()) == 0
+    assert float(full[:, :, :, 0].abs().max()) == 0 and float(full[:, :, :, W + 1:].abs().max()) == 0
+
+
+def test_winograd4_rejects_bad_shapes():
+    g = geom(1, 10, 16)
+    x = torch.zeros(2, g.cs, 8)
+    y = torch.zeros(8, g.cs, 8)
+    w = torch.zeros(64 * 16 * 36)
+    l = E.lib()
+    assert l.dinv_conv3x3_winograd4(ctypes.byref(g), E.p(x), E.p(w), 16, 64, E.p(y), None, 0, None, ctypes.c_size_t(0), None) != 0      # height % 4
+    g = geom(1, 8, 16)
+    assert l.dinv_conv3x3_winograd4(ctypes.byref(g), E.p(x), E.p(w), 24, 64, E.p(y), None, 0, None, ctypes.c_size_t(0), None) != 0      # cin % 16
