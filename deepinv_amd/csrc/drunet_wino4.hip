@@ -401,8 +401,9 @@ void conv3x3_wino4_kernel(W4Args a) {
         // one accumulator register quad (= 4 couts of this lane half) of point k as a float4
         auto Q = [&](int k, int g) { return make_float4(acc[k][4 * g], acc[k][4 * g + 1], acc[k][4 * g + 2], acc[k][4 * g + 3]); };
         auto est = [&](int g, int j, float4 val) { st4(lds + ewr + g * 1024 + ((2 * j + h + wt8) & 7) * 4, val); };
-        auto write_full = [&]() {
-            const int fb = (q & 1) ? 3 : 0;                      // first point of the full row
+        // (the branch on the wave's parity is OUTSIDE the loops: every accumulator index is then a compile-time constant)
+        auto full_rows = [&](auto fb_) {
+            constexpr int fb = decltype(fb_)::value;             // first point of the full row
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 F0 = Q(fb, g), F1 = Q(fb + 1, g), F2 = Q(fb + 2, g), F3 = Q(fb + 3, g), F4 = Q(fb + 4, g), F5 = Q(fb + 5, g);
@@ -413,18 +414,25 @@ void conv3x3_wino4_kernel(W4Args a) {
                 est(g, 3, add4(fma4(8.f, sd, sb), F5));
             }
         };
+        auto write_full = [&]() {
+            if (q & 1) full_rows(std::integral_constant<int, 3>{});
+            else full_rows(std::integral_constant<int, 0>{});
+        };
         auto write_half = [&]() {
-            const int hb = (q & 1) ? 0 : 6;                      // first point of the half row
+            if (q & 1) {          // points 0-2 = row cols 3-5:  s = (H3 + H4, 2 (H3 - H4), 4 (H3 + H4), 8 (H3 - H4) + H5)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 H0 = Q(hb, g), H1 = Q(hb + 1, g), H2 = Q(hb + 2, g);
-                if (q & 1) {      // row cols 3-5:  s = (H3 + H4, 2 (H3 - H4), 4 (H3 + H4), 8 (H3 - H4) + H5)
+                for (int g = 0; g < 4; ++g) {
+                    const float4 H0 = Q(0, g), H1 = Q(1, g), H2 = Q(2, g);
                     const float4 c = add4(H0, H1), d = sub4(H0, H1);
                     est(g, 0, c);
                     est(g, 1, add4(d, d));
                     est(g, 2, make_float4(4.f * c.x, 4.f * c.y, 4.f * c.z, 4.f * c.w));
                     est(g, 3, fma4(8.f, d, H2));
-                } else {          // row cols 0-2:  s = (L0 + L1 + L2, L1 - L2, L1 + L2, L1 - L2)
+                }
+            } else {              // points 6-8 = row cols 0-2:  s = (L0 + L1 + L2, L1 - L2, L1 + L2, L1 - L2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 H0 = Q(6, g), H1 = Q(7, g), H2 = Q(8, g);
                     const float4 c = add4(H1, H2), d = sub4(H1, H2);
                     est(g, 0, add4(H0, c));
                     est(g, 1, d);

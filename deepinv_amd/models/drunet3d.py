@@ -56,6 +56,7 @@ class Vol:
 
     def __init__(self, lv, channels, device):
         self.lv = lv
+        self.sig = _pool_sig          # buffers of an earlier problem shape are not recycled when they die later
         self.key = (torch.device(device), int(channels), lv.B, lv.D, lv.H, lv.W)
         free = _POOL.get(self.key)
         if free:
@@ -82,7 +83,7 @@ class Vol:
         global _pool_bytes
         try:
             t, key = self.t, self.key
-            if _pool_bytes + t.numel() * 4 <= POOL_MAX_BYTES:
+            if self.sig == _pool_sig and _pool_bytes + t.numel() * 4 <= POOL_MAX_BYTES:
                 _POOL.setdefault(key, []).append(t)
                 _pool_bytes += t.numel() * 4
         except Exception:       # interpreter shutdown
