@@ -575,7 +575,17 @@ def cpu_baseline(denoiser, maps, mask, H, W, coils, iters, y_cpu, x_gpu, parity_
     else:
         whole.update(value=round(1.0 / (per_it * iters), 5), unit="slices/s", sample="one process fills the usable cores")
     errs = {i: float((x_gpu[i:i + 1].double() - xk.double()).norm() / xk.double().norm()) for i, xk in recs.items()}
-    return {"_rec0": recs[0], "value": round(1.0 / (per_it * iters), 5), "unit": "slices/s", "cores": threads, "host_cores": cores,
+    # what backs kind = "port": the port and the REAL reference were run on this very problem (slice 0, 50 iterations) in the
+    # build container, where the reference imports (tests/golden/make_golden_r4.py): identical results, same seconds per slice
+    backing = None
+    try:
+        import numpy as np
+        g = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_named.npz"))
+        backing = {"where": "build container, %d threads" % int(g["threads"]), "seconds_per_slice_reference": round(float(g["seconds_reference"]), 1),
+                   "seconds_per_slice_port": round(float(g["seconds_port"]), 1), "rel_diff_port_vs_reference": float(g["port_vs_reference"])}
+    except (OSError, KeyError):
+        pass
+    return {"_rec0": recs[0], "port_vs_reference": backing, "value": round(1.0 / (per_it * iters), 5), "unit": "slices/s", "cores": threads, "host_cores": cores,
             "usable_cores": usable, "kind": "port", "threads_calibration_s_per_denoiser_call": calib,
             "samples_s_per_iteration": [round(v, 4) for v in samples],
             "sample": f"slice 0 of the batch: median of 3 timed samples ({iters} it once, {short} it twice), "

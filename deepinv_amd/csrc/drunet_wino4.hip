@@ -99,9 +99,6 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 b) {
     return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
 }
 
-#ifndef DINV_W4_DIAG
-#define DINV_W4_DIAG 0      // diagnostic builds only (scripts/r04): leave parts of the main loop out to price them
-#endif
 #ifdef DINV_EMU
 #define DINV_W4_ATTR
 #else
@@ -173,7 +170,7 @@ void conv3x3_wino4_kernel(W4Args a) {
 #pragma unroll
         for (int i = 0; i < S::NLD; ++i) {
             const int e = t + NTHR * i;
-            const int half = e >= S::NPIX ? 1 : 0, px = e - half * S::NPIX;
+            const int half = e & 1, px = e >> 1;      // lanes = consecutive 16-byte halves of consecutive pixels: 1 KB per wave load
             const int c = px % S::RW;
             const int r = (px / S::RW) % S::RH;
             const int sb = px / (S::RW * S::RH);
@@ -191,7 +188,7 @@ void conv3x3_wino4_kernel(W4Args a) {
     // LDS float offset of staging load i inside a raw stage
     auto loff = [&](int i) {
         const int e = tid + NTHR * i;
-        return (e >= S::NPIX ? e - S::NPIX + S::NPIXP : e) * 4;
+        return ((e & 1) * S::NPIXP + (e >> 1)) * 4;
     };
     auto stage_ok = [&](int i) { return S::RAW4 % NTHR == 0 || i + 1 < S::NLD || tid + NTHR * i < S::RAW4; };
 
@@ -328,23 +325,23 @@ void conv3x3_wino4_kernel(W4Args a) {
             const int cbs = cb + 2 < ecb1 ? cb + 2 : ecb1 - 1;
             static_for<36>([&](auto s_) {
                 constexpr int SL = decltype(s_)::value, pt = SL / 4, m = SL % 4;
-                if constexpr (SL == 30 && !(DINV_W4_DIAG & 16)) lds_barrier();
+                if constexpr (SL == 30) lds_barrier();
                 acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(u[pt % 3], m), comp(v[(pt + P) % 2], m), acc[pt], 0, 0, 0);
-                if constexpr (m == 0 && !(DINV_W4_DIAG & 2)) {
+                if constexpr (m == 0) {
                     constexpr int k = pt + 2;
                     if constexpr (k < 9) u[k % 3] = ld_u(wt, cb, k);
                     else u[k % 3] = ld_u(wt, cbu, k - 9);
                 }
-                if constexpr (m == 1 && !(DINV_W4_DIAG & 8)) {
+                if constexpr (m == 1) {
                     constexpr int k = pt + 1;
                     if constexpr (k < 9) v[(k + P) % 2] = ld4(vcur + vrd + k * 4);
                     else v[(k + P) % 2] = ld4(vnxt + vrd);            // next block's point 0: behind the barrier
                 }
-                if constexpr (SL < S::NLD && !(DINV_W4_DIAG & 4)) pr[SL] = ld_x(cbs, SL);
-                if constexpr (SL < 18 && SL % 3 == 0 && !(DINV_W4_DIAG & 1)) tr_read(rnxt, SL / 3);
-                if constexpr (SL < 18 && SL % 3 == 2 && !(DINV_W4_DIAG & 1)) tr_rows(SL / 3);
-                if constexpr (SL >= 18 && SL < 30 && (SL - 18) % 2 == 0 && !(DINV_W4_DIAG & 1)) tr_cols(vnxt, (SL - 18) / 4, ((SL - 18) / 2) % 2);
-                if constexpr (SL >= 24 && SL < 24 + S::NLD && !(DINV_W4_DIAG & 4))
+                if constexpr (SL < S::NLD) pr[SL] = ld_x(cbs, SL);
+                if constexpr (SL < 18 && SL % 3 == 0) tr_read(rnxt, SL / 3);
+                if constexpr (SL < 18 && SL % 3 == 2) tr_rows(SL / 3);
+                if constexpr (SL >= 18 && SL < 30 && (SL - 18) % 2 == 0) tr_cols(vnxt, (SL - 18) / 4, ((SL - 18) / 2) % 2);
+                if constexpr (SL >= 24 && SL < 24 + S::NLD)
                     if (stage_ok(SL - 24)) st4(rst + loff(SL - 24), pr[SL - 24]);
                 __builtin_amdgcn_sched_barrier(0);
             });

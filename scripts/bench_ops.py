@@ -66,14 +66,16 @@ def bench_radon(B, W, nang):
                           "alg_MB": alg / 1e6, "GBps": alg / t / 1e9, "Gsamples_per_s": B * G * G * nang / t / 1e9}))
 
 
-def bench_drunet(B, cin, H, W, gflop_per_img):
+def bench_drunet(B, cin, H, W, gflop_per_img, precision=None):
     dev = torch.device("cuda:0")
     model = dinv.models.DRUNet(cin, cin, pretrained=None).to(dev).eval()
+    if precision:
+        model.conv_precision = precision
     x = torch.rand(B, cin, H, W, device=dev)
     with torch.no_grad():
         t = timeit(lambda: model(x, 0.05), iters=5, warmup=2)
     tf = gflop_per_img * B / t / 1e3
-    print(json.dumps({"op": "DRUNet.forward", "B": B, "cin": cin, "img": [H, W], "ms": t * 1e3, "TFLOPs": tf,
+    print(json.dumps({"op": "DRUNet.forward", "conv_precision": model.conv_precision, "B": B, "cin": cin, "img": [H, W], "ms": t * 1e3, "TFLOPs": tf,
                       "frac_fp32_mfma_peak": tf / 157.3}))
 
 
@@ -112,6 +114,10 @@ if __name__ == "__main__":
         bench_radon(8, 512, 720)
     if "drunet" in which:
         bench_drunet(32, 2, 320, 320, 433.4)
+    if "drunet_fp32" in which:
+        bench_drunet(32, 2, 320, 320, 433.4, "fp32")
+    if "drunet4_fp32" in which:
+        bench_drunet(4, 2, 320, 320, 433.4, "fp32")
     if "convlv" in which:
         bench_conv_levels(32)
         bench_conv_levels(4)
