@@ -172,6 +172,7 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t shmem, Args... args) 
                 run_block([&] { kernel(args...); }, block);
             }
 }
+inline void yield_if_fiber() {}     // workgroups run one after the other: a spin on another workgroup's flag can only time out
 inline int lane() { return linear_tid() & 63; }
 inline int wave() { return linear_tid() >> 6; }
 // all live lanes of the wave deposit `words` 64-bit words, synchronise, and may then read anybody's
@@ -226,6 +227,10 @@ inline int emu_readfirstlane(int v) { return __shfl(v, 0, 64); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ::emu::yield_if_fiber()
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4      // (the __hip_atomic_* builtins themselves are clang's, also on the host)
+#endif
 // buffer resources (range-checked loads / stores: offsets >= num_records are dropped / read as zero)
 struct __amdgpu_buffer_rsrc_t { char* base; unsigned num; };
 inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) { return {(char*)p, (unsigned)num}; }
