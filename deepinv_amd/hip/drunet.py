@@ -21,7 +21,7 @@ _declared = False
 # ResBlock convolutions take (4: csrc/drunet_wino4.hip, 2: csrc/drunet_wino.hip) and the fewest workgroup tiles (64 couts x
 # 32 tile positions) a launch must have for the F(4x4,3x3) kernel (one persistent workgroup per CU: 256 on MI355X)
 FP32_WINOGRAD_TILE = 4
-WINOGRAD4_MIN_TILES = 192
+WINOGRAD4_MIN_TILES = 64
 
 
 def _l():
