@@ -457,34 +457,60 @@ __global__ __launch_bounds__(256) void tail3x3_kernel(Geom g, const float* __res
     st4(y + (g.sl + p) * 8, make_float4(o4[0], o4[1], o4[2], o4[3]));
 }
 
-// Row-blocked variant: one lane produces RB = 4 vertically adjacent pixels of one column, so the 3 x 3 neighbourhoods of
-// its pixels share input rows: 6 rows x 3 columns of loads per channel block instead of 4 x 9 (the one-pixel form is
-// bound by the vector cache: 9 taps x 64 channels x 2 tensors per pixel); lanes still run along the row (coalesced).
+// Lane-shift variant (the one the launcher uses): one lane owns one padded column and RB = 8 output rows; every input pixel
+// (32 bytes per channel block and tensor) is loaded ONCE by its own lane and reaches the two neighbouring columns through a
+// wave shift (v_mov_b32_dpp wave_shr:1 / wave_shl:1), so the vector cache sees 10 rows x 1 column of loads per 8 output pixels
+// instead of 6 x 3 per 4: the kernel then runs at the rate the two input tensors stream from HBM.  A wave covers `sw` <= 62
+// output columns (lanes 1 .. sw; lanes 0 and sw + 1 only feed their neighbours).
+__device__ __forceinline__ float lane_prev(float v) {     // value of lane - 1
+#ifdef DINV_EMU
+    return __shfl_up(v, 1);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+#endif
+}
+__device__ __forceinline__ float lane_next(float v) {     // value of lane + 1
+#ifdef DINV_EMU
+    return __shfl_down(v, 1);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+#endif
+}
+
 template <int COUT>
-__global__ __launch_bounds__(256) void tail3x3_rows_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ x2,
-                                                           const float* __restrict__ w, float* __restrict__ y, int ncb) {
-    constexpr int RB = 4;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);                   // padded column
-    const int rg = blockIdx.y * 4 + (threadIdx.x >> 6);                   // group of RB image rows
+__global__ __launch_bounds__(256) void tail3x3_shift_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ x2,
+                                                            const float* __restrict__ w, float* __restrict__ y, int ncb, int sw) {
+    constexpr int RB = 8;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * sw + lane;                                 // padded column of this lane
+    const int rg = blockIdx.y * 4 + (threadIdx.x >> 6);                   // group of RB image rows (wave-uniform)
     const int b = blockIdx.z;
     const int r0 = 1 + rg * RB;                                           // first padded row of the group
-    if (c < 1 || c > g.w || r0 > g.h) return;
+    if (r0 > g.h) return;                                                 // whole wave
+    const bool feeds = lane <= sw + 1 && c <= g.w + 1;                    // columns 0 and w + 1 are the zero frame
     float acc[RB][COUT];
 #pragma unroll
     for (int k = 0; k < RB; ++k)
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[k][co] = 0.f;
-    const int64_t p0 = (int64_t)b * g.plane + (int64_t)r0 * g.wp + c;       // pixel (r0, c)
+    const int64_t p0 = (int64_t)b * g.plane + (int64_t)r0 * g.wp + (feeds ? c : 0);
     for (int cb = 0; cb < ncb; ++cb) {
         const int64_t base = ((int64_t)cb * g.cs + g.sl + p0) * 8;
 #pragma unroll
         for (int rr = -1; rr <= RB; ++rr) {                               // input rows r0 - 1 .. r0 + RB
-            if (r0 + rr > g.h + 1) continue;                              // below the zero frame: nothing to read
+            if (r0 + rr > g.h + 1) continue;                              // below the zero frame: nothing to read (wave-uniform)
+            const int64_t o = base + (int64_t)rr * g.wp * 8;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bq = a;
+            if (feeds) {
+                a = ld4(x + o); bq = ld4(x + o + 4);
+                if (x2) { a = add4(a, ld4(x2 + o)); bq = add4(bq, ld4(x2 + o + 4)); }
+            }
+            const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
             for (int dc = -1; dc <= 1; ++dc) {
-                const int64_t o = base + ((int64_t)rr * g.wp + dc) * 8;
-                float4 a = ld4(x + o), bq = ld4(x + o + 4);
-                if (x2) { a = add4(a, ld4(x2 + o)); bq = add4(bq, ld4(x2 + o + 4)); }
+                float u[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) u[i] = dc == 0 ? v[i] : dc < 0 ? lane_prev(v[i]) : lane_next(v[i]);
 #pragma unroll
                 for (int k = 0; k < RB; ++k) {                            // output row r0 + k uses it as tap dy = rr - k + 1
                     const int dy = rr - k + 1;
@@ -493,13 +519,14 @@ __global__ __launch_bounds__(256) void tail3x3_rows_kernel(Geom g, const float* 
 #pragma unroll
                     for (int co = 0; co < COUT; ++co) {
                         const float* wv = w + (((int64_t)cb * 9 + t) * COUT + co) * 8;   // uniform: scalar loads
-                        acc[k][co] += a.x * wv[0] + a.y * wv[1] + a.z * wv[2] + a.w * wv[3] + bq.x * wv[4] + bq.y * wv[5] +
-                                      bq.z * wv[6] + bq.w * wv[7];
+                        acc[k][co] += u[0] * wv[0] + u[1] * wv[1] + u[2] * wv[2] + u[3] * wv[3] + u[4] * wv[4] + u[5] * wv[5] +
+                                      u[6] * wv[6] + u[7] * wv[7];
                     }
                 }
             }
         }
     }
+    if (lane < 1 || lane > sw || c > g.w) return;
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
         if (r0 + k > g.h) break;
@@ -625,12 +652,13 @@ extern "C" int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const f
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const Geom gg = make_geom(*g);
     if (g->batch <= 65535) {
-        const dim3 rgrid((unsigned)ceil_div(g->wp, 64), (unsigned)ceil_div(ceil_div(g->height, 4), 4), (unsigned)g->batch);
+        const int nstrip = (int)ceil_div(g->width, 62), sw = (int)ceil_div(g->width, nstrip);     // balanced strips of <= 62 columns
+        const dim3 rgrid((unsigned)nstrip, (unsigned)ceil_div(ceil_div(g->height, 8), 4), (unsigned)g->batch);
         switch (cout) {
-            case 1: hipLaunchKernelGGL(tail3x3_rows_kernel<1>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;
-            case 2: hipLaunchKernelGGL(tail3x3_rows_kernel<2>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;
-            case 3: hipLaunchKernelGGL(tail3x3_rows_kernel<3>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;
-            default: hipLaunchKernelGGL(tail3x3_rows_kernel<4>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8); break;
+            case 1: hipLaunchKernelGGL(tail3x3_shift_kernel<1>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw); break;
+            case 2: hipLaunchKernelGGL(tail3x3_shift_kernel<2>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw); break;
+            case 3: hipLaunchKernelGGL(tail3x3_shift_kernel<3>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw); break;
+            default: hipLaunchKernelGGL(tail3x3_shift_kernel<4>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw); break;
         }
         DINV_CHECK_LAUNCH();
         return 0;

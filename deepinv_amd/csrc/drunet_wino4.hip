@@ -132,13 +132,16 @@ void conv3x3_wino4_kernel(W4Args a) {
     constexpr int RROW = S::RW * 4;                                  // floats between two rows of the raw stage
     // rows of the patch that enter xa, xb, xc:  row half 0 -> (0, 2, 4), row half 1 -> (1, 3, 5)
     const int rx = rbase + trh * RROW;
-    // per-lane coefficients that let both row halves run ONE instruction stream (B^T rows {0,1,2} / {5,3,4}):
+    // per-lane coefficients that let both row halves run ONE instruction stream (B^T rows {0,1,2} / {5,4,3}):
     //   tA = 4 xa - 5 xb + xc;  p = d4 - al d2;  qq = d3 - al d1;  tB = p + be qq;  tC = p - be qq
-    const float al = trh ? 1.f : 4.f, be = trh ? 2.f : 1.f, nbe = -be;
-    // V write rows (6 points of 4 floats each): (A, B, C) = (0, 1, 2) / (5, 3, 4)
+    const float al = trh ? 1.f : 4.f, be = trh ? -2.f : 1.f, nbe = -be;
+    // Point slots of the V stage (and of the packed U): every wave's 9 consecutive slots are (a full Winograd row, half a row),
+    //   0-5 row 0 | 6-8 row 1 cols 0-2 | 9-14 row 2 | 15-17 row 1 cols 3-5 | 18-23 row 3 | 24-26 row 4 cols 0-2 | 27-32 row 5 | 33-35 row 4 cols 3-5
+    // so that the SAME six accumulators die first in every wave's epilogue.  V write rows (A, B, C) = (0, 1, 2) / (5, 4, 3):
+    // B is the row that is stored in two pieces (its columns 3-5 sit 9 slots behind its columns 0-2)
     const int vwbase = ((tch >> 2) * 32 + tpos) * VP + (tch & 3);
-    int vwa = S::VOFF + vwbase + (trh ? 5 : 0) * 24, vwb = S::VOFF + vwbase + (trh ? 3 : 1) * 24,
-        vwc = S::VOFF + vwbase + (trh ? 4 : 2) * 24;
+    int vwa = S::VOFF + vwbase + (trh ? 27 : 0) * 4, vwb = S::VOFF + vwbase + (trh ? 24 : 6) * 4,
+        vwc = S::VOFF + vwbase + (trh ? 18 : 9) * 4;
     // LDS map: [raw stage 0][raw stage 1][V stage 0][V stage 1].  The V bases are beyond the 64 KB reach of a ds immediate
     // offset: they are folded into the per-lane offsets above, which are made opaque so that the compiler addresses every
     // access as (one base register + immediate) instead of hoisting one address register per distinct constant
@@ -228,6 +231,7 @@ void conv3x3_wino4_kernel(W4Args a) {
     // row i of (B^T d) B: outputs 0..2 (part 0) or 3..5 (part 1), written to the V stage
     auto tr_cols = [&](float* vst, int i, int part) {
         const int wr = i == 0 ? vwa : i == 1 ? vwb : vwc;
+        const int hi = i == 1 ? 36 : 12;          // float offset of columns 3-5 behind columns 0-2
         const float* tt = t[i];
         if (part == 0) {
             const float o0 = fmaf(-5.f, tt[2], fmaf(4.f, tt[0], tt[4]));
@@ -240,9 +244,9 @@ void conv3x3_wino4_kernel(W4Args a) {
             const float p = tt[4] - tt[2];
             const float r = tt[3] - tt[1];
             const float o5 = fmaf(-5.f, tt[3], fmaf(4.f, tt[1], tt[5]));
-            vst[wr + 12] = fmaf(2.f, r, p);
-            vst[wr + 16] = fmaf(-2.f, r, p);
-            vst[wr + 20] = o5;
+            vst[wr + hi] = fmaf(2.f, r, p);
+            vst[wr + hi + 4] = fmaf(-2.f, r, p);
+            vst[wr + hi + 8] = o5;
         }
     };
 
@@ -298,10 +302,6 @@ void conv3x3_wino4_kernel(W4Args a) {
             if (stage_ok(i)) { st4(R0 + loff(i), pr[i]); st4(R0 + S::RAWF + loff(i), pr2[i]); }
         u[0] = ld_u(wt, ecb0, 0);
         u[1] = ld_u(wt, ecb0, 1);
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
         lds_barrier();
         DINV_STAMP(1);
 #pragma unroll
@@ -315,8 +315,10 @@ void conv3x3_wino4_kernel(W4Args a) {
         // ---- one 8-channel block = 36 slots of one MFMA + its share of: the U ring (3 points ahead, straight from L2), the
         // V ring (1 point ahead), staging block cb+2 (loads in slots 0.., LDS writes in slots 24..), transforming block cb+1
         // (columns in slots 0-17, rows and V writes in slots 18-29), the barrier in slot 30
-        auto block = [&](int cb, auto par) {
+        // (FIRST: the tile's first block starts every accumulator from the constant 0 - no registers are zeroed)
+        auto block = [&](int cb, auto par, auto first_) {
             constexpr int P = decltype(par)::value;
+            constexpr bool FIRST = decltype(first_)::value;
             const float* vcur = V0 + P * VBUF;
             float* vnxt = V0 + (1 - P) * VBUF;
             const float* rnxt = R0 + (1 - P) * S::RAWF;
@@ -326,7 +328,10 @@ void conv3x3_wino4_kernel(W4Args a) {
             static_for<36>([&](auto s_) {
                 constexpr int SL = decltype(s_)::value, pt = SL / 4, m = SL % 4;
                 if constexpr (SL == 30) lds_barrier();
-                acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(u[pt % 3], m), comp(v[(pt + P) % 2], m), acc[pt], 0, 0, 0);
+                if constexpr (FIRST && m == 0)
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(u[pt % 3], m), comp(v[(pt + P) % 2], m), (f32x16)(0.f), 0, 0, 0);
+                else
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(u[pt % 3], m), comp(v[(pt + P) % 2], m), acc[pt], 0, 0, 0);
                 if constexpr (m == 0) {
                     constexpr int k = pt + 2;
                     if constexpr (k < 9) u[k % 3] = ld_u(wt, cb, k);
@@ -349,16 +354,18 @@ void conv3x3_wino4_kernel(W4Args a) {
         {
             using P0 = std::integral_constant<int, 0>;
             using P1 = std::integral_constant<int, 1>;
+            block(ecb0, P0{}, std::true_type{});         // even number of channel blocks per item: checked on the host
+            block(ecb0 + 1, P1{}, std::false_type{});
 #pragma unroll 1
-            for (int cb = ecb0; cb < ecb1; cb += 2) {   // even number of channel blocks per item: checked on the host
-                block(cb, P0{});
-                block(cb + 1, P1{});
+            for (int cb = ecb0 + 2; cb < ecb1; cb += 2) {
+                block(cb, P0{}, std::false_type{});
+                block(cb + 1, P1{}, std::false_type{});
             }
         }
 
         DINV_STAMP(3);
-        // ---- epilogue.  Wave (c2, q) holds the points 9q .. 9q+8 of cout half c2: a full Winograd row and half a row,
-        //   q = 0: row 0, row 1 cols 0-2     q = 1: row 1 cols 3-5, row 2     q = 2: row 3, row 4 cols 0-2     q = 3: row 4 cols 3-5, row 5
+        // ---- epilogue.  Wave (c2, q) holds the point slots 9q .. 9q+8 of cout half c2: a full Winograd row, then half a row,
+        //   q = 0: row 0, row 1 cols 0-2     q = 1: row 2, row 1 cols 3-5     q = 2: row 3, row 4 cols 0-2     q = 3: row 5, row 4 cols 3-5
         // and reduces them along the row: s = (row of M) A, four values per (part of a) row.  Two exchange rounds through LDS
         // in which EVERY wave writes and every thread finishes: round A = the full rows (0, 2, 3, 5), round B = the half
         // rows (the two halves of rows 1 and 4 are added by the reader).  The finishing thread (wave = 8-channel block of the
@@ -398,12 +405,10 @@ void conv3x3_wino4_kernel(W4Args a) {
         // one accumulator register quad (= 4 couts of this lane half) of point k as a float4
         auto Q = [&](int k, int g) { return make_float4(acc[k][4 * g], acc[k][4 * g + 1], acc[k][4 * g + 2], acc[k][4 * g + 3]); };
         auto est = [&](int g, int j, float4 val) { st4(lds + ewr + g * 1024 + ((2 * j + h + wt8) & 7) * 4, val); };
-        // (the branch on the wave's parity is OUTSIDE the loops: every accumulator index is then a compile-time constant)
-        auto full_rows = [&](auto fb_) {
-            constexpr int fb = decltype(fb_)::value;             // first point of the full row
+        auto write_full = [&]() {       // accumulators 0-5
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 F0 = Q(fb, g), F1 = Q(fb + 1, g), F2 = Q(fb + 2, g), F3 = Q(fb + 3, g), F4 = Q(fb + 4, g), F5 = Q(fb + 5, g);
+                const float4 F0 = Q(0, g), F1 = Q(1, g), F2 = Q(2, g), F3 = Q(3, g), F4 = Q(4, g), F5 = Q(5, g);
                 const float4 sa = add4(F1, F2), sb = sub4(F1, F2), sc = add4(F3, F4), sd = sub4(F3, F4);
                 est(g, 0, add4(add4(F0, sa), sc));
                 est(g, 1, fma4(2.f, sd, sb));
@@ -411,22 +416,18 @@ void conv3x3_wino4_kernel(W4Args a) {
                 est(g, 3, add4(fma4(8.f, sd, sb), F5));
             }
         };
-        auto write_full = [&]() {
-            if (q & 1) full_rows(std::integral_constant<int, 3>{});
-            else full_rows(std::integral_constant<int, 0>{});
-        };
-        auto write_half = [&]() {
-            if (q & 1) {          // points 0-2 = row cols 3-5:  s = (H3 + H4, 2 (H3 - H4), 4 (H3 + H4), 8 (H3 - H4) + H5)
+        auto write_half = [&]() {       // accumulators 6-8 (the branch on the wave's parity is outside the loops)
+            if (q & 1) {          // row cols 3-5:  s = (H3 + H4, 2 (H3 - H4), 4 (H3 + H4), 8 (H3 - H4) + H5)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 H0 = Q(0, g), H1 = Q(1, g), H2 = Q(2, g);
+                    const float4 H0 = Q(6, g), H1 = Q(7, g), H2 = Q(8, g);
                     const float4 c = add4(H0, H1), d = sub4(H0, H1);
                     est(g, 0, c);
                     est(g, 1, add4(d, d));
                     est(g, 2, make_float4(4.f * c.x, 4.f * c.y, 4.f * c.z, 4.f * c.w));
                     est(g, 3, fma4(8.f, d, H2));
                 }
-            } else {              // points 6-8 = row cols 0-2:  s = (L0 + L1 + L2, L1 - L2, L1 + L2, L1 - L2)
+            } else {              // row cols 0-2:  s = (L0 + L1 + L2, L1 - L2, L1 + L2, L1 - L2)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 H0 = Q(6, g), H1 = Q(7, g), H2 = Q(8, g);
@@ -443,6 +444,13 @@ void conv3x3_wino4_kernel(W4Args a) {
         lds_barrier();                  // every wave is done with the V / raw stages: the exchange buffer overlays them
         DINV_STAMP(4);
         write_full();
+        if (NRES && !SPLIT) {     // the six full-row accumulators are dead: room for the 16 residual values, which travel while
+                                    // the first round is finished and the second one written
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rv[it][i] = ld4_so(a.res + cbo, out_off(it, i), 0u);
+        }
         lds_barrier();
         DINV_STAMP(5);
 #pragma unroll
@@ -466,13 +474,6 @@ void conv3x3_wino4_kernel(W4Args a) {
         __builtin_amdgcn_sched_barrier(0);
         // every accumulator is dead: the next tile's first two raw blocks are requested now and land while this tile's outputs
         // are finished and stored
-        if (NRES && !SPLIT) {     // every accumulator is dead: room for the 16 residual values (they land behind the barrier and
-                                    // while the first tiles are finished)
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rv[it][i] = ld4_so(a.res + cbo, out_off(it, i), 0u);
-        }
         if (more) {
 #pragma unroll
             for (int i = 0; i < S::NLD; ++i) { pr[i] = ld_x(cb0, i); pr2[i] = ld_x(cb0 + 1, i); }

@@ -171,16 +171,24 @@ def winograd4_matrices(dtype=torch.float64, device=None):
     return bt, g, at
 
 
+# Winograd point 6 * row + col held by each of the 36 point slots of csrc/drunet_wino4.hip: every wave's nine consecutive slots
+# are a full row of the 6 x 6 transform followed by half a row (the halves of rows 1 and 4), so that every wave's epilogue
+# retires the same six accumulators first
+WINOGRAD4_POINT_SLOTS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17, 9, 10, 11,
+                         18, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35, 27, 28, 29)
+
+
 def pack_winograd4_weight(w: torch.Tensor) -> torch.Tensor:
     """OIHW [Cout,Cin,3,3] -> U = G g G^T of Winograd F(4x4,3x3) (fp64, rounded once to fp32), packed for
     csrc/drunet_wino4.hip as the MFMA A fragments of the wave that uses them:
-    [Cout/64][Cin/8][wave = 4 c2 + q][k 9][lane = 32 h + r][m 4] holds U[point 9 q + k][cout 64 ct + 32 c2 + r][cin 8 cb + 4 h + m];
+    [Cout/64][Cin/8][wave = 4 c2 + q][k 9][lane = 32 h + r][m 4] holds U[point slot 9 q + k][cout 64 ct + 32 c2 + r][cin 8 cb + 4 h + m];
     needs Cin % 16 == 0 and Cout % 64 == 0"""
     cout, cin = w.shape[:2]
     if cin % 16 or cout % 64:
         raise ValueError(f"winograd F(4,3) packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
     _, G, _ = winograd4_matrices(device=w.device)
     u = (G @ w.detach().double() @ G.t()).float()                       # [co, ci, 6, 6]
+    u = u.reshape(cout, cin, 36)[:, :, list(WINOGRAD4_POINT_SLOTS)]     # slot order: see WINOGRAD4_POINT_SLOTS
     u = u.reshape(cout // 64, 2, 32, cin // 8, 2, 4, 4, 9)              # ct, c2, r, cb, h, m, q, k
     return u.permute(0, 3, 1, 6, 7, 4, 2, 5).contiguous()               # ct, cb, c2, q, k, h, r, m
 

@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 5 = this header (4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 6 = this header (5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -169,8 +169,10 @@ int dinv_conv3x3_winograd(const dinv_act_geom* g, const float* x, const float* w
  * instead of 144 (4x fewer MFMA flops than the direct form, 1.78x fewer than dinv_conv3x3_winograd), fp32 accumulation; the
  * transforms add 2-3e-6 relative per layer against an fp64 convolution (csrc/drunet_wino4.hip: U straight from L2 as MFMA
  * fragments, V = B^T d B computed once per workgroup through LDS, 64 couts x 32 tiles x 36 points per workgroup).
- * w_wino4: U = G g G^T per (cout, cin) packed [cout/64][cin/8][wave 8][point 9][lane 64][4]
- *   (deepinv_amd/hip/drunet.py: pack_winograd4_weight); cin % 16 == 0, cout % 64 == 0, height % 4 == 0, width % 4 == 0;
+ * w_wino4: U = G g G^T per (cout, cin) packed [cout/64][cin/8][wave 8 = 4 (cout half) + q][slot 9][lane 64][4]; the 36 point
+ *   slots 9 q + k hold the Winograd points (6 row + col) 0-5, 6-8 | 12-17, 9-11 | 18-23, 24-26 | 30-35, 27-29: a full row, then
+ *   half a row, per wave (deepinv_amd/hip/drunet.py: pack_winograd4_weight, WINOGRAD4_POINT_SLOTS; ABI version 6 - version 5
+ *   stored the points in natural order); cin % 16 == 0, cout % 64 == 0, height % 4 == 0, width % 4 == 0;
  * relu and res1 are mutually exclusive (ResBlock conv1 / conv2, drunet.py:403-434).
  * workspace (optional, may be NULL): dinv_conv3x3_winograd4_workspace_bytes() bytes of device memory, ZERO-FILLED once by the
  *   caller and then left to the library (it keeps its ticket words zero between launches).  With a workspace the tiles of the

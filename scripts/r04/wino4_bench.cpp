@@ -17,6 +17,8 @@
 
 static const double BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
 static const double G4[6][3] = {{0.25, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+// Winograd point (6 * row + col) of each point slot of the packed U (deepinv_amd/hip/drunet.py: WINOGRAD4_POINT_SLOTS)
+static const int SLOT4[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17, 9, 10, 11, 18, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35, 27, 28, 29};
 static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
 
 #ifdef TIMING
@@ -71,8 +73,8 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) { t2[i][j] = 0; for (int k = 0; k < 3; ++k) t2[i][j] += G2[i][k] * gk[k * 3 + j]; }
                 for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { U2[i][j] = 0; for (int k = 0; k < 3; ++k) U2[i][j] += t2[i][k] * G2[j][k]; }
                 const int ct = co / 64, c2 = (co % 64) / 32, r = co % 32, cb = ci / 8, hh = (ci % 8) / 4, m = ci % 4;
-                for (int pt = 0; pt < 36; ++pt) {
-                    const int q = pt / 9, k = pt % 9;
+                for (int sl = 0; sl < 36; ++sl) {
+                    const int q = sl / 9, k = sl % 9, pt = SLOT4[sl];
                     u4[(((((size_t)ct * ncb + cb) * 8 + (c2 * 4 + q)) * 9 + k) * 64 + (hh * 32 + r)) * 4 + m] = (float)U4[pt / 6][pt % 6];
                 }
                 for (int xi = 0; xi < 16; ++xi)

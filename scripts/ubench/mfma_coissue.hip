@@ -33,6 +33,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
     out[blockIdx.x * NT + threadIdx.x] = s;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two values per lane and instruction) beside the fp32 MFMA: NV packed instructions per MFMA
+template <int NV, bool FMA, int NT = 256>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT / 256))) void kp(float* out, int iters) {
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = 1.0f;
+    f32x2 f[8], c = {1.0f, 0.5f};
+    for (int i = 0; i < 8; ++i) f[i] = (f32x2){a + i, a - i};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[m]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(f[v % 8]) : "v"(c));
+                else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(f[v % 8]) : "v"(c));
+            }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += f[i].x + f[i].y + acc[i][0] + acc[i][7];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+}
+template <int NV, bool FMA, int NT = 256>
+void runp(const char* name, float* d) {
+    const int iters = 2000, blocks = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    kp<NV, FMA, NT><<<blocks, NT>>>(d, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kp<NV, FMA, NT><<<blocks, NT>>>(d, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s NPK=%2d fma=%d waves/simd=%d : %.1f ns per MFMA per SIMD\n", name, NV, (int)FMA, NT / 256,
+           ms * 1e6 / (iters * 8.0 * (NT / 256)));
+}
+
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // same experiment with the bf16 matrix core (v_mfma_f32_32x32x16_bf16, 8 passes = 32 cycles): does VALU hide there?
 template <int NV, int NT = 256>
@@ -111,6 +152,15 @@ int main() {
     run<8, 1, true, 512>("2w: mfma + 8 valu + 1 ds", d);
     run<8, 0, true, 1024>("4w: mfma + 8 valu", d);
     run<16, 0, true, 1024>("4w: mfma + 16 valu", d);
+    runp<2, false>("mfma + 2 pk_add", d);
+    runp<4, false>("mfma + 4 pk_add", d);
+    runp<8, false>("mfma + 8 pk_add", d);
+    runp<4, true>("mfma + 4 pk_fma", d);
+    runp<2, false, 512>("2w: mfma + 2 pk_add", d);
+    runp<4, false, 512>("2w: mfma + 4 pk_add", d);
+    runp<8, false, 512>("2w: mfma + 8 pk_add", d);
+    runp<4, true, 512>("2w: mfma + 4 pk_fma", d);
+    runp<8, true, 512>("2w: mfma + 8 pk_fma", d);
     runb<0>("mfma only", d);
     runb<2>("mfma + 2 valu", d);
     runb<4>("mfma + 4 valu", d);

@@ -162,6 +162,37 @@ def test_winograd4_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
     assert full[:, :, :, 0].abs().max() == 0 and full[:, :, :, W + 1:].abs().max() == 0
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,skip", [(2, 9, 21, 16, 2, True), (1, 19, 70, 8, 1, False), (1, 8, 130, 16, 3, True),
+                                                 (3, 17, 62, 24, 4, True), (4, 320, 320, 64, 2, True), (1, 5, 63, 8, 2, False)])
+def test_tail_conv_lane_shift(dev, B, H, W, cin, cout, skip):
+    """dinv_conv3x3_tail (csrc/drunet.hip tail3x3_shift_kernel: one load per pixel and tensor, column taps through
+    v_mov_b32_dpp wave_shr / wave_shl, 8 output rows per lane, strips of <= 62 columns per wave) against an fp64 conv2d of
+    x (+ x2): one to six strips, ragged row groups, the bench shape; frame and spare channels of the output untouched"""
+    from deepinv_amd.hip import drunet as K
+
+    g = torch.Generator().manual_seed(W)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    x2 = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dev)
+    geo = K.geom(B, H, W)
+
+    def to_act(t):
+        a = K.alloc(geo, t.shape[1], dev)
+        av = a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+        av[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    xa, x2a, wpk = to_act(x), to_act(x2), K.pack_tail_weight(w)
+    ya = torch.full((1, geo.cs, 8), 7.0, device=dev)
+    K.conv3x3_tail(geo, xa, wpk, cin, cout, ya, x2=x2a if skip else None)
+    ref = torch.nn.functional.conv2d((x + x2 if skip else x).double(), w.double(), padding=1)
+    yv = ya[:, geo.sl:geo.sl + geo.np].view(1, B, geo.hp, geo.wp, 8)
+    assert rel_err(yv[0, :, 1:H + 1, 1:W + 1, :cout].permute(0, 3, 1, 2), ref) < 2e-6
+    assert float(yv[0, :, 1:H + 1, 1:W + 1, 4:].min()) == 7.0 and float(yv[0, :, 0].min()) == 7.0
+    assert float(yv[0, :, :, 0].min()) == 7.0 and float(yv[0, :, :, W + 1:].min()) == 7.0
+    assert float(yv[0, :, H + 1:].min()) == 7.0
+
+
 def test_winograd4_conv_rejects_unsupported_shapes(dev):
     from deepinv_amd.hip import drunet as K
 

@@ -605,6 +605,33 @@ def test_conv3x3_fp32_direct(cout):
     assert float((from_act(ya, g, cout).double() - ref).norm() / ref.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,skip", [(2, 9, 21, 16, 2, True), (1, 19, 70, 8, 1, False), (1, 8, 130, 16, 3, True),
+                                                 (3, 17, 62, 24, 4, True), (1, 5, 63, 8, 2, False)])
+def test_tail_conv_lane_shift(B, H, W, cin, cout, skip):
+    """dinv_conv3x3_tail (tail3x3_shift_kernel: one load per pixel, the column taps arrive through wave shifts; 8 output rows
+    per lane, strips of <= 62 columns per wave) against conv2d in fp64: one / two / three strips, ragged row groups, with and
+    without the skip tensor added on the fly; the frame and the unused output channels stay untouched"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_tail_weight
+    gen = torch.Generator().manual_seed(W)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    x2 = torch.randn(B, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / (9 * cin) ** 0.5
+    g = geom(B, H, W)
+    ya = torch.full((1, g.cs, 8), 7.0)
+    xa, x2a, wpk = to_act(x, g), to_act(x2, g), pack_tail_weight(w)
+    E.check(E.lib().dinv_conv3x3_tail(ctypes.byref(g), E.p(xa), E.p(x2a) if skip else None, E.p(wpk), cin, cout, E.p(ya), None))
+    ref = torch.nn.functional.conv2d((x + x2 if skip else x).double(), w.double(), padding=1)
+    yv = ya[:, g.sl:g.sl + g.np].view(1, B, g.hp, g.wp, 8)
+    got = yv[0, :, 1:H + 1, 1:W + 1, :cout].permute(0, 3, 1, 2)
+    assert float((got.double() - ref).norm() / ref.norm()) < 2e-6
+    assert float(yv[0, :, 1:H + 1, 1:W + 1, 4:].min()) == 7.0 and float(yv[0, :, 0].min()) == 7.0      # untouched
+    assert float(yv[0, :, :, 0].min()) == 7.0 and float(yv[0, :, :, W + 1:].min()) == 7.0
+    if cout < 4:
+        assert float(yv[0, :, 1:H + 1, 1:W + 1, cout:4].abs().max()) == 0.0     # the float4 store pads with zeros
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,mode", [(1, 16, 32, 16, 64, "plain"), (2, 8, 8, 32, 64, "relu"), (1, 16, 16, 32, 128, "res"),
                                                  (3, 8, 12, 16, 64, "res"), (1, 20, 36, 16, 64, "relu"), (5, 8, 8, 16, 64, "plain"),
                                                  (20, 16, 16, 16, 128, "res"), (2, 32, 64, 48, 64, "relu"),
