@@ -8,6 +8,8 @@
 // workgroup through LDS, then across workgroups by a second fixed-order pass (no atomics: deterministic).
 #include "common.hpp"
 
+#include <cmath>
+
 using namespace dinv;
 
 namespace {
@@ -15,24 +17,26 @@ namespace {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// out = a*x + b*y + c*z   (y, z optional)
+// out = clamp(a*x + b*y + c*z + d, lo, hi)   (y, z optional; lo = -inf, hi = +inf: no clamp)
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 __global__ __launch_bounds__(256) void lincomb_kernel(int64_t n, float a, const float* __restrict__ x, float b,
                                                       const float* __restrict__ y, float c,
-                                                      const float* __restrict__ z, float* __restrict__ out) {
+                                                      const float* __restrict__ z, float d, float lo, float hi,
+                                                      float* __restrict__ out) {
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 v = ld4(x + 4 * i);
-        v = make_float4(a * v.x, a * v.y, a * v.z, a * v.w);
+        v = make_float4(fmaf(a, v.x, d), fmaf(a, v.y, d), fmaf(a, v.z, d), fmaf(a, v.w, d));
         if (y) { const float4 u = ld4(y + 4 * i); v = make_float4(fmaf(b, u.x, v.x), fmaf(b, u.y, v.y), fmaf(b, u.z, v.z), fmaf(b, u.w, v.w)); }
         if (z) { const float4 u = ld4(z + 4 * i); v = make_float4(fmaf(c, u.x, v.x), fmaf(c, u.y, v.y), fmaf(c, u.z, v.z), fmaf(c, u.w, v.w)); }
-        st4(out + 4 * i, v);
+        st4(out + 4 * i, make_float4(clampf(v.x, lo, hi), clampf(v.y, lo, hi), clampf(v.z, lo, hi), clampf(v.w, lo, hi)));
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = n4 * 4 + threadIdx.x;
-        float v = a * x[i];
+        float v = fmaf(a, x[i], d);
         if (y) v = fmaf(b, y[i], v);
         if (z) v = fmaf(c, z[i], v);
-        out[i] = v;
+        out[i] = clampf(v, lo, hi);
     }
 }
 
@@ -121,15 +125,26 @@ inline unsigned stream_blocks(int64_t n) { return (unsigned)std::min<int64_t>(st
 
 }  // namespace
 
-extern "C" int dinv_lincomb(int64_t n, float a, const float* x, float b, const float* y, float c, const float* z,
-                            float* out, dinv_stream_t stream) {
+static int affine_launch(int64_t n, float a, const float* x, float b, const float* y, float c, const float* z, float d,
+                         float lo, float hi, float* out, dinv_stream_t stream) {
     DINV_REQUIRE(n >= 0 && x && out, "bad arguments");
     if (n == 0) return 0;
     DINV_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)y | (uintptr_t)z) % 16 == 0, "tensors must be 16-byte aligned");
     hipLaunchKernelGGL(lincomb_kernel, dim3(stream_blocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, a, x,
-                       b, y, c, z, out);
+                       b, y, c, z, d, lo, hi, out);
     DINV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dinv_lincomb(int64_t n, float a, const float* x, float b, const float* y, float c, const float* z,
+                            float* out, dinv_stream_t stream) {
+    return affine_launch(n, a, x, b, y, c, z, 0.f, -INFINITY, INFINITY, out, stream);
+}
+
+extern "C" int dinv_affine(int64_t n, float a, const float* x, float b, const float* y, float c, const float* z, float d,
+                           float lo, float hi, float* out, dinv_stream_t stream) {
+    DINV_REQUIRE(lo <= hi, "empty clamp interval [%g, %g]", (double)lo, (double)hi);
+    return affine_launch(n, a, x, b, y, c, z, d, lo, hi, out, stream);
 }
 
 extern "C" int32_t dinv_batched_dot_blocks(int64_t n) { return (int32_t)std::min<int64_t>(std::max<int64_t>(ceil_div(n / 4 + 1, 1024), 1), 256); }

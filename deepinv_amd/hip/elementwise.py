@@ -18,6 +18,7 @@ def _l():
     if not _declared:
         vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
         l.dinv_lincomb.argtypes = [i64, f32, vp, f32, vp, f32, vp, vp, vp]
+        l.dinv_affine.argtypes = [i64, f32, vp, f32, vp, f32, vp, f32, f32, f32, vp, vp]
         l.dinv_batched_dot_blocks.restype = i32
         l.dinv_batched_dot_blocks.argtypes = [i64]
         l.dinv_batched_dot.argtypes = [i32, i64, vp, vp, vp, vp, vp]
@@ -47,6 +48,16 @@ def lincomb(a: float, x, b: float = 0.0, y=None, c: float = 0.0, z=None, out=Non
     if out is None:
         out = torch.empty_like(x)
     check(_l().dinv_lincomb(x.numel(), float(a), ptr(x), float(b), ptr(y), float(c), ptr(z), ptr(out), stream_ptr(x.device)))
+    return out
+
+
+def affine(a: float, x, b: float = 0.0, y=None, c: float = 0.0, z=None, d: float = 0.0, lo: float = -float("inf"),
+           hi: float = float("inf"), out=None):
+    """clamp(a*x + b*y + c*z + d, lo, hi) in one pass (into `out` when given: same shape, contiguous)"""
+    if out is None:
+        out = torch.empty_like(x)
+    check(_l().dinv_affine(x.numel(), float(a), ptr(x), float(b), ptr(y), float(c), ptr(z), float(d), float(lo), float(hi),
+                           ptr(out), stream_ptr(x.device)))
     return out
 
 

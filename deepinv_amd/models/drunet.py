@@ -142,6 +142,18 @@ class DRUNet(Denoiser):
             return torch.ones((x.size(0), 1, *x.shape[2:]), device=x.device) * sigma.to(x.device)
         return torch.full((x.size(0), 1, *x.shape[2:]), float(sigma), device=x.device, dtype=x.dtype)
 
+    def _sigma_operand(self, x, sigma):
+        """the noise level in the form the pack kernel takes it - a float, [B] values or a [B,1,H,W] map - after the shape checks
+        of `_noise_map` (drunet.py:226-249)"""
+        if not isinstance(sigma, torch.Tensor):
+            return float(sigma)
+        if sigma.ndim == 0 or sigma.numel() == 1:
+            return sigma if sigma.is_cuda else float(sigma)
+        if sigma.shape == (x.size(0), 1, *x.shape[2:]) or sigma.shape in [(x.size(0),), (x.size(0), 1, *[1] * self.dim)]:
+            return sigma
+        raise ValueError("Incorrect shape, sigma should be of shape (1,), (batch_size,) or "
+                         f"(batch_size, 1, height, width, (depth)), got {tuple(sigma.shape)}")
+
     def _use_hip(self, x):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         return self.dim == 2 and not needs_grad
@@ -159,6 +171,10 @@ class DRUNet(Denoiser):
         if not x.is_cuda:
             raise HipExtensionError("deepinv_amd.models.DRUNet runs only on a HIP device; there is no CPU fallback")
         if self._use_hip(x):
+            if all(v % 8 == 0 and v > 31 for v in x.shape[2:]):
+                # the pack kernel writes the noise-level channel itself (scalar, one value per sample, or a map): no concatenated
+                # copy of the input is built
+                return self._hip_forward(x, self._sigma_operand(x, sigma))
             run = lambda inp: self._hip_forward(inp[:, :-1], inp[:, -1:])
         elif drunet3d.supported(self):
             run = lambda inp: drunet3d.forward3d(self, inp)             # volumes as stacks of slices on the 2-D kernels

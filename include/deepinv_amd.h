@@ -406,6 +406,11 @@ int dinv_irfft2(const float* in, float* out, int64_t P, const dinv_fft_plan* pla
 /* out = a*x + b*y + c*z  (y, z may be null); n floats, 16-byte aligned */
 int dinv_lincomb(int64_t n, float a, const float* x, float b, const float* y, float c, const float* z,
                  float* out, dinv_stream_t stream);
+/* out = clamp(a*x + b*y + c*z + d, lo, hi)  (y, z may be null; lo = -INFINITY, hi = +INFINITY: no clamp): the affine updates
+ * of DiffPIR in one pass each (reference deepinv/sampling/diffusion.py:463-507: x / (2 sqrt(a_t)) + 0.5; clamp(2 D - 1, -1, 1) / 2
+ * + 0.5 = clamp(D, 0, 1); x_{t-1} = s_a x0 + s_1ma sqrt(1 - zeta) eps + s_1ma sqrt(zeta) n with eps = (x - s_a' x0) / s_1ma'). */
+int dinv_affine(int64_t n, float a, const float* x, float b, const float* y, float c, const float* z, float d,
+                float lo, float hi, float* out, dinv_stream_t stream);
 /* out[b] = <x[b,:], y[b,:]> for b < batch (n floats per sample, n % 4 == 0); deterministic two-stage reduction.
  * `partial` is caller scratch of batch * dinv_batched_dot_blocks(n) floats. */
 int32_t dinv_batched_dot_blocks(int64_t n);

@@ -46,6 +46,20 @@ def emu_backend():
                 setattr(m, name, fn)
     saved.append((H, "_lib", H._lib))
     H._lib = emu
+    EW = importlib.import_module("deepinv_amd.hip.elementwise")
+
+    def eligible_on_host(*tensors):   # the fast-path predicate of the loop algebra with "on the HIP device" read as "on the host"
+        for t in tensors:
+            if t is None:
+                continue
+            if not (isinstance(t, torch.Tensor) and not t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                return False
+            if (torch.is_grad_enabled() and t.requires_grad) or t.data_ptr() % 16:
+                return False
+        return True
+
+    saved.append((EW, "eligible", EW.eligible))
+    EW.eligible = eligible_on_host
     declared = [(m, getattr(m, "_declared")) for m in mods if hasattr(m, "_declared")]
     for m, _ in declared:
         m._declared = False                          # optional symbol groups are declared per library

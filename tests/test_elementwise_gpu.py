@@ -25,6 +25,20 @@ def test_lincomb_and_dot(dev, shape):
         assert torch.equal(d, ew.batched_dot(x, y))  # deterministic
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 17, 19), (1, 7), (16, 3, 256, 256)])
+def test_affine_clamp(dev, shape):
+    """dinv_affine: DiffPIR's affine updates (diffusion.py:463-507) in one launch each"""
+    from deepinv_amd.hip import elementwise as ew
+
+    g = torch.Generator().manual_seed(1)
+    x, y, z = (torch.randn(*shape, generator=g).to(dev) for _ in range(3))
+    assert rel_err(ew.affine(0.5, x, -1.25, y, 2.0, z, d=0.75), 0.5 * x - 1.25 * y + 2.0 * z + 0.75) < 1e-6
+    assert torch.equal(ew.affine(1.0, x, lo=0.0, hi=1.0), x.clamp(0, 1))
+    assert torch.equal(ew.affine(1.0, x, lo=0.0, hi=1.0), ((2 * x - 1).clamp(-1, 1) / 2 + 0.5)) or \
+        rel_err(ew.affine(1.0, x, lo=0.0, hi=1.0), (2 * x - 1).clamp(-1, 1) / 2 + 0.5) < 1e-6
+    assert rel_err(ew.affine(0.3, x, d=0.5), x * 0.3 + 0.5) < 1e-6
+
+
 def test_cg_fast_path_matches_oracle_cg(dev):
     import deepinv_amd as dinv
 

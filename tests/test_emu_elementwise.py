@@ -44,6 +44,26 @@ class EmuEw:
         E.check(self.l.dinv_cg_check(res.shape[0], E.p(res), E.p(tol2), E.p(done), None))
 
 
+@pytest.mark.parametrize("n", [1, 7, 1024, 4099])
+def test_affine_clamp(n):
+    """dinv_affine (DiffPIR's updates, diffusion.py:463-507, one launch each): clamp(a x + b y + c z + d, lo, hi) with optional
+    operands and an n that is not a multiple of 4; dinv_lincomb is the same kernel without constant and clamp"""
+    l = E.lib()
+    g = torch.Generator().manual_seed(n)
+    x, y, z = (torch.randn(n, generator=g) for _ in range(3))
+    f, i64 = ctypes.c_float, ctypes.c_int64
+    inf = float("inf")
+    out = torch.empty(n)
+    E.check(l.dinv_affine(i64(n), f(0.5), E.p(x), f(-1.25), E.p(y), f(2.0), E.p(z), f(0.75), f(-inf), f(inf), E.p(out), None))
+    assert torch.allclose(out, 0.5 * x - 1.25 * y + 2.0 * z + 0.75, atol=1e-6)
+    E.check(l.dinv_affine(i64(n), f(1.0), E.p(x), f(0.0), None, f(0.0), None, f(0.0), f(0.0), f(1.0), E.p(out), None))
+    assert torch.equal(out, x.clamp(0, 1))
+    E.check(l.dinv_affine(i64(n), f(2.0), E.p(x), f(3.0), E.p(y), f(0.0), None, f(-1.0), f(-1.0), f(inf), E.p(out), None))
+    assert torch.allclose(out, (2 * x + 3 * y - 1).clamp(min=-1), atol=1e-6)
+    assert l.dinv_affine(i64(n), f(1.0), E.p(x), f(0.0), None, f(0.0), None, f(0.0), f(1.0), f(0.0), E.p(out), None) != 0   # lo > hi
+    assert torch.allclose(EmuEw().lincomb(0.5, x, -1.25, y, 2.0, z), 0.5 * x - 1.25 * y + 2.0 * z, atol=1e-6)
+
+
 @pytest.mark.parametrize("check_every", [1, 4, 1000])
 def test_cg_with_device_side_convergence_matches_reference_cg(check_every, monkeypatch):
     """however rarely the host looks at the flag (every iteration, every 4th, never before max_iter), the iterate is
