@@ -28,6 +28,7 @@
 //   ReLU / residual, 16-byte stores.  The next tile's first two raw blocks are requested as soon as the accumulators are
 //   dead and land in registers behind the second exchange round.
 #include "drunet_common.hpp"
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -63,6 +64,7 @@ struct W4Args {
     FastDiv d_img, d_ntx, d_nct, d_npw;   // / (nty*ntx), / ntx, / nct, / npw
 #ifdef DINV_W4_TIMING
     long long* dbg;                // phase timestamps (s_memtime) of wave 0: 16 per tile, first 4 tiles of every workgroup
+    int32_t stagger;               // experiment: workgroup j of an XCD starts (j % 4) * stagger / 4 cycles late (DINV_W4_STAGGER)
 #endif
 };
 
@@ -282,6 +284,11 @@ void conv3x3_wino4_kernel(W4Args a) {
     for (int i = 0; i < S::NLD; ++i) { pr[i] = ld_x(cb0, i); pr2[i] = ld_x(cb0 + 1, i); }
 
 #ifdef DINV_W4_TIMING
+    if (a.stagger > 0) {
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        const long long wait = (long long)((bid >> 3) & 3) * a.stagger / 4;
+        while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     int tile_k = 0;
 #define DINV_STAMP(i) do { if (a.dbg && tid == 0 && tile_k < 4) a.dbg[(bid * 4 + tile_k) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
@@ -679,6 +686,7 @@ extern "C" int dinv_conv3x3_winograd4(const dinv_act_geom* g, const float* x, co
     }
 #ifdef DINV_W4_TIMING
     a.dbg = g_w4_dbg;
+    a.stagger = getenv("DINV_W4_STAGGER") ? atoi(getenv("DINV_W4_STAGGER")) : 0;
 #endif
     hipStream_t st = (hipStream_t)stream;
     if (relu) return launch_any<true, 0>(a, st);
