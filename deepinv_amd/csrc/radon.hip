@@ -28,13 +28,30 @@ struct RadonGeom {
     float scale;  // 1/operator_norm (tomography.py:253-254)
 };
 
-// bit-identical in both kernels: sample position (ix -> column, iy -> row) of lattice point (j, i)
-// grid = [xn_j, xn_i] R^T (radon.py:334-341), unnormalised as ATen's grid_sampler (align_corners=True)
+// sample position (ix -> column, iy -> row) for grid = [gx, gy] R^T (radon.py:334-341), unnormalised as ATen's grid_sampler
+// (align_corners=True): the fan-beam kernels, whose lattice is not uniform
 __device__ __forceinline__ void sample_pos(float c, float s, float xj, float xi, float gm1, float& ix, float& iy) {
     const float gx = fmaf(c, xj, s * xi);
     const float gy = fmaf(-s, xj, c * xi);
     ix = ((gx + 1.0f) * 0.5f) * gm1;
     iy = ((gy + 1.0f) * 0.5f) * gm1;
+}
+
+// Parallel beam: the lattice is the rotation of the UNIFORM base grid xn = linspace(-1, 1, G) of affine_grid (radon.py:252-342), so
+// in pixel units the sample of ray j at step i is   (ix, iy) = ctr + R (j - ctr, i - ctr),   ctr = (G - 1) / 2:
+//   ix = fma(s, i - ctr, fma(c, j - ctr, ctr)),   iy = fma(c, i - ctr, fma(-s, j - ctr, ctr))
+// - one fused multiply-add per coordinate and step from a per-ray base (j - ctr and i - ctr are exact), two roundings of at most
+// half an ulp of G each (6e-5 pixel at G = 729), against nine operations per step for the chain above, whose own roundings are of
+// the same size.  Bit-identical in the forward and adjoint kernels of radon.hip and radon_tiled.hip: the adjoint's tap weights
+// are the forward's.  (The base grid is the reference's linspace by construction; the `xn` arguments of the entry points keep
+// their place in the ABI, the parallel-beam kernels do not read them.)
+__device__ __forceinline__ void ray_base(float c, float s, float dj, float ctr, float& bx, float& by) {
+    bx = fmaf(c, dj, ctr);
+    by = fmaf(-s, dj, ctr);
+}
+__device__ __forceinline__ void lattice_pos(float c, float s, float bx, float by, float di, float& ix, float& iy) {
+    ix = fmaf(s, di, bx);
+    iy = fmaf(c, di, by);
 }
 
 // ---- x [n_img, W, W] -> xp [groups][(G+2)][(G+2)][NB], zero ring + zero padding, optional circle mask
@@ -69,25 +86,23 @@ template <int NB>
 __global__ __launch_bounds__(256) void radon_fwd_kernel(RadonGeom g, const float* __restrict__ xp,
                                                         const float* __restrict__ xn, const float2* __restrict__ cs,
                                                         float* __restrict__ sino) {
-    DINV_DYN_LDS(float, xn_s);
-    for (int i = threadIdx.x; i < g.G; i += 256) xn_s[i] = xn[i];
-    __syncthreads();
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int a = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int grp = blockIdx.z;
     if (j >= g.G || a >= g.A) return;
     const float2 t = cs[a];
     const float c = t.x, s = t.y;
-    const float gm1 = (float)(g.G - 1);
+    const float ctr = 0.5f * (float)(g.G - 1);
     const int GP = g.G + 2;
     const float* img = xp + (int64_t)grp * GP * GP * NB;
-    const float xj = xn_s[j];
+    float bx, by;
+    ray_base(c, s, (float)j - ctr, ctr, bx, by);
     float acc[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) acc[k] = 0.f;
     for (int i = 0; i < g.G; ++i) {
         float ix, iy;
-        sample_pos(c, s, xj, xn_s[i], gm1, ix, iy);
+        lattice_pos(c, s, bx, by, (float)i - ctr, ix, iy);
         const float fx = floorf(ix), fy = floorf(iy);
         const float tx = ix - fx, ty = iy - fy;
         int x0 = (int)fx, y0 = (int)fy;
@@ -133,9 +148,7 @@ __global__ __launch_bounds__(256) void radon_adj_kernel(RadonGeom g, const float
                                                         const float* __restrict__ xn, const float2* __restrict__ cs,
                                                         float* __restrict__ x) {
     DINV_DYN_LDS(float, smem);
-    float* xn_s = smem;                                         // G
-    float2* cs_s = reinterpret_cast<float2*>(smem + ((g.G + 1) / 2) * 2);  // A
-    for (int i = threadIdx.x; i < g.G; i += 256) xn_s[i] = xn[i];
+    float2* cs_s = reinterpret_cast<float2*>(smem + ((g.G + 1) / 2) * 2);  // A  (behind the G words the launch still reserves)
     for (int i = threadIdx.x; i < g.A; i += 256) cs_s[i] = cs[i];
     __syncthreads();
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -166,14 +179,15 @@ __global__ __launch_bounds__(256) void radon_adj_kernel(RadonGeom g, const float
             for (int dj = 0; dj < 4; ++dj) {
                 const int j = j0 + dj;
                 if (j < 0 || j >= g.G) continue;
-                const float xj = xn_s[j];
+                float bx, by;
+                ray_base(c, s, (float)j - ctr, ctr, bx, by);
                 float wsum = 0.f;
 #pragma unroll
                 for (int di = 0; di < 4; ++di) {
                     const int i = i0 + di;
                     if (i < 0 || i >= g.G) continue;
                     float ix, iy;
-                    sample_pos(c, s, xj, xn_s[i], gm1, ix, iy);
+                    lattice_pos(c, s, bx, by, (float)i - ctr, ix, iy);
                     const float fx = floorf(ix), fy = floorf(iy);
                     const float tx = ix - fx, ty = iy - fy;
                     const int ex = px - (int)fx, ey = py - (int)fy;  // 0 -> tap weight (1-t), 1 -> t

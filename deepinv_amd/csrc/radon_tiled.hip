@@ -56,12 +56,15 @@ struct TiledGeom {
     float scale;
 };
 
-// identical to radon.hip: sample position (ix -> column, iy -> row) of lattice point (j, i)
-__device__ __forceinline__ void sample_pos(float c, float s, float xj, float xi, float gm1, float& ix, float& iy) {
-    const float gx = fmaf(c, xj, s * xi);
-    const float gy = fmaf(-s, xj, c * xi);
-    ix = ((gx + 1.0f) * 0.5f) * gm1;
-    iy = ((gy + 1.0f) * 0.5f) * gm1;
+// identical to radon.hip (see the note there): sample position (ix -> column, iy -> row) of lattice point (j, i) of the rotated
+// uniform grid, (ix, iy) = ctr + R (j - ctr, i - ctr): a per-ray base and one fused multiply-add per coordinate and step
+__device__ __forceinline__ void ray_base(float c, float s, float dj, float ctr, float& bx, float& by) {
+    bx = fmaf(c, dj, ctr);
+    by = fmaf(-s, dj, ctr);
+}
+__device__ __forceinline__ void lattice_pos(float c, float s, float bx, float by, float di, float& ix, float& iy) {
+    ix = fmaf(s, di, bx);
+    iy = fmaf(c, di, by);
 }
 
 // bilinear weight of integer pixel p for a sample at position t along one axis.  With f = floor(t): p == f gives
@@ -120,12 +123,10 @@ __global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kern
     constexpr int V = Vec<NB>::V, PLANES = Vec<NB>::PLANES;
     using VF = vf<V>;
     DINV_DYN_LDS(float, lds);
-    float* xn_s = lds;
-    float* win = lds + ((g.G + 3) & ~3);
+    float* win = lds + ((g.G + 3) & ~3);      // (the first G words are reserved by the launch and unused)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kw = blockDim.x >> 6, nthr = blockDim.x;
     const int WW = g.WW;
-    for (int i = tid; i < g.G; i += nthr) xn_s[i] = xn[i];
     const int jb = blockIdx.x, ch = chunk_base + blockIdx.y, grp = blockIdx.z;
     const int a = chunk_angles[ch * kw + wv];
     const int dir = chunk_dir[ch];
@@ -137,31 +138,60 @@ __global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kern
                                       : 16 + (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16)));
     const int j = jb * 64 + ray;
     const bool active = a >= 0 && j < g.G;
-    __syncthreads();
-    float c = 0.f, s = 0.f, xj = 0.f;
+    const float ctr = 0.5f * (float)(g.G - 1);
+    float c = 0.f, s = 0.f, bx = 0.f, by = 0.f;
     if (active) {
         const float2 t = cs[a];
-        c = t.x; s = t.y; xj = xn_s[j];
+        c = t.x; s = t.y;
+        ray_base(c, s, (float)j - ctr, ctr, bx, by);
     }
-    const float gm1 = (float)(g.G - 1);
     VF acc[PLANES];
 #pragma unroll
     for (int pl = 0; pl < PLANES; ++pl) acc[pl] = VF(0.f);
-    int i = dir > 0 ? 0 : g.G - 1;
     int u0 = 0, v0 = 0;
     float tu = 0.f, tv = 0.f;
-    float xi_next = 0.f;   // base-grid coordinate of the NEXT step, fetched one step ahead of its use
-    auto eval = [&](float xi) {
+    const float dirf = (float)dir;
+    auto eval = [&](float dcur) {
         float ix, iy;
-        sample_pos(c, s, xj, xi, gm1, ix, iy);
+        lattice_pos(c, s, bx, by, dcur, ix, iy);
         const float fx = floorf(ix), fy = floorf(iy);
         if (SWAP) { u0 = (int)fy; v0 = (int)fx; tu = iy - fy; tv = ix - fx; }
         else      { u0 = (int)fx; v0 = (int)fy; tu = ix - fx; tv = iy - fy; }
     };
+    // The steps of a ray whose upper-left tap lies inside the zero-ringed image, floor(ix), floor(iy) in [-1, G-1], form ONE interval
+    // [ilo, ihi] (a line meets a square in a segment): it is found once per ray - an analytic estimate, widened by a step and
+    // then trimmed with the very test the samples would have failed - and the march runs over that interval only: no range
+    // test, no clamp and no zero-weight sample inside the loop (at 45 degrees a fifth of the lattice lies outside the image).
+    const float gtop = (float)(g.G - 1);
+    auto inside = [&](int ii) {
+        float ix, iy;
+        lattice_pos(c, s, bx, by, (float)ii - ctr, ix, iy);
+        const float fx = floorf(ix), fy = floorf(iy);
+        return fx >= -1.0f && fx <= gtop && fy >= -1.0f && fy <= gtop;
+    };
+    int nleft = 0;               // samples left on this ray
+    float di = 0.f;              // step coordinate i - ctr of the current sample (exact: half-integers)
     if (active) {
-        eval(xn_s[i]);
-        const int in = i + dir;
-        xi_next = xn_s[(unsigned)in < (unsigned)g.G ? in : i];
+        float lo = -ctr, hi = gtop - ctr;                 // in units of i - ctr
+        auto clip = [&](float b, float slope) {           // -1 <= b + slope * d < G
+            if (fabsf(slope) > 1e-12f) {
+                const float t1 = (-1.0f - b) / slope, t2 = ((float)g.G - b) / slope;
+                lo = fmaxf(lo, fminf(t1, t2));
+                hi = fminf(hi, fmaxf(t1, t2));
+            } else if (!(b >= -1.0f && b < (float)g.G)) {
+                hi = lo - 4.0f;                           // parallel to that side and outside: empty
+            }
+        };
+        clip(bx, s);
+        clip(by, c);
+        int ilo = (int)floorf(lo + ctr) - 1, ihi = (int)ceilf(hi + ctr) + 1;
+        ilo = ilo < 0 ? 0 : ilo;
+        ihi = ihi > g.G - 1 ? g.G - 1 : ihi;
+        while (ilo <= ihi && !inside(ilo)) ++ilo;
+        while (ihi >= ilo && !inside(ihi)) --ihi;
+        nleft = ihi >= ilo ? ihi - ilo + 1 : 0;
+        di = (float)(dir > 0 ? ilo : ihi) - ctr;
+        eval(di);
     }
     const int32_t* wt = wtab + ((int64_t)ch * g.njb + jb) * g.nbands;
     const float* img = xp + (int64_t)grp * g.PH * g.PW * NB;
@@ -220,21 +250,16 @@ __global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kern
         __syncthreads();
         if (band + 1 < g.nbands) issue(band + 1);
         if (active) {
-            // one basic block per sample: an out-of-image sample reads a clamped (valid) window address with zero
-            // weights instead of branching, and the position of the NEXT sample is evaluated between the tap reads and
-            // the multiply-adds of the current one, so the two LDS latencies of a step overlap
+            // one basic block per sample; the position of the NEXT sample is evaluated between the tap reads and the multiply-adds
+            // of the current one
             const int vend = band == g.nbands - 1 ? 0x7fffffff : vb + BH;
-            while ((unsigned)i < (unsigned)g.G && v0 < vend) {
-                const bool ok = u0 >= -1 && u0 <= g.G - 1 && v0 >= -1 && v0 <= g.G - 1;
-                int col = u0 - wx0, row = v0 - vb;
+            while (nleft > 0 && v0 < vend) {
+                const int col = u0 - wx0, row = v0 - vb;            // inside the window by construction (the plan; the interval)
 #ifdef DINV_EMU
-                if (ok && (col < 0 || col > ww - 2)) ++dinv_emu_window_misses;   // host emulation only: the plan must cover
+                if (col < 0 || col > ww - 2 || row < 0 || row > BH - 1) ++dinv_emu_window_misses;   // host emulation only
 #endif
-                col = col < 0 ? 0 : (col > WW - 2 ? WW - 2 : col);   // valid samples are inside by construction
-                row = row < 0 ? 0 : (row > BH - 1 ? BH - 1 : row);
-                const float okf = ok ? 1.0f : 0.0f;
-                const float a0 = 1.0f - tu, b0 = (1.0f - tv) * okf, b1 = tv * okf;
-                const float w00 = a0 * b0, w01 = tu * b0, w10 = a0 * b1, w11 = tu * b1;
+                const float a0 = 1.0f - tu, b0 = 1.0f - tv;
+                const float w00 = a0 * b0, w01 = tu * b0, w10 = a0 * tv, w11 = tu * tv;
                 const float* p = win + (row * WW + col) * V;
                 VF t00[PLANES], t01[PLANES], t10[PLANES], t11[PLANES];
 #pragma unroll
@@ -245,12 +270,9 @@ __global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kern
                     t10[pl] = *reinterpret_cast<const VF*>(pp + WW * V);
                     t11[pl] = *reinterpret_cast<const VF*>(pp + WW * V + V);
                 }
-                i += dir;
-                eval(xi_next);
-                {
-                    const int in = i + dir;
-                    xi_next = xn_s[(unsigned)in < (unsigned)g.G ? in : (i < 0 ? 0 : (i > g.G - 1 ? g.G - 1 : i))];
-                }
+                --nleft;
+                di += dirf;
+                eval(di);      // the position of the NEXT sample between the tap reads and the multiply-adds of this one
 #pragma unroll
                 for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
@@ -304,12 +326,10 @@ __global__ __launch_bounds__(256) void radon_adj_tiled_kernel(TiledGeom g, const
     constexpr int V = Vec<NB>::V, PLANES = Vec<NB>::PLANES;
     using VF = vf<V>;
     DINV_DYN_LDS(float, lds);
-    float* xn_s = lds;
-    float* seg = lds + ((g.G + 3) & ~3);                   // [KA][PLANES][JW][V]
+    float* seg = lds + ((g.G + 3) & ~3);                   // [KA][PLANES][JW][V]  (the first G words: reserved by the launch, unused)
     float2* cs_s = reinterpret_cast<float2*>(seg + KA * JW * NB);   // [KA]
     int* jlo_s = reinterpret_cast<int*>(cs_s + KA);        // [KA]
     const int tid = threadIdx.x;
-    for (int i = tid; i < g.G; i += 256) xn_s[i] = xn[i];
     const int col = blockIdx.x * 16 + (tid & 15);
     const int row = blockIdx.y * 16 + (tid >> 4);
     const int grp = blockIdx.z;
@@ -376,25 +396,26 @@ __global__ __launch_bounds__(256) void radon_adj_tiled_kernel(TiledGeom g, const
                 const float ux = c * dx - s * dy + ctr, uy = s * dx + c * dy + ctr;
                 const float w = fabsf(c) + fabsf(s) + 1e-3f;
                 const int jc = (int)ceilf(ux - w), ic = (int)ceilf(uy - w);
-                float xi[3];
+                float dif[3];
                 bool iv[3];
 #pragma unroll
                 for (int di = 0; di < 3; ++di) {
                     const int i = ic + di;
                     iv[di] = (unsigned)i < (unsigned)g.G;
-                    xi[di] = xn_s[iv[di] ? i : 0];
+                    dif[di] = (float)i - ctr;
                 }
                 const int jl = jlo_s[ai];
 #pragma unroll
                 for (int dj = 0; dj < 3; ++dj) {
                     const int j = jc + dj;
                     const bool jv = (unsigned)j < (unsigned)g.G;
-                    const float xj = xn_s[jv ? j : 0];
+                    float bx, by;
+                    ray_base(c, s, (float)j - ctr, ctr, bx, by);
                     float wsum = 0.f;
 #pragma unroll
                     for (int di = 0; di < 3; ++di) {
                         float ix, iy;
-                        sample_pos(c, s, xj, xi[di], gm1, ix, iy);
+                        lattice_pos(c, s, bx, by, dif[di], ix, iy);
                         const float wgt = weight_of(ix, fpx) * weight_of(iy, fpy);
                         wsum += (jv && iv[di]) ? wgt : 0.f;
                     }

@@ -259,8 +259,9 @@ def test_unfolded_pgd_golden(dev):
     loss.backward()
     assert rel_err(rec, d["rec"]) < TOL
     assert abs(float(loss) - float(d["loss"])) / float(d["loss"]) < TOL
-    for n, p in model.named_parameters():
-        assert rel_err(p.grad, d["grad_" + n.replace(".", "_")]) < 1e-3, n
+    worst = max((rel_err(p.grad, d["grad_" + n.replace(".", "_")]), n) for n, p in model.named_parameters())
+    print("unfolded PGD golden: worst gradient error vs the reference:", f"{worst[0]:.2e}", worst[1])      # (pytest -s)
+    assert worst[0] < TOL, worst
 
 
 @pytest.mark.parametrize("circle", [0, 1])

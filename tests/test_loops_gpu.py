@@ -105,8 +105,9 @@ def test_unfolded_pgd_3d_multicoil_autograd(dev):
     lc = (mc(y.cpu(), PhysCPU()) - x.cpu()).pow(2).mean()
     lc.backward()
     assert abs(loss.item() - lc.item()) / lc.item() < 1e-4
-    for (n, p) in mc.named_parameters():
-        assert rel_err(gs[n], p.grad) < 1e-3, n
+    worst = max((rel_err(gs[n], p.grad), n) for (n, p) in mc.named_parameters())
+    print("unfolded PGD (MultiCoilMRI) vs the CPU oracle: worst gradient error:", f"{worst[0]:.2e}", worst[1])      # (pytest -s)
+    assert worst[0] < 1e-4, worst
 
 
 def test_diffpir_superresolution(dev, monkeypatch):

@@ -90,12 +90,16 @@ def test_cfg4_multicoil_3d_12x16x256x256(dev):
     assert rel_err(sub(rec, st), d["rec"]) < TOL
     assert abs(float(loss.detach()) - float(d["loss"])) < TOL * float(d["loss"])
     gp = dict(model.named_parameters())
-    # gradients: an occasional ReLU mask at |z| ~ 1e-7 differs between two fp32 implementations and moves the upstream
-    # gradients by ~1e-4, hence 1e-3 here as in the small-shape golden (test_drunet3d_golden)
+    # gradients at the north_star tolerance (measured on an MI355X: 5.1e-7, 5.9e-7, 2.1e-7 - profiles/r04_gpu_tests.log; the 1e-3
+    # of round 3 was a guess about ReLU-mask flips that this shape does not show)
+    errs = {}
     for name, key in (("init_params_algo.stepsize.0", "grad_stepsize"), ("init_params_algo.g_param.0", "grad_g_param")):
         g_hip, g_ref = float(gp[name].grad), float(d[key])
-        assert abs(g_hip - g_ref) < 1e-3 * abs(g_ref), (name, g_hip, g_ref)
-    assert rel_err(den.m_head.weight.grad.reshape(-1), d["grad_head"]) < 1e-3
+        errs[key] = abs(g_hip - g_ref) / abs(g_ref)
+        assert errs[key] < TOL, (name, g_hip, g_ref)
+    errs["grad_head"] = rel_err(den.m_head.weight.grad.reshape(-1), d["grad_head"])
+    print("cfg4 named gradient errors vs the reference:", {k: f"{v:.2e}" for k, v in errs.items()})      # (pytest -s)
+    assert errs["grad_head"] < TOL
 
 
 def test_cfg5_downsampling_diffpir_256(dev, monkeypatch):
