@@ -11,8 +11,10 @@
 // points x 64 couts x 32 tile positions of accumulators already fill the register file of a CU (8 waves x 144 registers).
 //
 // * Workgroup = 8 waves = 64 couts x 32 tile positions (512 output pixels) x 36 Winograd points; wave (c2, q) owns the
-//   points 9q .. 9q+8 for cout half c2: 9 accumulators.  One workgroup per CU, two waves per SIMD, persistent (one per CU,
-//   walking a contiguous range of the tile order of its XCD; the cout tiles of one position group are neighbours).
+//   point slots 9q .. 9q+8 for cout half c2: 9 accumulators.  The points are stored (packed U, V stage) in an order in which
+//   every wave's nine slots are a full row of the 6x6 transform followed by half a row, so that the same six accumulators
+//   retire first in every wave's epilogue.  One workgroup per CU, two waves per SIMD, persistent (one per CU, walking a
+//   contiguous range of the tile order of its XCD; the cout tiles of one position group are neighbours).
 // * U = G g G^T (fp64 on the host, rounded once) is packed as the MFMA A fragments of exactly the wave that uses them
 //   ([cout/64][cin/8][wave][point 9][lane][channel 4]): every U value is needed by ONE wave, so it never passes through
 //   LDS - each lane loads 16 bytes (4 K steps of one point) straight from L2, three points ahead of their use.
@@ -25,8 +27,9 @@
 //   raw[b+2]; ONE LDS-only barrier per block.  Every filler instruction is pinned between two MFMAs (sched_barrier).
 // * Epilogue: each wave reduces its points to s = M A (a full Winograd row and half a row: 8 values), the four waves of
 //   a cout half exchange s through LDS, all 512 threads finish A^T s (two output columns of four channels each), fused
-//   ReLU / residual, 16-byte stores.  The next tile's first two raw blocks are requested as soon as the accumulators are
-//   dead and land in registers behind the second exchange round.
+//   ReLU / residual (requested after the first exchange round's writes, when six accumulators are dead), 16-byte stores that
+//   cover 1 KB per wave instruction.  The next tile's first two raw blocks are requested as soon as all accumulators are dead
+//   and land in registers behind the second exchange round.  The first block of a tile accumulates onto the constant 0.
 #include "drunet_common.hpp"
 #include <cstdlib>
 #include <type_traits>
