@@ -288,7 +288,11 @@ typedef struct {
 size_t dinv_radon_workspace_bytes(const dinv_radon_desc* d, int32_t adjoint);
 /* x:[n_img,W,W] -> sino:[n_img,G,A].  xn:[G] = linspace(-1,1,G) (affine_grid base grid, fp32);
  * cs:[A][2] = (cos,sin) of the angles in fp32 radians, both built by the host exactly as the
- * reference builds them (radon.py:70-71, 334-341). */
+ * reference builds them (radon.py:70-71, 334-341).
+ * The rotated lattice of that UNIFORM base grid is ctr + R (j - ctr, i - ctr) in pixel units (ctr = (G-1)/2); since ABI
+ * version 6 the parallel-beam kernels (these two entry points and the _tiled ones) evaluate it in that form - one fused
+ * multiply-add per coordinate and step, identical in forward and adjoint - and no longer read `xn` (the argument keeps its
+ * place; dinv_radon_backproject and the fan-beam entry points still use their grids). */
 int dinv_radon_forward(const dinv_radon_desc* d, const float* x, const float* xn, const float* cs,
                        float* sino, void* ws, size_t ws_bytes, dinv_stream_t stream);
 /* exact transpose of dinv_radon_forward: sino:[n_img,G,A] -> x:[n_img,W,W] */
