@@ -315,7 +315,9 @@ __global__ __launch_bounds__(256) void radon_fan_adj_kernel(RadonGeom g, int n_d
                 int dlo = 0, dhi = n_det - 1;
                 if (fabsf(sci) > 1e-20f && n_det > 1) {
                     const float dc = (qy / sci + 1.0f) * 0.5f * dm1;
-                    const float m = reach / fabsf(sci) * 0.5f * dm1 + 1.0f;
+                    // (floor / ceil below already widen the window by up to one detector on each side; the extra 0.01 covers
+                    // the rounding of this inverse map - the candidates are re-tested with the forward's own coordinates)
+                    const float m = reach / fabsf(sci) * 0.5f * dm1 + 0.01f;
                     const float lo = floorf(dc - m), hi = ceilf(dc + m);
                     if (!(hi >= 0.0f && lo <= dm1)) continue;
                     dlo = lo > 0.0f ? (int)lo : 0;

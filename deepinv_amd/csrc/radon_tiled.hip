@@ -184,6 +184,8 @@ __global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kern
         };
         clip(bx, s);
         clip(by, c);
+        lo = fminf(lo, gtop - ctr + 2.0f);                // (a ray far outside: keep the estimate inside the int range)
+        hi = fmaxf(hi, -ctr - 2.0f);
         int ilo = (int)floorf(lo + ctr) - 1, ihi = (int)ceilf(hi + ctr) + 1;
         ilo = ilo < 0 ? 0 : ilo;
         ihi = ihi > g.G - 1 ? g.G - 1 : ihi;
@@ -396,28 +398,25 @@ __global__ __launch_bounds__(256) void radon_adj_tiled_kernel(TiledGeom g, const
                 const float ux = c * dx - s * dy + ctr, uy = s * dx + c * dy + ctr;
                 const float w = fabsf(c) + fabsf(s) + 1e-3f;
                 const int jc = (int)ceilf(ux - w), ic = (int)ceilf(uy - w);
+                // lattice points outside the grid are moved far away instead of being masked: their weights clamp to zero
                 float dif[3];
-                bool iv[3];
 #pragma unroll
                 for (int di = 0; di < 3; ++di) {
                     const int i = ic + di;
-                    iv[di] = (unsigned)i < (unsigned)g.G;
-                    dif[di] = (float)i - ctr;
+                    dif[di] = (unsigned)i < (unsigned)g.G ? (float)i - ctr : 1.0e9f;
                 }
                 const int jl = jlo_s[ai];
 #pragma unroll
                 for (int dj = 0; dj < 3; ++dj) {
                     const int j = jc + dj;
-                    const bool jv = (unsigned)j < (unsigned)g.G;
                     float bx, by;
-                    ray_base(c, s, (float)j - ctr, ctr, bx, by);
+                    ray_base(c, s, (unsigned)j < (unsigned)g.G ? (float)j - ctr : 1.0e9f, ctr, bx, by);
                     float wsum = 0.f;
 #pragma unroll
                     for (int di = 0; di < 3; ++di) {
                         float ix, iy;
                         lattice_pos(c, s, bx, by, dif[di], ix, iy);
-                        const float wgt = weight_of(ix, fpx) * weight_of(iy, fpy);
-                        wsum += (jv && iv[di]) ? wgt : 0.f;
+                        wsum += weight_of(ix, fpx) * weight_of(iy, fpy);
                     }
                     int q = j - jl;
 #ifdef DINV_EMU
