@@ -278,11 +278,15 @@ __global__ __launch_bounds__(256) void radon_fan_adj_kernel(RadonGeom g, int n_d
                                                             const float* __restrict__ xm, const float* __restrict__ sc,
                                                             const float* __restrict__ yd, const float2* __restrict__ cs,
                                                             float* __restrict__ x) {
-    DINV_DYN_LDS(float, tab);      // xm [G], sc [G], yd [n_det]
+    DINV_DYN_LDS(float, tab);      // xm [G], sc [G], 1 / sc [G], yd [n_det]
     float* xm_s = tab;
     float* sc_s = tab + g.G;
-    float* yd_s = tab + 2 * g.G;
-    for (int i = threadIdx.x; i < g.G; i += 256) { xm_s[i] = xm[i]; sc_s[i] = sc[i]; }
+    float* rsc_s = tab + 2 * g.G;  // reciprocal stretch: the candidate window below needs two quotients per (angle, march index)
+    float* yd_s = tab + 3 * g.G;
+    for (int i = threadIdx.x; i < g.G; i += 256) {
+        const float v = sc[i];
+        xm_s[i] = xm[i]; sc_s[i] = v; rsc_s[i] = fabsf(v) > 1e-20f ? 1.0f / v : 0.f;
+    }
     for (int i = threadIdx.x; i < n_det; i += 256) yd_s[i] = yd[i];
     __syncthreads();
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -314,10 +318,11 @@ __global__ __launch_bounds__(256) void radon_fan_adj_kernel(RadonGeom g, int n_d
                 const float sci = sc_s[i], xmi = xm_s[i];
                 int dlo = 0, dhi = n_det - 1;
                 if (fabsf(sci) > 1e-20f && n_det > 1) {
-                    const float dc = (qy / sci + 1.0f) * 0.5f * dm1;
+                    const float rsc = rsc_s[i];
+                    const float dc = (qy * rsc + 1.0f) * 0.5f * dm1;
                     // (floor / ceil below already widen the window by up to one detector on each side; the extra 0.01 covers
                     // the rounding of this inverse map - the candidates are re-tested with the forward's own coordinates)
-                    const float m = reach / fabsf(sci) * 0.5f * dm1 + 0.01f;
+                    const float m = reach * fabsf(rsc) * 0.5f * dm1 + 0.01f;
                     const float lo = floorf(dc - m), hi = ceilf(dc + m);
                     if (!(hi >= 0.0f && lo <= dm1)) continue;
                     dlo = lo > 0.0f ? (int)lo : 0;
@@ -567,7 +572,7 @@ extern "C" int dinv_radon_fan_adjoint(const dinv_radon_desc* d, int32_t n_det, c
     if (g.n_img == 0) return 0;
     DINV_REQUIRE(x && xm && sc && yd && cs && sino && ws, "null pointer");
     DINV_REQUIRE(ws_bytes >= dinv_radon_fan_workspace_bytes(d, n_det, 1), "workspace too small");
-    const size_t lds = (size_t)(2 * g.G + n_det) * sizeof(float);
+    const size_t lds = (size_t)(3 * g.G + n_det) * sizeof(float);
     DINV_REQUIRE(lds <= 64 * 1024, "grid / detector too large for the LDS tables (%zu B)", lds);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* sp = reinterpret_cast<float*>(ws);
