@@ -379,8 +379,10 @@ def other_config_ops(dinv, device, op_row, ops_last, loop_row):
     hqs = dinv.optim.HQS(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den3), stepsize=list(map(float, st30)),
                          g_param=list(map(float, s30)), max_iter=30, early_stop=False,
                          custom_init=lambda yy, p: p.A_dagger(yy, fbp=True))
-    loop_row("FBP + PnP-HQS 30 it (CG prox) + DRUNet(1->1): loop", "cfg3", B, lambda: hqs(y, phys), 30 * 1109.0 * B,
-             unit="images_per_s", precision=den3.conv_precision)
+    for prec in ("fp32", "bf16split"):      # the model default (the reference's arithmetic type), then the throughput setting
+        den3.conv_precision = prec
+        loop_row("FBP + PnP-HQS 30 it (CG prox) + DRUNet(1->1): loop" + ("" if prec == "fp32" else " [bf16split]"), "cfg3", B,
+                 lambda: hqs(y, phys), 30 * 1109.0 * B, unit="images_per_s", precision=prec)
     del phys, y, den3, hqs
     # the same geometry with fan-beam rays (first-generation gather kernels: stated, not tuned)
     fphys = dinv.physics.Tomography(angles=A, img_width=W, circle=False, normalize=False, fan_beam=True, device=device)
@@ -444,8 +446,10 @@ def other_config_ops(dinv, device, op_row, ops_last, loop_row):
                                       noise_model=dinv.physics.GaussianNoise(0.05))
     sampler = dinv.sampling.DiffPIR(den5, dinv.optim.L2(), sigma=0.05, max_iter=100, zeta=0.1, lambda_=7.0, device=device)
     yn = nphys(x)
-    loop_row("DiffPIR 100 steps + DRUNet(3->3): loop", "cfg5", B, lambda: sampler(yn, nphys, seed=0), 100 * 277.6 * B,
-             unit="images_per_s", precision=den5.conv_precision)
+    for prec in ("fp32", "bf16split"):
+        den5.conv_precision = prec
+        loop_row("DiffPIR 100 steps + DRUNet(3->3): loop" + ("" if prec == "fp32" else " [bf16split]"), "cfg5", B,
+                 lambda: sampler(yn, nphys, seed=0), 100 * 277.6 * B, unit="images_per_s", precision=prec)
 
 
 def _pgd_cpu(sd, maps, mask, y, iters):

@@ -26,13 +26,14 @@ from .base import Denoiser
 
 
 # The ONE precision switch of the denoiser: how the 56 ResBlock 3x3 convolutions multiply.
-#   "bf16split": every fp32 operand as two bf16 parts, three products on the bf16 matrix cores, fp32 accumulation
-#                (csrc/drunet_split2d.hip; <= 2^-16 per operand, 2-4e-6 per layer, DRUNet output within 1e-4 of the fp32 path)
 #   "fp32":      fp32 multiplies on the fp32 matrix cores (Winograd F(4x4,3x3) kernel; F(2x2,3x3) / direct kernels for the
-#                shapes it does not take) - the reference's arithmetic type
-# Default for new models: `deepinv_amd.models.drunet.DEFAULT_CONV_PRECISION`; per model: `model.conv_precision = "fp32"`.
+#                shapes it does not take) - the reference's arithmetic type, and the default since round 4
+#   "bf16split": every fp32 operand as two bf16 parts, three products on the bf16 matrix cores, fp32 accumulation
+#                (csrc/drunet_wsplit.hip / drunet_split2d.hip; <= 2^-16 per operand, 4-6e-6 per layer, DRUNet output within 1e-4 of
+#                the fp32 path): the throughput setting, 15-20 % faster per convolution, opt-in
+# Default for new models: `deepinv_amd.models.drunet.DEFAULT_CONV_PRECISION`; per model: `model.conv_precision = "bf16split"`.
 CONV_PRECISIONS = ("bf16split", "fp32")
-DEFAULT_CONV_PRECISION = "bf16split"
+DEFAULT_CONV_PRECISION = "fp32"
 
 
 def _conv_nd(dim):

@@ -203,7 +203,9 @@ class DRUNet3dFunction(torch.autograd.Function):
         if D % 8 or H % 8 or Wd % 8:
             raise ValueError("3-D DRUNet on the HIP kernels needs depth, height and width to be multiples of 8")
         train = any(ctx.needs_input_grad[1:])
-        f32 = train and getattr(model, "train_forward_precision", "fp32") == "fp32"
+        # 3x3x3 convolutions in fp32 arithmetic (csrc/drunet.hip) or as bf16 split products: the training node follows
+        # `train_forward_precision` (ReLU masks identical to an fp32 reference), inference follows `conv_precision`
+        f32 = (getattr(model, "train_forward_precision", "fp32") if train else model.conv_precision) == "fp32"
         global _pool_sig
         if _pool_sig != (dev, B, D, H, Wd):       # buffers of another problem shape would never be reused: free them
             release_buffers()

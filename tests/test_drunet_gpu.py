@@ -407,11 +407,13 @@ def test_drunet_default_precision_matches_oracle(dev):
     model = dinv.models.DRUNet(2, 2, pretrained=None).to(dev)
     model.load_state_dict(sd)
     model.eval()
-    assert model.conv_precision == "bf16split"
+    assert model.conv_precision == "fp32"           # the reference's arithmetic type is the default; "bf16split" is opt-in
     x = torch.rand(2, 2, 64, 96, generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
         out = model(x.to(dev), 0.05)
-    assert rel_err(out, OD.drunet(sd, x, 0.05)) < 1e-4
+        assert rel_err(out, OD.drunet(sd, x, 0.05)) < 1e-5
+        model.conv_precision = "bf16split"
+        assert rel_err(model(x.to(dev), 0.05), OD.drunet(sd, x, 0.05)) < 1e-4
     model.conv_precision = "fp64"
     with pytest.raises(ValueError, match="conv_precision"):
         with torch.no_grad():
@@ -565,8 +567,11 @@ def test_drunet3d_hip_matches_torch_graph(dev, monkeypatch):
     with torch.no_grad():
         with _backend(model, "torch"):
             y_ref = model(x0, sig0)
-        y_inf = model(x0, sig0)            # bf16-split kernels
-    assert rel_err(y_inf, y_ref) < 1e-4
+        y_inf = model(x0, sig0)            # inference at the model's conv_precision (default: fp32 3x3x3 convolutions)
+        model.conv_precision = "bf16split"
+        y_split = model(x0, sig0)          # bf16-split kernels
+        model.conv_precision = "fp32"
+    assert rel_err(y_inf, y_ref) < 1e-5 and rel_err(y_split, y_ref) < 1e-4
 
     def run(mode):
         model.zero_grad()

@@ -298,7 +298,10 @@ def test_drunet3d_golden(dev, monkeypatch):
     assert [n for n, _ in model.named_parameters()] == [str(n) for n in raw["names"]]
     t = lambda k: torch.from_numpy(raw[k]).to(dev)
     with torch.no_grad():
+        assert rel_err(model(t("x"), t("sigma")), t("y")) < TOL          # inference at the default precision (fp32)
+        model.conv_precision = "bf16split"
         assert rel_err(model(t("x"), t("sigma")), t("y")) < TOL          # bf16-split kernels
+        model.conv_precision = "fp32"
     x = t("x").requires_grad_(True)
     sig = t("sigma").requires_grad_(True)
     y = model(x, sig)                                                     # fp32 forward (training node)
