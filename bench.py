@@ -211,9 +211,11 @@ def main():
         kdesc = {"conv3x3_wino4_kernel": "DRUNet 3x3 conv as Winograd F(4x4,3x3), v_mfma_f32_32x32x2_f32",
                  "conv3x3_wino_kernel": "DRUNet 3x3 conv as Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32",
                  "conv3x3_kernel": "DRUNet 3x3 conv, direct, v_mfma_f32_32x32x2_f32"}.get(kname, kname)
-        dtype = ("f32: every multiply and accumulate in fp32 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32); ResBlock convs as "
+        dtype = ("f32: fp32 multiplies and accumulation on the fp32 matrix cores (v_mfma_f32_32x32x2_f32); ResBlock convs as "
                  + ("Winograd F(4x4,3x3)" if kname == "conv3x3_wino4_kernel" else "Winograd F(2x2,3x3)" if kname == "conv3x3_wino_kernel"
-                    else "direct 3x3") + ", U = G g G^T formed in fp64 and rounded once")
+                    else "direct 3x3") + ", U = G g G^T formed in fp64 and rounded once; the three 2x2 stride-2 down convolutions "
+                 "(2 % of the FLOPs) as an exact three-part bf16 operand split with six products and fp32 accumulation = all 24 "
+                 "significand bits of both operands (layer_rel_err_vs_fp64: at the level of the fp32 kernel)")
         # HBM bytes per launch of the dominant kernel: measured by separate rocprofv3 --pmc passes (TCC_EA0_RDREQ x 64 B x 2
         # [gfx950 wide-load correction] + TCC_EA0_WRREQ x 64 B, averaged over the launches of one DRUNet call) and
         # recorded, with the commit and configuration they were taken at, in profiles/pmc_traffic.json
@@ -302,6 +304,26 @@ def layer_errors(device, B=4, H=80, C=256):
     out["bf16x2_direct (conv3x3_split2d_kernel)"] = err(lambda ya: K.conv3x3_split(geo, xa, ws, C, C, ya))
     ww = K.pack_wsplit_weight(w)
     out["bf16x2_winograd_F(2,3) (conv3x3_wsplit_kernel)"] = err(lambda ya: K.conv3x3_wsplit(geo, xa, ww, C, C, ya))
+    # the 2x2 stride-2 convolution between levels 1 and 2 (128 -> 256 channels): fp32 MFMA, three-part bf16 split with six
+    # products (what conv_precision = "fp32" runs), two-part split with three products (conv_precision = "bf16split")
+    C1 = C // 2
+    x1 = torch.randn(B, C1, 2 * H, 2 * H, generator=g).to(device)
+    wd = (torch.randn(C, C1, 2, 2, generator=g) / (2.0 * C1 ** 0.5)).to(device)
+    refd = torch.nn.functional.conv2d(x1.double(), wd.double(), stride=2)
+    gi = K.geom(B, 2 * H, 2 * H)
+    x1a = K.alloc(gi, C1, device)
+    x1a[:, gi.sl:gi.sl + gi.np].view(-1, B, gi.hp, gi.wp, 8)[:, :, 1:2 * H + 1, 1:2 * H + 1] = x1.view(B, -1, 8, 2 * H, 2 * H).permute(1, 0, 3, 4, 2)
+
+    def errd(run):
+        ya = K.alloc(geo, C, device)
+        run(ya)
+        y = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:H + 1].permute(1, 0, 4, 2, 3).reshape(B, C, H, H)
+        return float(f"{float((y.double() - refd).norm() / refd.norm()):.3e}")
+
+    wdf, wd3, wd2 = K.pack_down_weight(wd), K.pack_down_bf16x3_weight(wd), K.pack_down_bf16s_weight(wd)
+    out["down2x2_fp32 (down2x2_kernel)"] = errd(lambda ya: K.down2x2(gi, geo, x1a, wdf, C1, C, ya))
+    out["down2x2_bf16x3_six_products (down2x2_bf16s_kernel<3>)"] = errd(lambda ya: K.down2x2_bf16x3(gi, geo, x1a, wd3, C1, C, ya))
+    out["down2x2_bf16x2 (down2x2_bf16s_kernel<2>)"] = errd(lambda ya: K.down2x2_bf16s(gi, geo, x1a, wd2, C1, C, ya))
     return out
 
 

@@ -1,6 +1,10 @@
 // DRUNet 2x2 stride-2 down / up convolutions on the BF16 matrix cores with the two-part exact operand split (gfx950):
 // x = xh + xl (xh = bf16(x), xl = bf16(x - xh)), a product is ah*bl + al*bh + ah*bh with fp32 accumulation in
 // v_mfma_f32_32x32x16_bf16 - the same arithmetic as the ResBlock 3x3 convolutions (drunet_split2d.hip).
+// The down convolution also exists with a THREE-part split (NPL = 3: x = xh + xm + xl, 24 significand bits = all of an fp32
+// operand; six products ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm, the dropped terms are below 2^-24 of |a||b|): the
+// fp32-equivalent form that the `conv_precision = "fp32"` setting uses in place of the fp32-MFMA kernel of drunet.hip, which
+// is bound by the fp32 matrix pipe (0.60 ms per launch at every level of the headline configuration).
 #include "drunet_common.hpp"
 
 using namespace dinv;
@@ -33,6 +37,22 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// 8 fp32 -> three bf16 planes (high, middle, low parts: x = h + m + l to 24 bits)
+__device__ __forceinline__ void split8x3(const float4& a, const float4& b, uint4& hi, uint4& mi, uint4& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = f2bf(v[e]);
+        const float r1 = v[e] - bf2f(h[e]);          // exact
+        m[e] = f2bf(r1);
+        l[e] = f2bf(r1 - bf2f(m[e]));                // exact difference, rounded once
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    mi = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
 #ifdef DINV_EMU
 __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16& c) {
     emu_bf16x8 av, bv;
@@ -56,16 +76,20 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, cons
 struct DownSArgs {
     Geom gi, go;
     const float* x;    // [cin/8][gi.cs][8]
-    const uint4* w;    // [tap 4][cin/16][plane 2][cblk 2][cout] x (8 bf16)
+    const uint4* w;    // [tap 4][cin/16][plane NPL][cblk 2][cout] x (8 bf16)
     float* y;          // [cout/8][go.cs][8]
     int32_t cin, cout;
     int64_t ntiles, per_xcd;
     DepthMap dm;       // 3-D: output image (half grid) -> input image (full grid) for depth tap dm.dz
 };
 
-template <bool ACC>    // ACC: y += conv (second depth tap of a 2x2x2 convolution)
+// ACC: y += conv (second depth tap of a 2x2x2 convolution).  NPL = 2: two-part split, three products; NPL = 3: three-part split,
+// six products (fp32-equivalent)
+template <bool ACC, int NPL>
 __global__ __launch_bounds__(256) void down2x2_bf16s_kernel(DownSArgs a) {
-    __shared__ uint4 wl[2][256];   // [stage][plane 2][cblk 2][co 64]
+    constexpr int WU = NPL * 128;                  // 16-byte weight units of a K step
+    constexpr int WPT = (WU + 255) / 256;          // ... per thread
+    __shared__ uint4 wl[2][WU];    // [stage][plane NPL][cblk 2][co 64]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     // cout tiles of one pixel tile next to each other on one XCD (they read the same input pixels)
@@ -100,14 +124,17 @@ __global__ __launch_bounds__(256) void down2x2_bf16s_kernel(DownSArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     const int S = a.cin / 16, nsteps = 4 * S;
-    // this thread's weight unit of a K step: plane (tid >> 7), channel block ((tid >> 6) & 1), cout tid & 63
-    const int64_t wunit = (int64_t)(tid >> 6) * a.cout + co0 + (tid & 63);
+    // this thread's weight units of a K step: unit u = tid + 256 k = (plane * 2 + channel block) * 64 + cout
     float4 ba[2], bb[2];
-    uint4 wreg;
+    uint4 wreg[WPT];
     auto issue = [&](int g) {
         const int tap = g / S, s = g - tap * S;
         const int64_t toff = (int64_t)(tap >> 1) * a.gi.wp + (tap & 1);
-        wreg = a.w[(int64_t)g * 4 * a.cout + wunit];
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const int u = tid + 256 * k;
+            if (u < WU) wreg[k] = a.w[((int64_t)g * (2 * NPL) + (u >> 6)) * a.cout + co0 + (u & 63)];
+        }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const float* xb = a.x + ((int64_t)(2 * s + lhi) * a.gi.cs + ioff[n] + toff) * 8;
@@ -115,33 +142,42 @@ __global__ __launch_bounds__(256) void down2x2_bf16s_kernel(DownSArgs a) {
             bb[n] = ld4(xb + 4);
         }
     };
+    uint4 Bp[NPL][2];     // [plane: high, (middle,) low][n]
+    auto commit = [&](int stage) {
+#pragma unroll
+        for (int k = 0; k < WPT; ++k)
+            if (tid + 256 * k < WU) wl[stage][tid + 256 * k] = wreg[k];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if constexpr (NPL == 2) split8(ba[n], bb[n], Bp[0][n], Bp[1][n]);
+            else split8x3(ba[n], bb[n], Bp[0][n], Bp[1][n], Bp[2][n]);
+        }
+    };
     issue(0);
-    wl[0][tid] = wreg;
-    uint4 Bh[2], Bl[2];
-    split8(ba[0], bb[0], Bh[0], Bl[0]);
-    split8(ba[1], bb[1], Bh[1], Bl[1]);
+    commit(0);
     if (nsteps > 1) issue(1);
     __syncthreads();
+    // products (plane of a, plane of b), smallest terms first; product-major: consecutive MFMAs hit different accumulators
+    constexpr int NPROD = NPL == 2 ? 3 : 6;
+    constexpr int PA[6] = {0, 1, 0, 0, 1, 0}, PB2[3] = {1, 0, 0};               // NPL = 2: ah*bl, al*bh, ah*bh
+    constexpr int QA[6] = {1, 0, 2, 0, 1, 0}, QB[6] = {1, 2, 0, 1, 0, 0};       // NPL = 3: am*bm, ah*bl, al*bh, ah*bm, am*bh, ah*bh
     for (int g = 0; g < nsteps; ++g) {
         const uint4* ws = wl[g & 1];
-        uint4 A[2][2];   // [plane][m]
+        uint4 A[NPL][2];   // [plane][m]
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int m = 0; m < 2; ++m) A[pl][m] = ws[pl * 128 + lhi * 64 + m * 32 + l31];
-        // smallest terms first (ah*bl, al*bh, ah*bh), product-major: consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            const int pa = e == 1 ? 1 : 0;
+        for (int e = 0; e < NPROD; ++e) {
+            const int pa = NPL == 2 ? PA[e] : QA[e], pb = NPL == 2 ? PB2[e] : QB[e];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(A[pa][m], e == 0 ? Bl[n] : Bh[n], acc[m][n]);
+                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(A[pa][m], Bp[pb][n], acc[m][n]);
         }
         if (g + 1 < nsteps) {   // registers hold step g+1 (loaded one iteration ago)
-            wl[(g + 1) & 1][tid] = wreg;
-            split8(ba[0], bb[0], Bh[0], Bl[0]);
-            split8(ba[1], bb[1], Bh[1], Bl[1]);
+            commit((g + 1) & 1);
             if (g + 2 < nsteps) issue(g + 2);
         }
         lds_barrier();
@@ -287,7 +323,8 @@ __global__ __launch_bounds__(256) void up2x2_bf16s_kernel(UpSArgs a) {
 }  // namespace
 
 static int down2x2_bf16s_launch(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const void* w_split,
-                                int32_t cin, int32_t cout, float* y, DepthMap dm, int accumulate, dinv_stream_t stream) {
+                                int32_t cin, int32_t cout, float* y, DepthMap dm, int accumulate, dinv_stream_t stream,
+                                int planes = 2) {
     if (int e = check_geom(gin)) return e;
     if (int e = check_geom(gout)) return e;
     DINV_REQUIRE(x && w_split && y, "null tensor pointer");
@@ -303,8 +340,9 @@ static int down2x2_bf16s_launch(const dinv_act_geom* gin, const dinv_act_geom* g
     a.per_xcd = ceil_div(a.ntiles, 8);
     const dim3 grid((unsigned)(a.per_xcd * 8));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (accumulate) hipLaunchKernelGGL(down2x2_bf16s_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(down2x2_bf16s_kernel<false>, grid, dim3(256), 0, st, a);
+    if (planes == 3) hipLaunchKernelGGL((down2x2_bf16s_kernel<false, 3>), grid, dim3(256), 0, st, a);
+    else if (accumulate) hipLaunchKernelGGL((down2x2_bf16s_kernel<true, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((down2x2_bf16s_kernel<false, 2>), grid, dim3(256), 0, st, a);
     DINV_CHECK_LAUNCH();
     return 0;
 }
@@ -312,6 +350,11 @@ static int down2x2_bf16s_launch(const dinv_act_geom* gin, const dinv_act_geom* g
 extern "C" int dinv_conv_down2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                                        const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream) {
     return down2x2_bf16s_launch(gin, gout, x, w_split, cin, cout, y, DepthMap{0, 0, 0}, 0, stream);
+}
+
+extern "C" int dinv_conv_down2x2_bf16x3(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
+                                        const void* w_split3, int32_t cin, int32_t cout, float* y, dinv_stream_t stream) {
+    return down2x2_bf16s_launch(gin, gout, x, w_split3, cin, cout, y, DepthMap{0, 0, 0}, 0, stream, 3);
 }
 
 extern "C" int dinv_conv_down2x2_bf16s_3d(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,

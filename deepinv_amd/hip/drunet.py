@@ -45,6 +45,7 @@ def _l():
         l.dinv_conv3x3x3.argtypes = [G, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp]
         l.dinv_conv_down2x2.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_down2x2_bf16s.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
+        l.dinv_conv_down2x2_bf16x3.argtypes = [G, G, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_up2x2_bf16s.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
         l.dinv_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
         l.dinv_conv_wgrad_workspace_bytes.argtypes = [G, i32, i32, i32]
@@ -208,6 +209,21 @@ def pack_down_bf16s_weight(w: torch.Tensor) -> torch.Tensor:
     hi = w.bfloat16()
     lo = (w - hi.float()).bfloat16()
     planes = torch.stack((hi, lo)).reshape(2, cout, cin // 16, 2, 8, 2, 2)        # pl, co, s, cblk, ci, dy, dx
+    return planes.permute(5, 6, 2, 0, 3, 1, 4).contiguous()                       # dy, dx, s, pl, cblk, co, ci
+
+
+def pack_down_bf16x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d k2 s2 weight [Cout,Cin,2,2] -> THREE-part bf16 split (hi, mid, lo: 24 significand bits) packed
+    [tap=dy*2+dx][Cin/16][plane 3][cblk 2][Cout][ci 8] for dinv_conv_down2x2_bf16x3 (six products: fp32-equivalent)"""
+    cout, cin = w.shape[:2]
+    if cin % 16 or cout % 64:
+        raise ValueError(f"bf16x3 down packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
+    w = w.detach().float()
+    hi = w.bfloat16()
+    r1 = w - hi.float()
+    mid = r1.bfloat16()
+    lo = (r1 - mid.float()).bfloat16()
+    planes = torch.stack((hi, mid, lo)).reshape(3, cout, cin // 16, 2, 8, 2, 2)   # pl, co, s, cblk, ci, dy, dx
     return planes.permute(5, 6, 2, 0, 3, 1, 4).contiguous()                       # dy, dx, s, pl, cblk, co, ci
 
 
@@ -447,6 +463,13 @@ def down2x2_bf16s(gi, go, x, wsplit, cin, cout, y):
     """the same 2x2 stride-2 convolution on the bf16 matrix cores (weights from pack_down_bf16s_weight)"""
     check(_l().dinv_conv_down2x2_bf16s(ctypes.byref(gi), ctypes.byref(go), ptr(x), ptr(wsplit), cin, cout, ptr(y),
                                        stream_ptr(y.device)))
+
+
+def down2x2_bf16x3(gi, go, x, wsplit3, cin, cout, y):
+    """the same 2x2 stride-2 convolution with the three-part operand split and six products: fp32-equivalent
+    (weights from pack_down_bf16x3_weight)"""
+    check(_l().dinv_conv_down2x2_bf16x3(ctypes.byref(gi), ctypes.byref(go), ptr(x), ptr(wsplit3), cin, cout, ptr(y),
+                                        stream_ptr(y.device)))
 
 
 def up2x2_bf16s(gi, go, x, x2, wsplit, cin, cout, y):

@@ -229,7 +229,10 @@ class DRUNet(Denoiser):
             e[name] = [(c3(b.res[0]), c3(b.res[2])) for b in list(seq)[:-1]]
             wd = seq[-1].weight.to(device)
             e[name + "_s"] = K.pack_down_weight(wd)
-            e[name + "_sb"] = K.pack_down_bf16s_weight(wd) if (split and wd.shape[0] % 64 == 0 and wd.shape[1] % 16 == 0) else None
+            okd = wd.shape[0] % 64 == 0 and wd.shape[1] % 16 == 0
+            e[name + "_sb"] = K.pack_down_bf16s_weight(wd) if (split and okd) else None
+            # fp32 setting: three-part bf16 split, six products (fp32-equivalent; the fp32-MFMA kernel is bound by that pipe)
+            e[name + "_s3"] = K.pack_down_bf16x3_weight(wd) if (not split and okd) else None
         body = [self.m_body] if isinstance(self.m_body, ResBlock) else list(self.m_body)
         e["m_body"] = [(c3(b.res[0]), c3(b.res[2])) for b in body]
         for name in ("m_up3", "m_up2", "m_up1"):
@@ -323,6 +326,8 @@ class DRUNet(Denoiser):
             r = self._res_chain(g[i], e[name], nc[i], cur, ws[f"a{i}"], ws[f"b{i}"], ws[f"t{i}"])
             if e[name + "_sb"] is not None:   # same arithmetic as the ResBlock convs
                 K.down2x2_bf16s(g[i], g[i + 1], r, e[name + "_sb"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])   # x2, x3, x4
+            elif e[name + "_s3"] is not None:
+                K.down2x2_bf16x3(g[i], g[i + 1], r, e[name + "_s3"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])
             else:
                 K.down2x2(g[i], g[i + 1], r, e[name + "_s"], nc[i], nc[i + 1], ws[f"skip{i + 1}"])
             cur = ws[f"skip{i + 1}"]

@@ -221,6 +221,13 @@ int dinv_conv3x3x3_split(const dinv_act_geom* g, const void* x, const void* w_sp
  * dinv_conv_down2x2 (fp32 pipe). */
 int dinv_conv_down2x2_bf16s(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x,
                             const void* w_split, int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
+/* The same stride-2 convolution with a THREE-part bf16 operand split (x = xh + xm + xl: all 24 significand bits of an fp32 operand)
+ * and six products (ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm; the dropped terms are below 2^-24 |a||b|), fp32 accumulation:
+ * the fp32-equivalent form used by `conv_precision = "fp32"` (the fp32-MFMA kernel dinv_conv_down2x2 is bound by that pipe).
+ * w_split3: [tap 4][cin/16][plane 3][cblk 2][cout][8] bf16 (deepinv_amd/hip/drunet.py: pack_down_bf16x3_weight);
+ * cin % 16 == 0, cout % 64 == 0. */
+int dinv_conv_down2x2_bf16x3(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const void* w_split3,
+                             int32_t cin, int32_t cout, float* y, dinv_stream_t stream);
 
 /* 2x2 stride-2 transposed convolution (upsample_convtranspose, drunet.py:493-521) of x (+ x2, the U-Net skip add) on
  * the bf16 matrix cores; w_split: [Cin/16][tap = dy*2+dx][plane hi/lo][cblk 2][Cout][ci 8] bf16.  Same operator as

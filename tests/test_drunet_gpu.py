@@ -193,6 +193,32 @@ def test_tail_conv_lane_shift(dev, B, H, W, cin, cout, skip):
     assert float(yv[0, :, H + 1:].min()) == 7.0
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 24, 16, 64), (3, 40, 40, 64, 128), (1, 64, 64, 256, 512), (32, 80, 80, 128, 256)])
+def test_bf16x3_down2x2_is_fp32_equivalent(dev, B, H, W, cin, cout):
+    """dinv_conv_down2x2_bf16x3 (three-part bf16 operand split, six products: the stride-2 layers of conv_precision = "fp32")
+    against an fp64 convolution: at the level of the fp32-MFMA kernel it replaces (asserted < 1e-6 and within 3x of that
+    kernel's own error; the two-part kernel of the bf16split setting sits at 3e-6)"""
+    from deepinv_amd.hip import drunet as K
+
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 2, 2, generator=g) / (2.0 * cin ** 0.5)).to(dev)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=2)
+    gi, go = K.geom(B, H, W), K.geom(B, H // 2, W // 2)
+    xa = K.alloc(gi, cin, dev)
+    xa[:, gi.sl:gi.sl + gi.np].view(-1, B, gi.hp, gi.wp, 8)[:, :, 1:H + 1, 1:W + 1] = x.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+
+    def run(fn, pack):
+        ya = K.alloc(go, cout, dev)
+        fn(gi, go, xa, pack(w), cin, cout, ya)
+        return ya[:, go.sl:go.sl + go.np].view(-1, B, go.hp, go.wp, 8)[:, :, 1:H // 2 + 1, 1:W // 2 + 1].permute(1, 0, 4, 2, 3).reshape(ref.shape)
+
+    e3 = rel_err(run(K.down2x2_bf16x3, K.pack_down_bf16x3_weight), ref)
+    e32 = rel_err(run(K.down2x2, K.pack_down_weight), ref)
+    e2 = rel_err(run(K.down2x2_bf16s, K.pack_down_bf16s_weight), ref)
+    assert e3 < 1e-6 and e3 < 3 * e32 + 1e-7 and e2 > 3 * e3, (e3, e32, e2)
+
+
 def test_winograd4_conv_rejects_unsupported_shapes(dev):
     from deepinv_amd.hip import drunet as K
 

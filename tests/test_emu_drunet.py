@@ -286,6 +286,41 @@ def test_bf16_split_down2x2_matches_fp64(B, H, W, cin, cout):
     assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(1, 8, 12, 16, 64), (2, 10, 6, 32, 128), (3, 16, 16, 64, 64), (1, 4, 36, 128, 64)])
+def test_bf16x3_down2x2_is_fp32_equivalent(B, H, W, cin, cout):
+    """dinv_conv_down2x2_bf16x3: three-part operand split, six products (the stride-2 layers of conv_precision = "fp32").  Against an
+    fp64 convolution it must sit at the level of fp32 arithmetic itself: measured 1.5e-7 ... 4.1e-7 where PyTorch's fp32 conv2d
+    has 1.0e-7 ... 1.5e-7 on the same operands (operands carried to 24 bits, the three dropped cross terms are 2^-24 each, the
+    accumulator is rounded once per 16-term MFMA and product) - the two-part kernel of the bf16split setting: 3e-6, the F(4x4)
+    ResBlock kernel of the same setting: 3e-6.  Asserted: below 1e-6 and within 4x of the fp32 conv2d"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepinv_amd.hip.drunet import pack_down_bf16x3_weight
+
+    gen = torch.Generator().manual_seed(H * W + cin)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, 2, 2, generator=gen) / (2.0 * cin ** 0.5)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=2)
+    gi, go = geom(B, H, W), geom(B, H // 2, W // 2)
+    xa = to_act(x, gi)
+    ya = torch.full((cout // 8, go.cs, 8), float("nan"))
+    ya[:, :go.sl] = 0
+    wp = pack_down_bf16x3_weight(w)
+    hi, mid, lo = (wp[:, :, :, k].float() for k in range(3))
+    back = (hi.double() + mid.double() + lo.double()).permute(4, 2, 3, 5, 0, 1).reshape(cout, cin, 2, 2)    # co, (s, cblk, ci), dy, dx
+    assert float((back - w.double()).abs().max() / w.abs().max()) < 2 ** -23          # the three planes carry the fp32 weight
+    l = E.lib()
+    E.check(l.dinv_conv_down2x2_bf16x3(ctypes.byref(gi), ctypes.byref(go), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout,
+                                       E.p(ya), None))
+    out = from_act(ya, go, cout)
+    assert not torch.isnan(out).any()
+    err = float((out.double() - ref).norm() / ref.norm())
+    err32 = float((torch.nn.functional.conv2d(x, w, stride=2).double() - ref).norm() / ref.norm())
+    assert err < 1e-6 and err < 4 * err32 + 1e-7, (err, err32)
+    full = ya[:, go.sl:go.sl + go.np].view(-1, B, go.hp, go.wp, 8)       # the zero frame of the output is written as zeros
+    assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, :, 0].abs().max()) == 0
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,skip", [(1, 5, 7, 16, 64, False), (2, 6, 4, 32, 128, True), (3, 8, 8, 64, 64, True)])
 def test_bf16_split_up2x2_matches_fp64(B, H, W, cin, cout, skip):
     """2x2 stride-2 transposed convolution of drunet_bf16s.hip (upsample_convtranspose, drunet.py:493-521), input = x (+ x2)"""
