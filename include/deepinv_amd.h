@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 6 = this header (5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 6 = this header (adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
