@@ -151,3 +151,38 @@ def test_res_block_dispatch_even_and_odd_widths(monkeypatch):
     none = ((None, 64, 64), None, None, None, None)
     model._res_block(types.SimpleNamespace(width=40), none, none, x, t, y)
     assert calls == [("fp32", True, False), ("fp32", False, True)]
+
+
+def test_sigma_operand_forms_and_shape_checks():
+    """DRUNet.forward hands the noise level to the pack kernel as it came (float / per-sample values / map) instead of building
+    the concatenated noise-map channel of drunet.py:226-249; the shape checks are the reference's"""
+    import deepinv_amd as dinv
+
+    m = dinv.models.DRUNet(2, 2, nc=(8, 8, 8, 8), nb=1, pretrained=None)
+    x = torch.zeros(3, 2, 32, 40)
+    assert m._sigma_operand(x, 0.1) == pytest.approx(0.1) and isinstance(m._sigma_operand(x, 0.1), float)
+    assert isinstance(m._sigma_operand(x, torch.tensor(0.2)), float)                      # 0-dim host tensor: a scalar
+    assert isinstance(m._sigma_operand(x, torch.tensor([0.2])), float)
+    per = torch.tensor([0.1, 0.2, 0.3])
+    assert m._sigma_operand(x, per) is per and m._sigma_operand(x, per.view(3, 1, 1, 1)).shape == (3, 1, 1, 1)
+    smap = torch.rand(3, 1, 32, 40)
+    assert m._sigma_operand(x, smap) is smap
+    for bad in (torch.rand(2), torch.rand(3, 1, 32, 41), torch.rand(3, 2, 32, 40)):
+        with pytest.raises(ValueError, match="Incorrect shape"):
+            m._sigma_operand(x, bad)
+    # the same map the reference would have concatenated
+    assert torch.equal(m._noise_map(x, per)[:, 0, 0, 0], per) and m._noise_map(x, 0.1).shape == (3, 1, 32, 40)
+
+
+def test_bf16x3_pack_carries_all_24_bits():
+    """pack_down_bf16x3_weight: hi + mid + lo reproduces the fp32 weight to its last bit (the six-product stride-2 convolution of
+    the fp32 setting multiplies full fp32 operands)"""
+    from deepinv_amd.hip.drunet import pack_down_bf16x3_weight
+
+    w = torch.randn(64, 32, 2, 2, generator=torch.Generator().manual_seed(3))
+    p = pack_down_bf16x3_weight(w)                      # dy, dx, s, plane, cblk, co, ci
+    assert p.shape == (2, 2, 2, 3, 2, 64, 8) and p.dtype == torch.bfloat16
+    back = (p[:, :, :, 0].double() + p[:, :, :, 1].double() + p[:, :, :, 2].double()).permute(4, 2, 3, 5, 0, 1).reshape(64, 32, 2, 2)
+    assert float((back - w.double()).abs().max()) <= float(w.abs().max()) * 2.0 ** -24
+    with pytest.raises(ValueError):
+        pack_down_bf16x3_weight(torch.zeros(64, 24, 2, 2))
