@@ -211,8 +211,15 @@ struct UpSArgs {
     DepthMap dm;       // 3-D: input image (half grid) -> output image (full grid) for depth tap dm.dz
 };
 
+#ifdef DINV_EMU
+#define DINV_BF16S_UP_ATTR
+#else
+#define DINV_BF16S_UP_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 template <bool SKIP>
-__global__ __launch_bounds__(256) void up2x2_bf16s_kernel(UpSArgs a) {
+// (waves_per_eu(2, 2): with the default bounds the compiler keeps the 128 accumulator registers in AGPRs and spills 80 bytes per lane of
+// MFMA temporaries to scratch; told that two waves per SIMD is all there will be, it allocates 222 unified registers and no scratch)
+__global__ __launch_bounds__(256) DINV_BF16S_UP_ATTR void up2x2_bf16s_kernel(UpSArgs a) {
     __shared__ uint4 wl[2][1024];   // [stage][tap 4][plane 2][cblk 2][co 64]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
