@@ -1,5 +1,5 @@
 #!/bin/bash
-# twenty-sixth hardware run: rocprofv3 kernel statistics of the bench command at the final code
+# rocprofv3 kernel statistics of the bench command at the final code
 cd $GRAFT_REPO_ROOT
 R=gpurun_out
 mkdir -p $R

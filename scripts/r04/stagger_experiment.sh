@@ -1,5 +1,5 @@
 #!/bin/bash
-# sixteenth hardware run (experiment, timing build only): do the workgroups of a launch run their epilogues in lock step and saturate
+# experiment, timing build only: do the workgroups of a launch run their epilogues in lock step and saturate
 # HBM in bursts?  Workgroup j of an XCD starts (j % 4) / 4 of a tile late (DINV_W4_STAGGER cycles per tile); per-phase stamps of
 # tiles 1-2 and the launch time with and without the stagger
 cd $GRAFT_REPO_ROOT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# twenty-fifth hardware run (final code, after the six-product down convolution): the whole GPU suite, smoke, the bench line (loops of configs 3 and 5 in
+# validation batch of the round (ran on the final code): the whole GPU suite, smoke, the bench line (loops of configs 3 and 5 in
 # both precision settings)
 cd $GRAFT_REPO_ROOT
 R=gpurun_out

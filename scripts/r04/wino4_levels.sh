@@ -1,6 +1,6 @@
 #!/bin/bash
-# eleventh hardware run: F(4x4) kernel with permuted point slots (same six accumulators retire first in every wave), residual
-# requested after the first exchange round, first block of a tile accumulating onto the constant 0
+# the F(4x4) kernel per DRUNet level through the C-ABI harness (scripts/r04/wino4_bench.cpp; build lines in its header): correctness
+# against F(2x2) and sampled fp64, ms per launch at B = 32 and B = 4, per-phase cycle stamps of the -DDINV_W4_TIMING build
 cd $GRAFT_REPO_ROOT
 export LD_LIBRARY_PATH=$PWD/deepinv_amd:$LD_LIBRARY_PATH
 R=gpurun_out
