@@ -291,6 +291,42 @@ def test_diffpir_schedule_matches_reference_golden():
             assert torch.allclose(s.reduced_alpha_cumprod, d["reduced"], rtol=1e-7)
 
 
+@pytest.mark.parametrize("kw", [dict(sigma=0.05, max_iter=6, lambda_=7.0), dict(sigma=0.1, max_iter=30, lambda_=3.0),
+                                dict(sigma=0.02, max_iter=100, lambda_=7.0)])
+def test_diffpir_host_schedule_equals_the_per_step_lookups(kw):
+    """DiffPIR._host_schedule (the per-step scalars, evaluated once per call) against the reference's per-step tensor look-ups
+    (diffusion.py:452-507) on the same schedule tensors: identical time steps, scalars equal to fp32 rounding, and the fused
+    update x <- cx x + cx0 (2 x0_p - 1) + cn n equal to the reference's three-line form"""
+    zeta = 0.1
+    s = dinv.sampling.DiffPIR(None, None, zeta=zeta, device="cpu", **kw)
+    steps = s._host_schedule()
+    sr, _ = s.get_alpha_prod()
+    n = len(s.seq)
+    assert len(steps) == n and steps[-1]["last"]
+    g = torch.Generator().manual_seed(0)
+    for i, st in enumerate(steps):
+        cs = s.sigmas[s.seq[i]]
+        t_i = s.find_nearest(s.reduced_alpha_cumprod, cs)
+        at = 1 / sr[t_i] ** 2
+        assert st["sigma_den"] == pytest.approx(float(cs / 2), rel=1e-7)
+        assert st["pre_scale"] == pytest.approx(float(1 / (2 * at.sqrt())), rel=1e-6)
+        assert st["last"] == bool(s.seq[i] == s.seq[-1])
+        if i == 0:
+            assert st["init_noise"] == pytest.approx(float((cs ** 2 - 4.0 * kw["sigma"] ** 2).sqrt()), rel=1e-6)
+            assert st["init_div"] == pytest.approx(float(sr[-1]), rel=1e-7)
+        if st["last"]:
+            continue
+        assert st["gamma"] == pytest.approx(float(1.0 / (2 * s.rhos[t_i])), rel=1e-6)
+        t_im1 = s.find_nearest(s.reduced_alpha_cumprod, s.sigmas[s.seq[i + 1]])
+        x, x0p, nz = (torch.randn(5, generator=g).double() for _ in range(3))
+        x0 = x0p * 2 - 1
+        eps = (x - s.sqrt_alphas_cumprod[t_i].double() * x0) / s.sqrt_1m_alphas_cumprod[t_i].double()
+        ref = (s.sqrt_alphas_cumprod[t_im1].double() * x0 + s.sqrt_1m_alphas_cumprod[t_im1].double() * (1 - zeta) ** 0.5 * eps
+               + s.sqrt_1m_alphas_cumprod[t_im1].double() * zeta ** 0.5 * nz)
+        fused = st["cx"] * x + 2.0 * st["cx0"] * x0p + st["cn"] * nz - st["cx0"]
+        assert torch.allclose(fused, ref, rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("solver", ["CG", "BiCGStab", "lsqr", "minres"])
 def test_least_squares_solvers_match_reference_golden(solver):
     """least_squares(solver=...) (least_squares.py:15-197, lsqr.py, bicgstab.py, minres.py) against outputs of the REAL
