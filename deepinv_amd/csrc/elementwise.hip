@@ -18,7 +18,9 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // out = clamp(a*x + b*y + c*z + d, lo, hi)   (y, z optional; lo = -inf, hi = +inf: no clamp)
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// (torch.clamp propagates NaN; fminf / fmaxf return the non-NaN operand, so a NaN is passed through explicitly: a diverged
+// iterate must not turn into a finite-looking -inf / 0)
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
 __global__ __launch_bounds__(256) void lincomb_kernel(int64_t n, float a, const float* __restrict__ x, float b,
                                                       const float* __restrict__ y, float c,
                                                       const float* __restrict__ z, float d, float lo, float hi,

@@ -39,6 +39,21 @@ def test_affine_clamp(dev, shape):
     assert rel_err(ew.affine(0.3, x, d=0.5), x * 0.3 + 0.5) < 1e-6
 
 
+def test_lincomb_and_affine_propagate_nan(dev):
+    """NaN in -> NaN out, as torch.clamp and the reference's plain arithmetic do (fminf / fmaxf drop NaN)"""
+    from deepinv_amd.hip import elementwise as ew
+
+    x = torch.randn(4, 2, 33, 35, generator=torch.Generator().manual_seed(2))
+    x.view(-1)[::97] = float("nan")
+    x = x.to(dev)
+    y = torch.ones_like(x)
+    o = ew.lincomb(1.0, x, -1.0, y)
+    assert torch.equal(torch.isnan(o), torch.isnan(x)) and torch.equal(o[~torch.isnan(o)], (x - y)[~torch.isnan(x)])
+    o = ew.affine(1.0, x, lo=0.0, hi=1.0)
+    ref = x.clamp(0, 1)
+    assert torch.equal(torch.isnan(o), torch.isnan(ref)) and torch.equal(o[~torch.isnan(o)], ref[~torch.isnan(ref)])
+
+
 def test_cg_fast_path_matches_oracle_cg(dev):
     import deepinv_amd as dinv
 

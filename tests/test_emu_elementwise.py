@@ -64,6 +64,21 @@ def test_affine_clamp(n):
     assert torch.allclose(EmuEw().lincomb(0.5, x, -1.25, y, 2.0, z), 0.5 * x - 1.25 * y + 2.0 * z, atol=1e-6)
 
 
+def test_lincomb_and_affine_propagate_nan():
+    """torch.clamp / plain arithmetic in the reference propagate NaN (a diverged iterate stays visibly diverged): so must the
+    fused kernel, although fminf / fmaxf alone would return the non-NaN bound"""
+    l = E.lib()
+    f, i64 = ctypes.c_float, ctypes.c_int64
+    x = torch.tensor([0.5, float("nan"), -2.0, float("nan"), 3.0, float("nan"), 0.25])
+    y = torch.ones(7)
+    out = torch.empty(7)
+    o = EmuEw().lincomb(1.0, x, -1.0, y)
+    assert torch.equal(torch.isnan(o), torch.isnan(x)) and torch.equal(o[~torch.isnan(o)], (x - y)[~torch.isnan(x)])
+    E.check(l.dinv_affine(i64(7), f(1.0), E.p(x), f(0.0), None, f(0.0), None, f(0.0), f(0.0), f(1.0), E.p(out), None))
+    ref = x.clamp(0, 1)
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.equal(out[~torch.isnan(out)], ref[~torch.isnan(ref)])
+
+
 @pytest.mark.parametrize("check_every", [1, 4, 1000])
 def test_cg_with_device_side_convergence_matches_reference_cg(check_every, monkeypatch):
     """however rarely the host looks at the flag (every iteration, every 4th, never before max_iter), the iterate is
