@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "fft_static.hpp"
+#include "fft_wave.hpp"
 
 namespace dinv {
 
@@ -46,6 +47,23 @@ struct C2CIo {
     static constexpr bool has_vec4 = true;
     __device__ __forceinline__ void load4(const RowCtx& c, int n0, float2 (&v)[4]) const { ld_c4(in + c.base + n0, v); }
     __device__ __forceinline__ void store4(const RowCtx& c, int k0, const float2 (&v)[4]) const { st_c4(out + c.base + k0, v); }
+    // wave-autonomous rows pass (fft_wave.hpp): a tile's base pointers are wave-uniform (scalar registers), lanes add a
+    // 32-bit element offset; loads are left in flight as raw registers and finished at their first use
+    struct Raw4 { float4 a, b; };
+    struct TileCtx { const float2* in; float2* out; };
+    __host__ bool wave_rows_ok(int, int64_t) const { return true; }     // rows are independent: any tile of consecutive rows
+    __device__ __forceinline__ TileCtx tile_ctx(int64_t line0) const { return TileCtx{in + line0 * n_, out + line0 * n_}; }
+    __device__ __forceinline__ void load4_raw(const TileCtx& c, unsigned off, Raw4& r) const {
+        r.a = reinterpret_cast<const float4*>(c.in + off)[0];
+        r.b = reinterpret_cast<const float4*>(c.in + off)[1];
+    }
+    struct Mask4 {};
+    __device__ __forceinline__ bool has_mask() const { return false; }
+    __device__ __forceinline__ void load_mask4(const TileCtx&, unsigned, Mask4&) const {}
+    __device__ __forceinline__ void unpack4(const Raw4& r, const Mask4&, float2 (&v)[4]) const {
+        v[0] = make_float2(r.a.x, r.a.y); v[1] = make_float2(r.a.z, r.a.w); v[2] = make_float2(r.b.x, r.b.y); v[3] = make_float2(r.b.z, r.b.w);
+    }
+    __device__ __forceinline__ void store4(const TileCtx& c, unsigned off, const float2 (&v)[4]) const { st_c4(c.out + off, v); }
     __device__ __forceinline__ ColCtx col_ctx(int64_t p, int64_t q) const { return ColCtx{p * n_ * q_ + q, q_}; }
     __device__ __forceinline__ float2 load(const ColCtx& c, int k) const { return in[c.base + (int64_t)k * c.q]; }
     __device__ __forceinline__ void store(const ColCtx& c, int k, float2 v) const { out[c.base + (int64_t)k * c.q] = v; }
@@ -155,11 +173,28 @@ inline int set_lds_limit(K kernel, size_t bytes) {
 }
 
 // ------------------------------------------------------------------ static-plan dispatch
-constexpr int kMaxGrid = 256 * 8;  // grid-stride over tiles: enough workgroups to fill 256 CUs several times
+constexpr int kMaxGrid = 256 * 8;
+#ifndef DINV_COLS_PREFETCH
+#define DINV_COLS_PREFETCH 0
+#endif
+#ifndef DINV_COLS_PF_GRID
+#define DINV_COLS_PF_GRID 512    // two 256-thread workgroups per CU (41 KB of LDS, < 256 registers)
+#endif
+#ifndef DINV_WAVE_WPB
+#define DINV_WAVE_WPB 4      // waves per workgroup of the wave-autonomous rows pass (they only share the LDS allocation)
+#endif
+#ifndef DINV_WAVE_PREFETCH
+#define DINV_WAVE_PREFETCH 1  // issue the next tile's loads behind stage 1 of the current one
+#endif
+#ifndef DINV_WAVE_MINW
+#define DINV_WAVE_MINW 2     // waves per SIMD it is compiled for (register budget 256): 8 tiles of 10 KB in flight per CU
+#endif  // grid-stride over tiles: enough workgroups to fill 256 CUs several times
 
 template <int N> struct RowsL { static constexpr int value = N >= 512 ? 8 : (N >= 128 ? 16 : 32); };
 template <int N> struct ColsL { static constexpr int value = N == 16 ? 256 : 16; };
 
+template <class T, class = void> struct io_has_raw4 : std::false_type {};
+template <class T> struct io_has_raw4<T, std::void_t<typename T::Raw4>> : std::true_type {};
 template <class T, class = void> struct io_planar_store : std::false_type {};
 template <class T> struct io_planar_store<T, std::void_t<decltype(T::planar_store)>> : std::bool_constant<T::planar_store> {};
 
@@ -171,6 +206,28 @@ inline int launch_rows_static_L(Io io, int64_t nlines, const void* table, int in
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, kMaxGrid);
     if constexpr (io_has_vec4<Io>::value && P::STAGES >= 2 && P::M1 % 4 == 0 && (P::N / (P::STAGES == 3 ? P::R3 : P::R2)) % 4 == 0) {
         if (centered == 0 || (P::N / 2) % 4 == 0) {
+#ifndef DINV_NO_WAVE_ROWS
+            if constexpr (io_has_raw4<Io>::value && N >= 256) {
+                // wave-autonomous pass (fft_wave.hpp): one wave per tile of LW rows, no workgroup barrier, persistent waves
+                constexpr int LW = WaveRowsL<P>::value, WPB = DINV_WAVE_WPB, MINW = DINV_WAVE_MINW;
+                constexpr bool PF = DINV_WAVE_PREFETCH != 0;
+                if (io.wave_rows_ok(LW, nlines)) {
+                    const int64_t wtiles = ceil_div(nlines, LW);
+                    int cus = 256;
+                    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+                    const int64_t resident = (int64_t)cus * (4 * MINW / WPB);          // workgroups the chip holds at MINW waves per SIMD
+                    const unsigned wgrid = (unsigned)std::min<int64_t>(ceil_div(wtiles, WPB), resident);
+                    if (inverse)
+                        hipLaunchKernelGGL((fft_rows_wave_kernel<P, Io, true, LW, WPB, MINW, PF>), dim3(wgrid), dim3(64 * WPB), 0, s, io,
+                                           nlines, wtiles, table, centered, scale);
+                    else
+                        hipLaunchKernelGGL((fft_rows_wave_kernel<P, Io, false, LW, WPB, MINW, PF>), dim3(wgrid), dim3(64 * WPB), 0, s, io,
+                                           nlines, wtiles, table, centered, scale);
+                    DINV_CHECK_LAUNCH();
+                    return 0;
+                }
+            }
+#endif
             if (inverse)
                 hipLaunchKernelGGL((fft_rows_static_v4_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, nlines,
                                    ntiles, table, centered, scale);
@@ -207,6 +264,20 @@ inline int launch_cols_static(Io io, int64_t P_, int64_t Q, const void* table, i
     if (group > 1 && P_ % group != 0) group = 1;
     const int64_t padded = group > 1 ? ceil_div(ntiles, (int64_t)8 * group) * 8 * group : ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(padded, kMaxGrid);
+#if DINV_COLS_PREFETCH
+    if constexpr (P::STAGES > 1) {
+        if (group <= 1 && ntiles > DINV_COLS_PF_GRID) {     // persistent workgroups, next tile's loads in flight during the transform
+            if (inverse)
+                hipLaunchKernelGGL((fft_cols_static_pf_kernel<P, Io, true, L>), dim3(DINV_COLS_PF_GRID), dim3(256), 0, s, io, Q, qtiles,
+                                   ntiles, table, centered, scale);
+            else
+                hipLaunchKernelGGL((fft_cols_static_pf_kernel<P, Io, false, L>), dim3(DINV_COLS_PF_GRID), dim3(256), 0, s, io, Q, qtiles,
+                                   ntiles, table, centered, scale);
+            DINV_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+#endif
     if (inverse)
         hipLaunchKernelGGL((fft_cols_static_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, Q, qtiles, ntiles,
                            table, centered, scale, group);

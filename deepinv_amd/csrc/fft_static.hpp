@@ -250,6 +250,143 @@ struct TileFft {
         }
     }
 
+    // ---- the pieces of run() for callers that pipeline tiles themselves: stage 1 from registers (load_inputs), then the rest;
+    // between the two the caller may issue the NEXT tile's load_inputs into the same registers (they fly during stages 2, 3)
+    static __device__ __forceinline__ void stage1_regs(float2* buf, const float2* __restrict__ tw, int lines, int tid,
+                                                       const float2 (&vin)[NS1][P::R1]) {
+        static_assert(P::STAGES > 1, "multi-stage plans only");
+        constexpr int R1 = P::R1;
+#pragma unroll
+        for (int slot = 0; slot < NS1; ++slot) {
+            const int w = tid + NT * slot;
+            int line, u;
+            split(w, P::K1, line, u);
+            if (w >= L * P::K1 || line >= lines) continue;
+            float2 v[R1];
+#pragma unroll
+            for (int j = 0; j < R1; ++j) v[j] = vin[slot][j];
+            Bfly<R1, INV>::run(v);
+            apply_twiddle_powers<R1, INV>(v, tw[u]);
+#pragma unroll
+            for (int q = 0; q < R1; ++q) buf[addr(line, q, u)] = v[q];
+        }
+    }
+    template <class EmitF>
+    static __device__ __forceinline__ void after_stage1(float2* buf, const float2* __restrict__ tw, int lines, int c, float scale,
+                                                        int tid, EmitF emit) {
+        constexpr int R1 = P::R1, R2 = P::R2, M2 = P::M2;
+        __syncthreads();
+        if constexpr (P::STAGES == 3) {
+            constexpr int NS2 = (L * P::K2 + NT - 1) / NT;
+#pragma unroll
+            for (int slot = 0; slot < NS2; ++slot) {
+                const int w = tid + NT * slot;
+                int line, i;
+                split(w, P::K2, line, i);
+                if (w >= L * P::K2 || line >= lines) continue;
+                const int q1 = i / M2, u = i % M2;
+                float2 v[R2];
+#pragma unroll
+                for (int j = 0; j < R2; ++j) v[j] = buf[addr(line, q1, u + M2 * j)];
+                Bfly<R2, INV>::run(v);
+                apply_twiddle_powers<R2, INV>(v, tw[R1 * u]);
+#pragma unroll
+                for (int q = 0; q < R2; ++q) buf[addr(line, q1, q * M2 + u)] = v[q];
+            }
+            __syncthreads();
+        }
+        constexpr int Q2N = (P::STAGES == 3) ? R2 : 1;
+#pragma unroll
+        for (int slot = 0; slot < NSL; ++slot) {
+            const int w = tid + NT * slot;
+            int line, i;
+            split(w, KL, line, i);
+            if (w >= L * KL || line >= lines) continue;
+            const int q1 = i % R1, q2 = i / R1;
+            float2 v[RL];
+#pragma unroll
+            for (int j = 0; j < RL; ++j) v[j] = buf[addr(line, q1, (Q2N > 1 ? q2 * RL : 0) + j)];
+            Bfly<RL, INV>::run(v);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                int k = q1 + R1 * q2 + R1 * Q2N * q + c;
+                if (k >= N) k -= N;
+                emit(slot, line, k, q, cscale(v[q], scale));
+            }
+        }
+    }
+
+    // ---- the pieces of run_v4 for callers that pipeline tiles themselves (fft_wave.hpp): one stage-1 item from registers,
+    // and everything after stage 1 with a caller-chosen synchronisation (workgroup barrier or wave-local ordering)
+    static constexpr int NSV1 = (L * (P::M1 / 4) + NT - 1) / NT;
+    // (`tw` may point to an LDS copy of the table: a global-memory twiddle read is a dependent L2 round trip per stage)
+    static __device__ __forceinline__ void v4_stage1_item(float2* buf, const float2* tw, int line, int u0,
+                                                          const float2 (&x)[P::R1][4]) {
+        constexpr int R1 = P::R1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float2 v[R1];
+#pragma unroll
+            for (int j = 0; j < R1; ++j) v[j] = x[j][e];
+            Bfly<R1, INV>::run(v);
+            apply_twiddle_powers<R1, INV>(v, tw[u0 + e]);
+#pragma unroll
+            for (int q = 0; q < R1; ++q) buf[addr(line, q, u0 + e)] = v[q];
+        }
+    }
+    template <class Sync, class EmitV>
+    static __device__ __forceinline__ void v4_finish(float2* buf, const float2* tw, int lines, int c, float scale,
+                                                     int tid, EmitV emitv) {
+        static_assert(ROW, "v4_finish is a rows-pass piece");
+        constexpr int R1 = P::R1, R2 = P::R2, M2 = P::M2;
+        if constexpr (P::STAGES == 3) {
+            constexpr int NS2 = (L * P::K2 + NT - 1) / NT;
+#pragma unroll
+            for (int slot = 0; slot < NS2; ++slot) {
+                const int w = tid + NT * slot;
+                int line, i;
+                split(w, P::K2, line, i);
+                if (w >= L * P::K2 || line >= lines) continue;
+                const int q1 = i / M2, u = i % M2;
+                float2 v[R2];
+#pragma unroll
+                for (int j = 0; j < R2; ++j) v[j] = buf[addr(line, q1, u + M2 * j)];
+                Bfly<R2, INV>::run(v);
+                apply_twiddle_powers<R2, INV>(v, tw[R1 * u]);
+#pragma unroll
+                for (int q = 0; q < R2; ++q) buf[addr(line, q1, q * M2 + u)] = v[q];
+            }
+            Sync::sync();
+        }
+        constexpr int Q2N = (P::STAGES == 3) ? R2 : 1;
+        constexpr int TL = KL / 4;
+        constexpr int NSVL = (L * TL + NT - 1) / NT;
+#pragma unroll
+        for (int slot = 0; slot < NSVL; ++slot) {
+            const int w = tid + NT * slot;
+            const int line = w / TL, i0 = (w - line * TL) * 4;
+            if (w >= L * TL || line >= lines) continue;
+            float2 o[RL][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e;
+                const int q1 = i % R1, q2 = i / R1;
+                float2 v[RL];
+#pragma unroll
+                for (int j = 0; j < RL; ++j) v[j] = buf[addr(line, q1, (Q2N > 1 ? q2 * RL : 0) + j)];
+                Bfly<RL, INV>::run(v);
+#pragma unroll
+                for (int q = 0; q < RL; ++q) o[q][e] = cscale(v[q], scale);
+            }
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                int k0 = i0 + R1 * Q2N * q + c;
+                if (k0 >= N) k0 -= N;
+                emitv(slot, line, k0, q, o[q]);
+            }
+        }
+    }
+
     // ---- ROW-mode variant with 4 adjacent elements per thread on the global side: every global access is a
     // 16-byte-per-lane vector access (the guide's "vectorize ALWAYS" rule; 4-byte-per-lane streams top out near
     // 2.7 TB/s on this chip, 16-byte ones reach >5 TB/s).  loadv(line, n0, out[4]) / emitv(slot, line, k0, q, v[4]).
@@ -408,6 +545,45 @@ __global__ __launch_bounds__(256) void fft_cols_static_kernel(Io io, int64_t Q, 
         TF::run(buf, tw, cols, c, scale, tid,
                 [&](int, int, int, int n) { return io.load(ctx, n); },
                 [&](int, int, int k, int, float2 v) { io.store(ctx, k, v); });
+    }
+}
+
+// column pass with the NEXT tile's stage-1 inputs in flight while the current tile is transformed (persistent workgroups,
+// one register set: the loads are issued right after stage 1 has consumed the registers)
+template <class P, class Io, bool INV, int L>
+__global__ __launch_bounds__(256) void fft_cols_static_pf_kernel(Io io, int64_t Q, int64_t qtiles, int64_t ntiles,
+                                                                 const void* table, int centered, float scale) {
+    using TF = TileFft<P, INV, false, L>;
+    static_assert(P::STAGES > 1, "multi-stage plans only");
+    __shared__ __attribute__((aligned(16))) float2 buf[TF::lds_floats2];
+    const float2* tw = reinterpret_cast<const float2*>(table);
+    const int tid = threadIdx.x;
+    const int c = centered ? P::N / 2 : 0;
+    const int line = tid % L;
+    float2 vin[TF::NS1][P::R1];
+    auto ctx_of = [&](int64_t tile, int& cols) __attribute__((always_inline)) {
+        const int64_t p = tile / qtiles;
+        const int64_t q0 = (tile - p * qtiles) * L;
+        cols = (int)min((int64_t)L, Q - q0);
+        return io.col_ctx(p, q0 + (line < cols ? line : 0));
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) {
+        int cols;
+        const typename Io::ColCtx ctx = ctx_of(tile, cols);
+        TF::load_inputs(vin, cols, c, tid, [&](int, int, int, int n) { return io.load(ctx, n); });
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        int cols;
+        const typename Io::ColCtx ctx = ctx_of(tile, cols);
+        __syncthreads();        // the previous tile's last stage has read `buf`
+        TF::stage1_regs(buf, tw, cols, tid, vin);
+        if (tile + gridDim.x < ntiles) {
+            int ncols;
+            const typename Io::ColCtx nctx = ctx_of(tile + gridDim.x, ncols);
+            TF::load_inputs(vin, ncols, c, tid, [&](int, int, int, int n) { return io.load(nctx, n); });
+        }
+        TF::after_stage1(buf, tw, cols, c, scale, tid, [&](int, int, int k, int, float2 v) { io.store(ctx, k, v); });
     }
 }
 

@@ -15,6 +15,10 @@
 #include "fft_core.hpp"
 #include "fft_launch.hpp"
 
+#ifndef DINV_EXPAND_PREFETCH
+#define DINV_EXPAND_PREFETCH 0
+#endif
+
 using namespace dinv;
 
 namespace {
@@ -316,6 +320,38 @@ struct RowsPlanarMaskStoreIo {
         st_f4(y + c.yre + k0, re);
         st_f4(y + c.yim + k0, im);
     }
+    // wave-autonomous rows pass (fft_wave.hpp): a tile of LW consecutive rows must lie inside one (b, n) image; its base
+    // pointers are wave-uniform, lanes add a 32-bit element offset
+    __host__ bool wave_rows_ok(int lw, int64_t nlines) const { return R % lw == 0 && (uint64_t)R * (uint64_t)W < (1ull << 31) && nlines < (1ll << 31); }
+    struct Raw4 { float4 a, b; };
+    struct TileCtx { const float2* tin; float* yre; float* yim; const float* mre; const float* mim; };
+    __device__ __forceinline__ TileCtx tile_ctx(int64_t line0) const {      // (32-bit divisions: wave_rows_ok bounds the sizes)
+        const unsigned l0 = (unsigned)line0, Ru = (unsigned)R, bn = l0 / Ru, r = l0 - bn * Ru;
+        const unsigned b = bn / (unsigned)ncoil, n = bn - b * (unsigned)ncoil;
+        const int64_t vol = R * W;
+        const int64_t yre = ((int64_t)(b * 2) * ncoil + n) * vol + (int64_t)r * W, mre = ((mask_batch > 1 ? (int64_t)b : 0) * 2) * vol + (int64_t)r * W;
+        return TileCtx{t + line0 * W, y + yre, y + yre + (int64_t)ncoil * vol, mask ? mask + mre : nullptr, mask ? mask + mre + vol : nullptr};
+    }
+    __device__ __forceinline__ void load4_raw(const TileCtx& c, unsigned off, Raw4& r) const {
+        r.a = reinterpret_cast<const float4*>(c.tin + off)[0];
+        r.b = reinterpret_cast<const float4*>(c.tin + off)[1];
+    }
+    struct Mask4 {};
+    __device__ __forceinline__ bool has_mask() const { return false; }      // (of the LOADED side: the mask is applied by store4)
+    __device__ __forceinline__ void load_mask4(const TileCtx&, unsigned, Mask4&) const {}
+    __device__ __forceinline__ void unpack4(const Raw4& r, const Mask4&, float2 (&v)[4]) const {
+        v[0] = make_float2(r.a.x, r.a.y); v[1] = make_float2(r.a.z, r.a.w); v[2] = make_float2(r.b.x, r.b.y); v[3] = make_float2(r.b.z, r.b.w);
+    }
+    __device__ __forceinline__ void store4(const TileCtx& c, unsigned off, const float2 (&v)[4]) const {
+        float4 re = make_float4(v[0].x, v[1].x, v[2].x, v[3].x), im = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+        if (mask) {  // float multiply exactly as mri.py:271; masked-out samples are written as exact zeros
+            const float4 mr = ld_f4(c.mre + off), mi = ld_f4(c.mim + off);
+            re = make_float4(mr.x * re.x, mr.y * re.y, mr.z * re.z, mr.w * re.w);
+            im = make_float4(mi.x * im.x, mi.y * im.y, mi.z * im.z, mi.w * im.w);
+        }
+        st_f4(c.yre + off, re);
+        st_f4(c.yim + off, im);
+    }
     __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
 };
 
@@ -362,6 +398,39 @@ struct RowsPlanarMaskLoadIo {
         v[2] = make_float2(re.z, im.z); v[3] = make_float2(re.w, im.w);
     }
     __device__ __forceinline__ void store4(const RowCtx& c, int k0, const float2 (&v)[4]) const { st_c4(t + c.tout + k0, v); }
+    // wave-autonomous rows pass (fft_wave.hpp): the mask multiply happens when the registers are consumed
+    __host__ bool wave_rows_ok(int lw, int64_t nlines) const { return R % lw == 0 && (uint64_t)R * (uint64_t)W < (1ull << 31) && nlines < (1ll << 31); }
+    struct Raw4 { float4 re, im; };
+    struct TileCtx { float2* tout; const float* yre; const float* yim; const float* mre; const float* mim; };
+    __device__ __forceinline__ TileCtx tile_ctx(int64_t line0) const {      // (32-bit divisions: wave_rows_ok bounds the sizes)
+        const unsigned l0 = (unsigned)line0, Ru = (unsigned)R, bn = l0 / Ru, r = l0 - bn * Ru;
+        const unsigned b = bn / (unsigned)ncoil, n = bn - b * (unsigned)ncoil;
+        const int64_t vol = R * W;
+        const int64_t yre = ((int64_t)(b * 2) * ncoil + n) * vol + (int64_t)r * W, mre = ((mask_batch > 1 ? (int64_t)b : 0) * 2) * vol + (int64_t)r * W;
+        return TileCtx{t + line0 * W, y + yre, y + yre + (int64_t)ncoil * vol, mask ? mask + mre : nullptr, mask ? mask + mre + vol : nullptr};
+    }
+    __device__ __forceinline__ void load4_raw(const TileCtx& c, unsigned off, Raw4& r) const {
+        r.re = ld_f4(c.yre + off);
+        r.im = ld_f4(c.yim + off);
+    }
+    // (the mask - small, L2-resident - is fetched when the samples are consumed: its latency is covered by the other waves
+    // of the CU, and the 8 registers per element group it would occupy while in flight are what limits their number)
+    struct Mask4 { float4 mr, mi; };
+    __device__ __forceinline__ bool has_mask() const { return mask != nullptr; }
+    __device__ __forceinline__ void load_mask4(const TileCtx& c, unsigned off, Mask4& m) const {
+        m.mr = ld_f4(c.mre + off);
+        m.mi = ld_f4(c.mim + off);
+    }
+    __device__ __forceinline__ void unpack4(const Raw4& r, const Mask4& m, float2 (&v)[4]) const {
+        float4 re = r.re, im = r.im;
+        if (mask) {
+            re = make_float4(m.mr.x * re.x, m.mr.y * re.y, m.mr.z * re.z, m.mr.w * re.w);
+            im = make_float4(m.mi.x * im.x, m.mi.y * im.y, m.mi.z * im.z, m.mi.w * im.w);
+        }
+        v[0] = make_float2(re.x, im.x); v[1] = make_float2(re.y, im.y);
+        v[2] = make_float2(re.z, im.z); v[3] = make_float2(re.w, im.w);
+    }
+    __device__ __forceinline__ void store4(const TileCtx& c, unsigned off, const float2 (&v)[4]) const { st_c4(c.tout + off, v); }
     __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
 };
 
@@ -401,7 +470,7 @@ struct ColsCoilLoadIo {
 // one write of t instead of a write, a read and a write (210 of the 630 MB that A moved per call at cfg2).
 // The coils of one (slice, column tile) run on one XCD at the same time (blocks b and b + 8; observed placement, speed
 // only), so x is read from HBM once and from that XCD's L2 seven times.
-template <class P, int L, int NT>
+template <class P, int L, int NT, bool PF>
 __global__ __launch_bounds__(NT) void mri_cols_expand_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ maps,
                                                                   float2* __restrict__ t, int ncoil, int maps_batch, int64_t Q,
                                                                   int64_t qtiles, int64_t nsets, const void* table, float scale) {
@@ -414,16 +483,24 @@ __global__ __launch_bounds__(NT) void mri_cols_expand_fwd_kernel(const float* __
     const int c = N / 2;
     const int64_t vol = (int64_t)N * Q;
     const int64_t padded = ceil_div_dev(nsets, 8) * 8 * ncoil;
-    for (int64_t T = blockIdx.x; T < padded; T += gridDim.x) {
+    float4 xr[NI], xi[NI], sa[NI], sb[NI];
+    // tile T -> (slice b, column tile q0, coil n); false for the padding tiles
+    auto decode = [&](int64_t T, int64_t& b, int64_t& q0, int& cols, int& n) __attribute__((always_inline)) {
         const int64_t chunk = T / (8 * ncoil), within = T - chunk * (8 * ncoil);
         const int64_t set = chunk * 8 + within % 8;
-        const int n = (int)(within / 8);
-        if (set >= nsets) continue;
-        const int64_t b = set / qtiles, q0 = (set - b * qtiles) * L;
-        const int cols = (int)min((int64_t)L, Q - q0);
+        n = (int)(within / 8);
+        if (set >= nsets) return false;
+        b = set / qtiles;
+        q0 = (set - b * qtiles) * L;
+        cols = (int)min((int64_t)L, Q - q0);
+        return true;
+    };
+    auto issue = [&](int64_t T) __attribute__((always_inline)) {
+        int64_t b, q0;
+        int cols, n;
+        if (!decode(T, b, q0, cols, n)) return;
         const float* xre = x + (b * 2) * vol + q0;
         const float2* sp = maps ? maps + ((maps_batch > 1 ? b : 0) * ncoil + n) * vol + q0 : nullptr;
-        float4 xr[NI], xi[NI], sa[NI], sb[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int item = tid + NT * i, row = item / QL, quad = item - row * QL;
@@ -436,22 +513,37 @@ __global__ __launch_bounds__(NT) void mri_cols_expand_fwd_kernel(const float* __
                 sb[i] = reinterpret_cast<const float4*>(sp + o)[1];
             }
         }
-        __syncthreads();   // the previous tile's last stage has left the LDS tile
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int item = tid + NT * i, row = item / QL, quad = item - row * QL;
-            if (item >= N * QL) continue;
-            float2 v[4] = {make_float2(xr[i].x, xi[i].x), make_float2(xr[i].y, xi[i].y), make_float2(xr[i].z, xi[i].z),
-                           make_float2(xr[i].w, xi[i].w)};
-            if (sp) {
-                v[0] = cmul(make_float2(sa[i].x, sa[i].y), v[0]);
-                v[1] = cmul(make_float2(sa[i].z, sa[i].w), v[1]);
-                v[2] = cmul(make_float2(sb[i].x, sb[i].y), v[2]);
-                v[3] = cmul(make_float2(sb[i].z, sb[i].w), v[3]);
-            }
-            st_c4(buf + row * L + 4 * quad, v);
+    };
+    int64_t T = blockIdx.x;
+    if (PF && T < padded) issue(T);
+    for (; T < padded; T += gridDim.x) {
+        int64_t b = 0, q0 = 0;
+        int cols = 0, n = 0;
+        const bool valid = decode(T, b, q0, cols, n);
+        if (!PF) {
+            if (!valid) continue;
+            issue(T);
         }
+        __syncthreads();   // the previous tile's last stage has left the LDS tile
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int item = tid + NT * i, row = item / QL, quad = item - row * QL;
+                if (item >= N * QL) continue;
+                float2 v[4] = {make_float2(xr[i].x, xi[i].x), make_float2(xr[i].y, xi[i].y), make_float2(xr[i].z, xi[i].z),
+                               make_float2(xr[i].w, xi[i].w)};
+                if (maps) {
+                    v[0] = cmul(make_float2(sa[i].x, sa[i].y), v[0]);
+                    v[1] = cmul(make_float2(sa[i].z, sa[i].w), v[1]);
+                    v[2] = cmul(make_float2(sb[i].x, sb[i].y), v[2]);
+                    v[3] = cmul(make_float2(sb[i].z, sb[i].w), v[3]);
+                }
+                st_c4(buf + row * L + 4 * quad, v);
+            }
+        }
+        if (PF && T + gridDim.x < padded) issue(T + gridDim.x);   // the next tile's loads fly during the transform
         __syncthreads();
+        if (!valid) continue;        // (workgroup-uniform)
         float2* o = t + (b * ncoil + n) * vol + q0 + (line < cols ? line : 0);
         TF::template run<true>(buf, tw, cols, c, scale, tid,
                                [&](int, int, int, int nn) { return buf[nn * L + line]; },
@@ -595,7 +687,15 @@ int launch_cols_expand_fwd(const float* x, const float2* maps, float2* t, int64_
         // (measured at cfg2: 111 us; 512 threads / 148 VGPRs = one workgroup per CU: 135 us; 512 threads capped at 128
         // VGPRs (spills): 171 us)
         constexpr int NT = 256;
-        hipLaunchKernelGGL((mri_cols_expand_fwd_kernel<P, L, NT>), dim3(grid), dim3(NT), 0, s, x, maps, t, ncoil, maps_batch, Q,
+#if DINV_EXPAND_PREFETCH
+        if (padded > DINV_COLS_PF_GRID) {     // persistent workgroups, the next tile's loads in flight during the transform
+            hipLaunchKernelGGL((mri_cols_expand_fwd_kernel<P, L, NT, true>), dim3(DINV_COLS_PF_GRID), dim3(NT), 0, s, x, maps, t, ncoil,
+                               maps_batch, Q, qtiles, nsets, table, scale);
+            DINV_CHECK_LAUNCH();
+            return 0;
+        }
+#endif
+        hipLaunchKernelGGL((mri_cols_expand_fwd_kernel<P, L, NT, false>), dim3(grid), dim3(NT), 0, s, x, maps, t, ncoil, maps_batch, Q,
                            qtiles, nsets, table, scale);
         DINV_CHECK_LAUNCH();
         return 0;

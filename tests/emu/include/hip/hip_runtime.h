@@ -183,6 +183,12 @@ inline uint64_t* wave_exchange_begin(const uint64_t* mine, int words) {
     barrier_wait(g.wave_bar[w], &g.wave_alive[w]);
     return buf.data();
 }
+// ordering point of a wave's LDS traffic (the product's wave_lds_sync): on the hardware the lanes of a wave run in lock step,
+// here its fibers meet at a barrier
+inline void wave_sync() {
+    const int w = wave();
+    barrier_wait(g.wave_bar[w], &g.wave_alive[w]);
+}
 inline void wave_exchange_end() {
     const int w = wave();
     barrier_wait(g.wave_bar[w], &g.wave_alive[w]);

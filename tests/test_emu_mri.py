@@ -63,7 +63,8 @@ def _run(fn, d, *ptrs):
 
 
 CASES = [((32, 64), 2, 3, 1), ((64, 32), 1, 2, 2), ((16, 32, 32), 1, 2, 1), ((17, 11), 2, 3, 1), ((128, 32), 1, 1, 1),
-         ((24, 40), 1, 2, 1), ((320, 64), 1, 2, 1), ((64, 256), 1, 1, 1)]
+         ((24, 40), 1, 2, 1), ((320, 64), 1, 2, 1), ((64, 256), 1, 1, 1), ((32, 320), 2, 2, 2), ((32, 512), 1, 2, 1),
+         ((16, 16, 256), 1, 2, 1)]
 
 
 @pytest.mark.parametrize("vol,B,N,mask_b", CASES)
