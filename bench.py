@@ -143,10 +143,11 @@ def main():
                      "steps_bf16split": n2,
                      "dtype_bf16split": "f32 in/out; ResBlock convs = Winograd F(2,3) along rows, every multiply as bf16 x2 exact "
                                         "operand split (3 products: 16 significand bits per operand), f32 accumulate",
-                     "roofline_bf16split": {"kernel": k2, "achieved": round(p2["direct_flops"] / (p2["ms"] * 1e-3) / 1e12, 2),
+                     "roofline_bf16split": {"kernel": k2, "achieved": round(p2["mfma_flops"] / (p2["ms"] * 1e-3) / 1e12, 2),
                                             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                                            "frac": round(p2["direct_flops"] / (p2["ms"] * 1e-3) / MFMA_BF16_PEAK, 4),
-                                            "executed": round(p2["mfma_flops"] / (p2["ms"] * 1e-3) / 1e12, 2),
+                                            "frac": round(p2["mfma_flops"] / (p2["ms"] * 1e-3) / MFMA_BF16_PEAK, 4),
+                                            "flops": "executed on the bf16 matrix pipe (three bf16 products per fp32 multiply)",
+                                            "direct_equiv": round(p2["direct_flops"] / (p2["ms"] * 1e-3) / 1e12, 2),
                                             "avg_launch_ms": round(p2["ms"] / max(p2["launches"], 1), 4)},
                      "rel_diff_bf16split_vs_fp32": float(f"{float((out2 - out).norm() / out.norm()):.3e}")}
 
@@ -200,10 +201,11 @@ def main():
         # dominant kernel = the one with the largest share of the timed region
         kname, kp = max(conv_prof.items(), key=lambda kv: kv[1]["ms"]) if conv_prof else ("none", None)
         peak = MFMA_F32_PEAK        # the headline leg multiplies in fp32 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32)
-        # roofline.achieved = ALGORITHMIC flops (direct 3x3 convolution: 2*9*Cin*Cout*B*H*W per launch) / HIP-event
-        # time of the launches.  A Winograd kernel EXECUTES fewer multiplies than that count (36 instead of 144 per 4x4 output
-        # tile and channel pair for F(4x4,3x3), 16 instead of 36 per 2x2 tile for F(2x2,3x3)), so `frac` = algorithmic / peak
-        # can exceed 1; what the kernel really issues on the matrix pipe is `executed` / `frac_executed` (how well the pipe is used)
+        # The roofline of the dominant kernel is the fp32 MATRIX PIPE: `achieved` = the flops the kernel EXECUTES on it per launch
+        # / the HIP-event time of the launches, `frac` = achieved / peak (<= 1).  A Winograd kernel executes fewer multiplies than
+        # the direct convolution it evaluates (36 instead of 144 per 4x4 output tile and channel pair for F(4x4,3x3)): the
+        # ALGORITHMIC count of SURVEY 8d (2*9*Cin*Cout*B*H*W per launch) over the same time is reported beside it as
+        # `direct_equiv` / `frac_direct_equiv` (that one can exceed 1 and is not a fraction of any roofline).
         achieved = kp["direct_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
         executed = kp["mfma_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
         all_ms = sum(v["ms"] for v in conv_prof.values())
@@ -219,17 +221,31 @@ def main():
         # HBM bytes per launch of the dominant kernel: measured by separate rocprofv3 --pmc passes (TCC_EA0_RDREQ x 64 B x 2
         # [gfx950 wide-load correction] + TCC_EA0_WRREQ x 64 B, averaged over the launches of one DRUNet call) and
         # recorded, with the commit and configuration they were taken at, in profiles/pmc_traffic.json
-        traffic = None
-        pmc = {}
+        # A recorded row is used only if the kernel sources it was measured on are the ones in the tree now (`sources_sha16`
+        # = hash of the files that hold the kernels of that row, written by scripts/r05/merge_pmc.py): a stale row is dropped
+        # and named in `pmc_stale`.
+        traffic, mfma_busy = None, None
+        pmc, stale = {}, []
         try:
             pmc = json.load(open(PMC_TRAFFIC_FILE))
-            rec = pmc.get(kname)
-            if rec and rec.get("config") == {"batch": B_local, "height": H, "width": W}:
-                traffic = rec["bytes_per_launch"]
         except (OSError, ValueError):
             pass
+
+        def fresh(key):
+            rec = pmc.get(key)
+            if not rec:
+                return None
+            if rec.get("sources_sha16") != sources_sha16(rec.get("sources", [])):
+                stale.append(key)
+                return None
+            return rec
+
+        rec = fresh(kname)
+        if rec and rec.get("config") == {"batch": B_local, "height": H, "width": W}:
+            traffic = rec["bytes_per_launch"]
+            mfma_busy = rec.get("mfma_busy")
         for row in ops:     # measured HBM bytes of the operator rows (same counter method), where a pass was recorded
-            rec = pmc.get("op:" + row["op"] + "@" + row["config"])
+            rec = fresh("op:" + row["op"] + "@" + row["config"])
             if rec and rec.get("batch") == row["batch"]:
                 row["pmc_MB"] = round(rec["bytes_per_call"] / 1e6, 1)
                 row["pmc_over_alg"] = round(rec["bytes_per_call"] / 1e6 / max(row["alg_MB"], 1e-9), 2)
@@ -244,11 +260,13 @@ def main():
                        "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if world > 1 else "none",
                        "conv_precision": "fp32", "loop_graph": bool(getattr(model.fixed_point, "use_graph", False))},
             "roofline": {"bound": "mfma", "kernel": f"{kname} ({kdesc})",
-                         "achieved": round(achieved / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "flops": "algorithmic: direct 3x3 convolution, 2*9*Cin*Cout*B*H*W per launch (a Winograd kernel executes "
-                                  "fewer: see executed / frac_executed)",
-                         "executed": round(executed / 1e12, 2), "frac_executed": round(executed / peak, 4),
+                         "achieved": round(executed / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                         "frac": round(executed / peak, 4), "traffic": traffic, "mfma_busy": mfma_busy,
+                         "flops": "executed on the fp32 matrix pipe: 2*36*Cin*Cout*B*H*W/16 per launch for Winograd F(4x4,3x3) (a "
+                                  "quarter of the direct convolution's 2*9*Cin*Cout*B*H*W = SURVEY 8d's algorithmic count, which is "
+                                  "direct_equiv)",
+                         "direct_equiv": round(achieved / 1e12, 2), "frac_direct_equiv": round(achieved / peak, 4),
+                         "pmc_stale": stale,
                          "launches": kp["launches"] if kp else 0,
                          "avg_launch_ms": round(kp["ms"] / max(kp["launches"], 1), 4) if kp else 0.0,
                          "share_of_step": round(kp["ms"] * 1e-3 / elapsed, 4) if kp else 0.0,
@@ -272,6 +290,18 @@ def main():
                 res["parity_unit_gain_50it"] = ug
         print(json.dumps(res))
     ctx.__exit__(None, None, None)
+
+
+def sources_sha16(files):
+    """hash of the kernel source files a profiles/pmc_traffic.json row was measured on (paths relative to the repo root)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(files):
+        try:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        except OSError:
+            h.update(b"missing:" + f.encode())
+    return h.hexdigest()[:16]
 
 
 def layer_errors(device, B=4, H=80, C=256):

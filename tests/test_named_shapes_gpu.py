@@ -134,6 +134,73 @@ def test_cfg5_downsampling_diffpir_256(dev, monkeypatch):
     assert rel_err(sub(out, st), d["out_exact"]) < TOL       # ... and against the fp64 evaluation of the same sample path
 
 
+def full_length_cfg5(dinv, dev, d, B=16, precisions=None):
+    """BASELINE configs[4] at FULL length on the per-GPU shard (16 images 3x256x256): 100-step DiffPIR, unit 0 = the fixture's
+    seeded image with the fixture's torch.randn_like draws replayed (the other units get different images and draws).  Returns
+    {precision: (rel. error vs the reference's sample, vs the fp64 evaluation of the same sample path, trace errors)}.
+    Shared by the GPU test below and by bench.py's cfg5 loop row (checker only)."""
+    from oracle import drunet_cpu as OD
+
+    st, stt = int(d["stride"]), int(d["stride_trace"])
+    img = (3, 256, 256)
+    x = torch.cat((torch.rand(1, *img, generator=gen(70)), torch.rand(B - 1, *img, generator=gen(700))))
+    p = dinv.physics.Downsampling(img_size=img, filter="bicubic", factor=4, padding="circular", device=dev,
+                                  noise_model=dinv.physics.GaussianNoise(0.05))
+    y = p.A(x.to(dev))
+    assert rel_err(y[:1], d["y"]) < TOL
+    yn = torch.cat((d["y"] + 0.05 * torch.randn(1, 3, 64, 64, generator=gen(73)),
+                    y[1:].cpu() + 0.05 * torch.randn(B - 1, 3, 64, 64, generator=gen(703)))).to(dev)
+    den = dinv.models.DRUNet(3, 3, pretrained=None).to(dev).eval()
+    den.load_state_dict(OD.init_state_dict(3, 3, seed=int(d["drunet_seed"])))
+    res = {}
+    orig = torch.randn_like
+    from deepinv_amd.models.drunet import CONV_PRECISIONS
+    for prec in precisions or CONV_PRECISIONS:
+        den.conv_precision = prec
+        trace = []
+        hook = den.register_forward_hook(lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt].cpu()))
+        g0, g1 = gen(74), gen(704)
+
+        def draws(t, **kw):      # unit 0 replays the reference's generator stream, the rest of the shard has its own
+            return torch.cat((torch.randn(1, *t.shape[1:], generator=g0), torch.randn(t.shape[0] - 1, *t.shape[1:], generator=g1))).to(t.device)
+
+        torch.randn_like = draws
+        try:
+            sampler = dinv.sampling.DiffPIR(den, dinv.optim.L2(), sigma=0.05, max_iter=int(d["steps"]), zeta=0.1, lambda_=7.0, device=dev)
+            assert torch.equal(sampler.seq.cpu(), d["seq"])
+            torch.cuda.synchronize()
+            import time
+            t0 = time.perf_counter()
+            out = sampler(yn, p)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            torch.randn_like = orig
+            hook.remove()
+        tr = torch.stack(trace)
+        res[prec] = {"vs_reference": rel_err(sub(out[:1], st), d["out"]), "vs_fp64": rel_err(sub(out[:1], st), d["out_exact"]),
+                     "trace_vs_fp64_max": max(rel_err(a, b) for a, b in zip(tr, d["den_outs_exact"])), "seconds": dt,
+                     "finite": bool(torch.isfinite(out).all())}
+    return res
+
+
+def test_cfg5_diffpir_full_length_100_steps(dev):
+    """configs[4] at its FULL length: 100 DiffPIR steps (deepinv/sampling/diffusion.py:423-513) on the per-GPU shard of 16 images,
+    unit 0 against the REAL reference's sample (tests/golden/cfg5_full.npz, make_golden_r5.py) and against the fp64 evaluation
+    of the same sample path, in both conv_precision settings; the denoiser output of every step is compared as well"""
+    import deepinv_amd as dinv
+
+    d = load("cfg5_full")
+    res = full_length_cfg5(dinv, dev, d)
+    print("cfg5 full length:", {k: {a: (f"{b:.2e}" if isinstance(b, float) else b) for a, b in v.items()} for k, v in res.items()})
+    for prec, r in res.items():
+        assert r["finite"]
+        # the reference's own fp32 rounding along the path is `out_err_vs_exact` (2.5e-6 after 100 steps)
+        assert r["vs_reference"] < max(TOL, 2.0 * float(d["out_err_vs_exact"])), (prec, r)
+        assert r["vs_fp64"] < TOL, (prec, r)
+        assert r["trace_vs_fp64_max"] < 10 * TOL, (prec, r)     # (early steps: x0 predictions of nearly pure noise, looser)
+
+
 @pytest.mark.parametrize("gain_tag", ["", "_gain"])
 def test_cfg2_multicoil_pnp_pgd_320(dev, gain_tag):
     """The HEADLINE configuration (BASELINE configs[1]) against the REAL reference (tests/golden/cfg2_named.npz, written by
