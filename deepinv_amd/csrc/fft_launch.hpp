@@ -174,12 +174,6 @@ inline int set_lds_limit(K kernel, size_t bytes) {
 
 // ------------------------------------------------------------------ static-plan dispatch
 constexpr int kMaxGrid = 256 * 8;
-#ifndef DINV_COLS_PREFETCH
-#define DINV_COLS_PREFETCH 0
-#endif
-#ifndef DINV_COLS_PF_GRID
-#define DINV_COLS_PF_GRID 512    // two 256-thread workgroups per CU (41 KB of LDS, < 256 registers)
-#endif
 #ifndef DINV_WAVE_WPB
 #define DINV_WAVE_WPB 4      // waves per workgroup of the wave-autonomous rows pass (they only share the LDS allocation)
 #endif
@@ -264,20 +258,6 @@ inline int launch_cols_static(Io io, int64_t P_, int64_t Q, const void* table, i
     if (group > 1 && P_ % group != 0) group = 1;
     const int64_t padded = group > 1 ? ceil_div(ntiles, (int64_t)8 * group) * 8 * group : ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(padded, kMaxGrid);
-#if DINV_COLS_PREFETCH
-    if constexpr (P::STAGES > 1) {
-        if (group <= 1 && ntiles > DINV_COLS_PF_GRID) {     // persistent workgroups, next tile's loads in flight during the transform
-            if (inverse)
-                hipLaunchKernelGGL((fft_cols_static_pf_kernel<P, Io, true, L>), dim3(DINV_COLS_PF_GRID), dim3(256), 0, s, io, Q, qtiles,
-                                   ntiles, table, centered, scale);
-            else
-                hipLaunchKernelGGL((fft_cols_static_pf_kernel<P, Io, false, L>), dim3(DINV_COLS_PF_GRID), dim3(256), 0, s, io, Q, qtiles,
-                                   ntiles, table, centered, scale);
-            DINV_CHECK_LAUNCH();
-            return 0;
-        }
-    }
-#endif
     if (inverse)
         hipLaunchKernelGGL((fft_cols_static_kernel<P, Io, true, L>), dim3(grid), dim3(256), 0, s, io, Q, qtiles, ntiles,
                            table, centered, scale, group);

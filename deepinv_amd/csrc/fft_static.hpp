@@ -250,72 +250,6 @@ struct TileFft {
         }
     }
 
-    // ---- the pieces of run() for callers that pipeline tiles themselves: stage 1 from registers (load_inputs), then the rest;
-    // between the two the caller may issue the NEXT tile's load_inputs into the same registers (they fly during stages 2, 3)
-    static __device__ __forceinline__ void stage1_regs(float2* buf, const float2* __restrict__ tw, int lines, int tid,
-                                                       const float2 (&vin)[NS1][P::R1]) {
-        static_assert(P::STAGES > 1, "multi-stage plans only");
-        constexpr int R1 = P::R1;
-#pragma unroll
-        for (int slot = 0; slot < NS1; ++slot) {
-            const int w = tid + NT * slot;
-            int line, u;
-            split(w, P::K1, line, u);
-            if (w >= L * P::K1 || line >= lines) continue;
-            float2 v[R1];
-#pragma unroll
-            for (int j = 0; j < R1; ++j) v[j] = vin[slot][j];
-            Bfly<R1, INV>::run(v);
-            apply_twiddle_powers<R1, INV>(v, tw[u]);
-#pragma unroll
-            for (int q = 0; q < R1; ++q) buf[addr(line, q, u)] = v[q];
-        }
-    }
-    template <class EmitF>
-    static __device__ __forceinline__ void after_stage1(float2* buf, const float2* __restrict__ tw, int lines, int c, float scale,
-                                                        int tid, EmitF emit) {
-        constexpr int R1 = P::R1, R2 = P::R2, M2 = P::M2;
-        __syncthreads();
-        if constexpr (P::STAGES == 3) {
-            constexpr int NS2 = (L * P::K2 + NT - 1) / NT;
-#pragma unroll
-            for (int slot = 0; slot < NS2; ++slot) {
-                const int w = tid + NT * slot;
-                int line, i;
-                split(w, P::K2, line, i);
-                if (w >= L * P::K2 || line >= lines) continue;
-                const int q1 = i / M2, u = i % M2;
-                float2 v[R2];
-#pragma unroll
-                for (int j = 0; j < R2; ++j) v[j] = buf[addr(line, q1, u + M2 * j)];
-                Bfly<R2, INV>::run(v);
-                apply_twiddle_powers<R2, INV>(v, tw[R1 * u]);
-#pragma unroll
-                for (int q = 0; q < R2; ++q) buf[addr(line, q1, q * M2 + u)] = v[q];
-            }
-            __syncthreads();
-        }
-        constexpr int Q2N = (P::STAGES == 3) ? R2 : 1;
-#pragma unroll
-        for (int slot = 0; slot < NSL; ++slot) {
-            const int w = tid + NT * slot;
-            int line, i;
-            split(w, KL, line, i);
-            if (w >= L * KL || line >= lines) continue;
-            const int q1 = i % R1, q2 = i / R1;
-            float2 v[RL];
-#pragma unroll
-            for (int j = 0; j < RL; ++j) v[j] = buf[addr(line, q1, (Q2N > 1 ? q2 * RL : 0) + j)];
-            Bfly<RL, INV>::run(v);
-#pragma unroll
-            for (int q = 0; q < RL; ++q) {
-                int k = q1 + R1 * q2 + R1 * Q2N * q + c;
-                if (k >= N) k -= N;
-                emit(slot, line, k, q, cscale(v[q], scale));
-            }
-        }
-    }
-
     // ---- the pieces of run_v4 for callers that pipeline tiles themselves (fft_wave.hpp): one stage-1 item from registers,
     // and everything after stage 1 with a caller-chosen synchronisation (workgroup barrier or wave-local ordering)
     static constexpr int NSV1 = (L * (P::M1 / 4) + NT - 1) / NT;
@@ -385,6 +319,155 @@ struct TileFft {
                 emitv(slot, line, k0, q, o[q]);
             }
         }
+    }
+
+    // ---- twiddles from a per-plan LDS table instead of powers by multiplication (R - 2 complex multiplies per butterfly are
+    // traded for R - 1 LDS reads; the wave-autonomous kernels are bound by vector-ALU issue, not by LDS):
+    //   T1[(q - 1) * M1 + u] = W_N^(u q), u < M1, 1 <= q < R1        T2[(q - 1) * M2 + u] = W_N^(R1 u q), u < M2, 1 <= q < R2
+    static constexpr int TAB1 = (P::R1 - 1) * P::M1, TAB2 = (P::STAGES == 3) ? (P::R2 - 1) * P::M2 : 0;
+    static constexpr int TAB = (TAB1 + TAB2 + 1) / 2 * 2;       // float2 entries (kept even: 16-byte aligned neighbours)
+    static __device__ __forceinline__ void fill_twiddle_table(float2* tab, const float2* __restrict__ tw, int tid, int nthreads) {
+        for (int i = tid; i < TAB1; i += nthreads) tab[i] = tw[(i % P::M1) * (i / P::M1 + 1)];
+        if constexpr (P::STAGES == 3)
+            for (int i = tid; i < TAB2; i += nthreads) tab[TAB1 + i] = tw[P::R1 * (i % P::M2) * (i / P::M2 + 1)];
+    }
+    static __device__ __forceinline__ float2 twmul(float2 v, float2 w) { return INV ? cmulc(v, w) : cmul(v, w); }
+    static __device__ __forceinline__ void v4_stage1_item_tab(float2* buf, const float2* tab, int line, int u0,
+                                                              const float2 (&x)[P::R1][4]) {
+        constexpr int R1 = P::R1, M1 = P::M1;
+        float2 w[R1 - 1 > 0 ? R1 - 1 : 1][4];
+#pragma unroll
+        for (int q = 1; q < R1; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[q - 1][e] = tab[(q - 1) * M1 + u0 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float2 v[R1];
+#pragma unroll
+            for (int j = 0; j < R1; ++j) v[j] = x[j][e];
+            Bfly<R1, INV>::run(v);
+            buf[addr(line, 0, u0 + e)] = v[0];
+#pragma unroll
+            for (int q = 1; q < R1; ++q) buf[addr(line, q, u0 + e)] = twmul(v[q], w[q - 1][e]);
+        }
+    }
+    template <class Sync>
+    static __device__ __forceinline__ void v4_stage2_tab(float2* buf, const float2* tab, int lines, int tid) {
+        static_assert(ROW && P::STAGES == 3, "three-stage rows plans");
+        constexpr int R2 = P::R2, M2 = P::M2;
+        constexpr int NS2 = (L * P::K2 + NT - 1) / NT;
+        const float2* t2 = tab + TAB1;
+#pragma unroll
+        for (int slot = 0; slot < NS2; ++slot) {
+            const int w = tid + NT * slot;
+            int line, i;
+            split(w, P::K2, line, i);
+            if (w >= L * P::K2 || line >= lines) continue;
+            const int q1 = i / M2, u = i % M2;
+            float2 v[R2];
+#pragma unroll
+            for (int j = 0; j < R2; ++j) v[j] = buf[addr(line, q1, u + M2 * j)];
+            Bfly<R2, INV>::run(v);
+            buf[addr(line, q1, u)] = v[0];
+#pragma unroll
+            for (int q = 1; q < R2; ++q) buf[addr(line, q1, q * M2 + u)] = twmul(v[q], t2[(q - 1) * M2 + u]);
+        }
+        Sync::sync();
+    }
+
+    // ---- pieces for the wave-autonomous MRI passes (mri_wave.hpp): stage 2 alone, the last stage IN PLACE (the output
+    // k = q1 + R1 q2 + R1 Q2N q of an item overwrites the item's input j = q), and the LDS position of output k after it
+    template <class Sync>
+    static __device__ __forceinline__ void v4_stage2(float2* buf, const float2* tw, int lines, int tid) {
+        static_assert(ROW && P::STAGES == 3, "three-stage rows plans");
+        constexpr int R1 = P::R1, R2 = P::R2, M2 = P::M2;
+        constexpr int NS2 = (L * P::K2 + NT - 1) / NT;
+#pragma unroll
+        for (int slot = 0; slot < NS2; ++slot) {
+            const int w = tid + NT * slot;
+            int line, i;
+            split(w, P::K2, line, i);
+            if (w >= L * P::K2 || line >= lines) continue;
+            const int q1 = i / M2, u = i % M2;
+            float2 v[R2];
+#pragma unroll
+            for (int j = 0; j < R2; ++j) v[j] = buf[addr(line, q1, u + M2 * j)];
+            Bfly<R2, INV>::run(v);
+            apply_twiddle_powers<R2, INV>(v, tw[R1 * u]);
+#pragma unroll
+            for (int q = 0; q < R2; ++q) buf[addr(line, q1, q * M2 + u)] = v[q];
+        }
+        Sync::sync();
+    }
+    static __device__ __forceinline__ void last_inplace(float2* buf, int lines, float scale, int tid) {
+        static_assert(ROW && P::STAGES == 3, "three-stage rows plans");
+        constexpr int R1 = P::R1;
+#pragma unroll
+        for (int slot = 0; slot < NSL; ++slot) {
+            const int w = tid + NT * slot;
+            int line, i;
+            split(w, KL, line, i);
+            if (w >= L * KL || line >= lines) continue;
+            const int q1 = i % R1, q2 = i / R1;
+            float2 v[RL];
+#pragma unroll
+            for (int j = 0; j < RL; ++j) v[j] = buf[addr(line, q1, q2 * RL + j)];
+            Bfly<RL, INV>::run(v);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) buf[addr(line, q1, q2 * RL + q)] = cscale(v[q], scale);
+        }
+    }
+    // the last stage with 4 adjacent outputs per emit (as in run_v4), and the same item decomposition without the arithmetic
+    template <class EmitV>
+    static __device__ __forceinline__ void v4_last(float2* buf, int lines, int c, float scale, int tid, EmitV emitv) {
+        static_assert(ROW && P::STAGES == 3, "three-stage rows plans");
+        constexpr int R1 = P::R1, Q2N = P::R2, TL = KL / 4, NSVL = (L * TL + NT - 1) / NT;
+#pragma unroll
+        for (int slot = 0; slot < NSVL; ++slot) {
+            const int w = tid + NT * slot;
+            const int line = w / TL, i0 = (w - line * TL) * 4;
+            if (w >= L * TL || line >= lines) continue;
+            float2 o[RL][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e;
+                const int q1 = i % R1, q2 = i / R1;
+                float2 v[RL];
+#pragma unroll
+                for (int j = 0; j < RL; ++j) v[j] = buf[addr(line, q1, q2 * RL + j)];
+                Bfly<RL, INV>::run(v);
+#pragma unroll
+                for (int q = 0; q < RL; ++q) o[q][e] = cscale(v[q], scale);
+            }
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                int k0 = i0 + R1 * Q2N * q + c;
+                if (k0 >= N) k0 -= N;
+                emitv(slot, line, k0, q, o[q]);
+            }
+        }
+    }
+    template <class F>
+    static __device__ __forceinline__ void v4_last_positions(int lines, int c, int tid, F f) {
+        constexpr int R1 = P::R1, Q2N = P::R2, TL = KL / 4, NSVL = (L * TL + NT - 1) / NT;
+#pragma unroll
+        for (int slot = 0; slot < NSVL; ++slot) {
+            const int w = tid + NT * slot;
+            const int line = w / TL, i0 = (w - line * TL) * 4;
+            if (w >= L * TL || line >= lines) continue;
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                int k0 = i0 + R1 * Q2N * q + c;
+                if (k0 >= N) k0 -= N;
+                f(slot, line, k0, q);
+            }
+        }
+    }
+    static __device__ __forceinline__ int pos_of(int line, int k) {      // where last_inplace left output k of `line`
+        constexpr int R1 = P::R1, R2 = P::R2;
+        const int q1 = k % R1, r = k / R1, q2 = r % R2, q = r / R2;
+        return addr(line, q1, q2 * RL + q);
     }
 
     // ---- ROW-mode variant with 4 adjacent elements per thread on the global side: every global access is a
@@ -545,45 +628,6 @@ __global__ __launch_bounds__(256) void fft_cols_static_kernel(Io io, int64_t Q, 
         TF::run(buf, tw, cols, c, scale, tid,
                 [&](int, int, int, int n) { return io.load(ctx, n); },
                 [&](int, int, int k, int, float2 v) { io.store(ctx, k, v); });
-    }
-}
-
-// column pass with the NEXT tile's stage-1 inputs in flight while the current tile is transformed (persistent workgroups,
-// one register set: the loads are issued right after stage 1 has consumed the registers)
-template <class P, class Io, bool INV, int L>
-__global__ __launch_bounds__(256) void fft_cols_static_pf_kernel(Io io, int64_t Q, int64_t qtiles, int64_t ntiles,
-                                                                 const void* table, int centered, float scale) {
-    using TF = TileFft<P, INV, false, L>;
-    static_assert(P::STAGES > 1, "multi-stage plans only");
-    __shared__ __attribute__((aligned(16))) float2 buf[TF::lds_floats2];
-    const float2* tw = reinterpret_cast<const float2*>(table);
-    const int tid = threadIdx.x;
-    const int c = centered ? P::N / 2 : 0;
-    const int line = tid % L;
-    float2 vin[TF::NS1][P::R1];
-    auto ctx_of = [&](int64_t tile, int& cols) __attribute__((always_inline)) {
-        const int64_t p = tile / qtiles;
-        const int64_t q0 = (tile - p * qtiles) * L;
-        cols = (int)min((int64_t)L, Q - q0);
-        return io.col_ctx(p, q0 + (line < cols ? line : 0));
-    };
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) {
-        int cols;
-        const typename Io::ColCtx ctx = ctx_of(tile, cols);
-        TF::load_inputs(vin, cols, c, tid, [&](int, int, int, int n) { return io.load(ctx, n); });
-    }
-    for (; tile < ntiles; tile += gridDim.x) {
-        int cols;
-        const typename Io::ColCtx ctx = ctx_of(tile, cols);
-        __syncthreads();        // the previous tile's last stage has read `buf`
-        TF::stage1_regs(buf, tw, cols, tid, vin);
-        if (tile + gridDim.x < ntiles) {
-            int ncols;
-            const typename Io::ColCtx nctx = ctx_of(tile + gridDim.x, ncols);
-            TF::load_inputs(vin, ncols, c, tid, [&](int, int, int, int n) { return io.load(nctx, n); });
-        }
-        TF::after_stage1(buf, tw, cols, c, scale, tid, [&](int, int, int k, int, float2 v) { io.store(ctx, k, v); });
     }
 }
 

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fft_rows_wave_kernel(Io io, in
     __shared__ __attribute__((aligned(16))) float2 buf_all[(size_t)WPB * TF::lds_floats2];
     // the twiddle table in LDS (2.5 KB at N = 320, shared by the waves of the workgroup: the only workgroup-wide step of the
     // kernel): a table read is then an LDS read inside the stage instead of a dependent L2 round trip
-    __shared__ __attribute__((aligned(16))) float2 tw[N];
-    for (int i = threadIdx.x; i < N; i += 64 * WPB) tw[i] = reinterpret_cast<const float2*>(table)[i];
+    __shared__ __attribute__((aligned(16))) float2 tw[TF::TAB];        // W^(u q) of the two twiddled stages (fft_static.hpp)
+    TF::fill_twiddle_table(tw, reinterpret_cast<const float2*>(table), threadIdx.x, 64 * WPB);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -98,11 +98,12 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fft_rows_wave_kernel(Io io, in
             float2 x[R1][4];
 #pragma unroll
             for (int j = 0; j < R1; ++j) io.unpack4(raw[j], m[j], x[j]);
-            TF::v4_stage1_item(buf, tw, l1, u0, x);
+            TF::v4_stage1_item_tab(buf, tw, l1, u0, x);
         }
         if (PF && tile + stride < ntiles) issue(tile + stride);      // next tile's loads fly during stages 2, 3 and the stores
         wave_lds_sync();
-        TF::template v4_finish<WaveSync>(buf, tw, lines, c, scale, lane, [&](int, int line, int k0, int, const float2 (&v)[4]) {
+        TF::template v4_stage2_tab<WaveSync>(buf, tw, lines, lane);
+        TF::v4_last(buf, lines, c, scale, lane, [&](int, int line, int k0, int, const float2 (&v)[4]) {
             io.store4(tc, (unsigned)(line * N + k0), v);
         });
     }

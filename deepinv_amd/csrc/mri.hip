@@ -15,9 +15,7 @@
 #include "fft_core.hpp"
 #include "fft_launch.hpp"
 
-#ifndef DINV_EXPAND_PREFETCH
-#define DINV_EXPAND_PREFETCH 0
-#endif
+#include "mri_wave.hpp"
 
 using namespace dinv;
 
@@ -470,7 +468,7 @@ struct ColsCoilLoadIo {
 // one write of t instead of a write, a read and a write (210 of the 630 MB that A moved per call at cfg2).
 // The coils of one (slice, column tile) run on one XCD at the same time (blocks b and b + 8; observed placement, speed
 // only), so x is read from HBM once and from that XCD's L2 seven times.
-template <class P, int L, int NT, bool PF>
+template <class P, int L, int NT>
 __global__ __launch_bounds__(NT) void mri_cols_expand_fwd_kernel(const float* __restrict__ x, const float2* __restrict__ maps,
                                                                   float2* __restrict__ t, int ncoil, int maps_batch, int64_t Q,
                                                                   int64_t qtiles, int64_t nsets, const void* table, float scale) {
@@ -483,24 +481,16 @@ __global__ __launch_bounds__(NT) void mri_cols_expand_fwd_kernel(const float* __
     const int c = N / 2;
     const int64_t vol = (int64_t)N * Q;
     const int64_t padded = ceil_div_dev(nsets, 8) * 8 * ncoil;
-    float4 xr[NI], xi[NI], sa[NI], sb[NI];
-    // tile T -> (slice b, column tile q0, coil n); false for the padding tiles
-    auto decode = [&](int64_t T, int64_t& b, int64_t& q0, int& cols, int& n) __attribute__((always_inline)) {
+    for (int64_t T = blockIdx.x; T < padded; T += gridDim.x) {
         const int64_t chunk = T / (8 * ncoil), within = T - chunk * (8 * ncoil);
         const int64_t set = chunk * 8 + within % 8;
-        n = (int)(within / 8);
-        if (set >= nsets) return false;
-        b = set / qtiles;
-        q0 = (set - b * qtiles) * L;
-        cols = (int)min((int64_t)L, Q - q0);
-        return true;
-    };
-    auto issue = [&](int64_t T) __attribute__((always_inline)) {
-        int64_t b, q0;
-        int cols, n;
-        if (!decode(T, b, q0, cols, n)) return;
+        const int n = (int)(within / 8);
+        if (set >= nsets) continue;
+        const int64_t b = set / qtiles, q0 = (set - b * qtiles) * L;
+        const int cols = (int)min((int64_t)L, Q - q0);
         const float* xre = x + (b * 2) * vol + q0;
         const float2* sp = maps ? maps + ((maps_batch > 1 ? b : 0) * ncoil + n) * vol + q0 : nullptr;
+        float4 xr[NI], xi[NI], sa[NI], sb[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int item = tid + NT * i, row = item / QL, quad = item - row * QL;
@@ -513,37 +503,22 @@ __global__ __launch_bounds__(NT) void mri_cols_expand_fwd_kernel(const float* __
                 sb[i] = reinterpret_cast<const float4*>(sp + o)[1];
             }
         }
-    };
-    int64_t T = blockIdx.x;
-    if (PF && T < padded) issue(T);
-    for (; T < padded; T += gridDim.x) {
-        int64_t b = 0, q0 = 0;
-        int cols = 0, n = 0;
-        const bool valid = decode(T, b, q0, cols, n);
-        if (!PF) {
-            if (!valid) continue;
-            issue(T);
-        }
         __syncthreads();   // the previous tile's last stage has left the LDS tile
-        if (valid) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int item = tid + NT * i, row = item / QL, quad = item - row * QL;
-                if (item >= N * QL) continue;
-                float2 v[4] = {make_float2(xr[i].x, xi[i].x), make_float2(xr[i].y, xi[i].y), make_float2(xr[i].z, xi[i].z),
-                               make_float2(xr[i].w, xi[i].w)};
-                if (maps) {
-                    v[0] = cmul(make_float2(sa[i].x, sa[i].y), v[0]);
-                    v[1] = cmul(make_float2(sa[i].z, sa[i].w), v[1]);
-                    v[2] = cmul(make_float2(sb[i].x, sb[i].y), v[2]);
-                    v[3] = cmul(make_float2(sb[i].z, sb[i].w), v[3]);
-                }
-                st_c4(buf + row * L + 4 * quad, v);
+        for (int i = 0; i < NI; ++i) {
+            const int item = tid + NT * i, row = item / QL, quad = item - row * QL;
+            if (item >= N * QL) continue;
+            float2 v[4] = {make_float2(xr[i].x, xi[i].x), make_float2(xr[i].y, xi[i].y), make_float2(xr[i].z, xi[i].z),
+                           make_float2(xr[i].w, xi[i].w)};
+            if (sp) {
+                v[0] = cmul(make_float2(sa[i].x, sa[i].y), v[0]);
+                v[1] = cmul(make_float2(sa[i].z, sa[i].w), v[1]);
+                v[2] = cmul(make_float2(sb[i].x, sb[i].y), v[2]);
+                v[3] = cmul(make_float2(sb[i].z, sb[i].w), v[3]);
             }
+            st_c4(buf + row * L + 4 * quad, v);
         }
-        if (PF && T + gridDim.x < padded) issue(T + gridDim.x);   // the next tile's loads fly during the transform
         __syncthreads();
-        if (!valid) continue;        // (workgroup-uniform)
         float2* o = t + (b * ncoil + n) * vol + q0 + (line < cols ? line : 0);
         TF::template run<true>(buf, tw, cols, c, scale, tid,
                                [&](int, int, int, int nn) { return buf[nn * L + line]; },
@@ -687,15 +662,7 @@ int launch_cols_expand_fwd(const float* x, const float2* maps, float2* t, int64_
         // (measured at cfg2: 111 us; 512 threads / 148 VGPRs = one workgroup per CU: 135 us; 512 threads capped at 128
         // VGPRs (spills): 171 us)
         constexpr int NT = 256;
-#if DINV_EXPAND_PREFETCH
-        if (padded > DINV_COLS_PF_GRID) {     // persistent workgroups, the next tile's loads in flight during the transform
-            hipLaunchKernelGGL((mri_cols_expand_fwd_kernel<P, L, NT, true>), dim3(DINV_COLS_PF_GRID), dim3(NT), 0, s, x, maps, t, ncoil,
-                               maps_batch, Q, qtiles, nsets, table, scale);
-            DINV_CHECK_LAUNCH();
-            return 0;
-        }
-#endif
-        hipLaunchKernelGGL((mri_cols_expand_fwd_kernel<P, L, NT, false>), dim3(grid), dim3(NT), 0, s, x, maps, t, ncoil, maps_batch, Q,
+        hipLaunchKernelGGL((mri_cols_expand_fwd_kernel<P, L, NT>), dim3(grid), dim3(NT), 0, s, x, maps, t, ncoil, maps_batch, Q,
                            qtiles, nsets, table, scale);
         DINV_CHECK_LAUNCH();
         return 0;
@@ -837,6 +804,9 @@ extern "C" int dinv_mri_forward(const dinv_mri_desc* d, const float* x, const fl
     const int64_t R = vol / W;
     float2* t = reinterpret_cast<float2*>(workspace);
     const int64_t P = (int64_t)d->batch * d->coils;
+#ifndef DINV_NO_WAVE2D
+    if (mriw::wave2d_ok(d, 0)) return mriw::run_wave2d(d, 0, x, reinterpret_cast<const float2*>(maps), mask, y, t, s);
+#endif
 
     if (all_static(d)) {
         const float2* mp = reinterpret_cast<const float2*>(maps);
@@ -891,6 +861,9 @@ extern "C" int dinv_mri_adjoint(const dinv_mri_desc* d, const float* y, const fl
     const int64_t R = vol / W;
     float2* t = reinterpret_cast<float2*>(workspace);
     const int64_t P = (int64_t)d->batch * d->coils;
+#ifndef DINV_NO_WAVE2D
+    if (mriw::wave2d_ok(d, 1)) return mriw::run_wave2d(d, 1, y, reinterpret_cast<const float2*>(maps), mask, x, t, s);
+#endif
 
     if (all_static(d)) {
         RowsPlanarMaskLoadIo lio{y, mask, t, d->coils, d->mask_batch, R, W, 0, 0};
@@ -988,6 +961,9 @@ extern "C" int dinv_mri_normal(const dinv_mri_desc* d, const float* x, const flo
     float2* t = reinterpret_cast<float2*>(workspace);
     const int64_t P = (int64_t)d->batch * d->coils;
     const float2* mp = reinterpret_cast<const float2*>(maps);
+#ifndef DINV_NO_WAVE2D
+    if (mriw::wave2d_ok(d, 2)) return mriw::run_wave2d(d, 2, x, mp, mask, out, t, s);
+#endif
     const float scw = 1.0f / sqrtf((float)W);
     const int64_t N0 = d->dims[0], Q0 = vol / N0;
     const float sc0 = 1.0f / sqrtf((float)N0);

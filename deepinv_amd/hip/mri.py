@@ -14,8 +14,14 @@ import torch
 from . import MriDesc, check, f32c, fft_plan, lib, ptr, require_hip, stream_ptr
 
 
+# Test hook (dinv_mri_desc.reserved = 1): take the wave-autonomous 2-D pipelines (csrc/mri_wave.hpp) whenever the sizes allow,
+# also below the batch size from which the library picks them for A^T / A^T A on its own.
+FORCE_WAVE_PIPELINES = False
+
+
 def _desc(batch, coils, vol, mask, maps, coil_dim, device):
     d = MriDesc()
+    d.reserved = 1 if FORCE_WAVE_PIPELINES else 0
     d.batch, d.coils, d.ndim = int(batch), int(coils), len(vol)
     keep = []
     for i, n in enumerate(vol):

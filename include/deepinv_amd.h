@@ -79,7 +79,8 @@ typedef struct {
     int32_t maps_batch;  /* 0 = no coil maps, 1 = shared, B = per-sample; maps are [mb,N,vol] c64 */
     int32_t coil_dim;    /* 1: k-space has a coil dim  [B,2,N,vol] (MultiCoilMRI);
                             0: k-space is [B,2,vol] (single-coil MRI, coils must be 1) */
-    int32_t reserved;
+    int32_t reserved;    /* 0.  (1 = take the wave-autonomous 2-D pipelines of csrc/mri_wave.hpp whenever the sizes allow, also
+                            below the batch size from which they pay off: lets tests reach them with small inputs) */
     dinv_fft_plan plan[3];     /* one per transformed dim, same order as dims */
     const void*   table[3];    /* device tables matching plan[] */
 } dinv_mri_desc;

@@ -12,7 +12,7 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   mkdir -p $V/obj_$name
   for f in mri fft; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast $flags -c deepinv_amd/csrc/$f.hip -o $V/obj_$name/$f.o 2>&1 | grep -E "error" || true &
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast -fno-slp-vectorize $flags -c deepinv_amd/csrc/$f.hip -o $V/obj_$name/$f.o 2>&1 | grep -E "error" || true &
   done
   wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/lib$name.so $V/obj_$name/mri.o $V/obj_$name/fft.o $OTHERS

@@ -30,6 +30,7 @@ def _desc(B, N, vol, mask, maps, coil_dim=1):
     d.mask_batch = 0 if mask is None else mask.shape[0]
     d.maps_batch = 0 if maps is None else maps.shape[0]
     d.coil_dim = coil_dim
+    d.reserved = 1      # reach the wave-autonomous 2-D pipelines (csrc/mri_wave.hpp) at these small batches too
     return d, keep
 
 
@@ -63,7 +64,8 @@ def _run(fn, d, *ptrs):
 
 
 CASES = [((32, 64), 2, 3, 1), ((64, 32), 1, 2, 2), ((16, 32, 32), 1, 2, 1), ((17, 11), 2, 3, 1), ((128, 32), 1, 1, 1),
-         ((24, 40), 1, 2, 1), ((320, 64), 1, 2, 1), ((64, 256), 1, 1, 1), ((32, 320), 2, 2, 2), ((32, 512), 1, 2, 1),
+         ((24, 40), 1, 2, 1), ((320, 64), 1, 2, 1), ((64, 256), 1, 1, 1), ((32, 320), 2, 2, 2), ((32, 512), 1, 2, 1), ((256, 256), 1, 2, 1), ((320, 320), 2, 2, 2), ((320, 256), 1, 1, 1),
+         ((256, 320), 1, 2, 1), ((512, 256), 1, 1, 1),
          ((16, 16, 256), 1, 2, 1)]
 
 

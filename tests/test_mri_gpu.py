@@ -83,6 +83,41 @@ def test_multicoil_mri(dev, img, three_d, coils, batched):
     assert rel_err(xr, O.multicoil_AT_rss(y_ref, mask, three_d)) < TOL
 
 
+@pytest.mark.parametrize("img,coils,B", [((320, 320), 8, 3), ((256, 256), 4, 2), ((320, 256), 2, 2), ((256, 512), 3, 1), ((512, 320), 2, 1)])
+def test_wave_pipelines_against_oracle_and_cooperative_pipelines(dev, img, coils, B, monkeypatch):
+    """The two families of 2-D pipelines behind dinv_mri_forward / _adjoint / _normal - wave-autonomous (csrc/mri_wave.hpp:
+    rows pass with the radix-R column stage as its epilogue + 64-point column pass) and workgroup-cooperative (csrc/mri.hip) -
+    on the same inputs: each against the CPU oracle (deepinv/physics/mri.py:254-324), the dot test, A^T A against A^T(A x),
+    and against each other.  (The library picks the wave family for A always, for A^T / A^T A from 16 slices up; the test
+    hook forces it.)"""
+    import deepinv_amd as dinv
+    from deepinv_amd.hip import mri as M
+
+    g = _g(7)
+    x = torch.randn(B, 2, *img, generator=g)
+    maps = torch.randn(1, coils, *img, dtype=torch.complex64, generator=g) / coils ** 0.5
+    mask = (torch.rand(1, 1, *img, generator=g) > 0.6).float()
+    v = torch.randn(B, 2, coils, *img, generator=g)
+    y_ref = O.multicoil_A(x, maps, mask)
+    xa_ref = O.multicoil_AT(v, maps, mask)
+    xn_ref = O.multicoil_AT(y_ref, maps, mask)
+    outs = {}
+    for force in (True, False):
+        monkeypatch.setattr(M, "FORCE_WAVE_PIPELINES", force)
+        phys = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, *img), device=dev)
+        y = phys.A(x.to(dev))
+        assert rel_err(y, y_ref) < TOL
+        assert torch.all(y.cpu()[O.check_mask(mask)[:, :, None].expand_as(y_ref) == 0] == 0)      # exact zeros under the mask
+        xa = phys.A_adjoint(v.to(dev))
+        assert rel_err(xa, xa_ref) < TOL
+        xn = phys.A_adjoint_A(x.to(dev))
+        assert rel_err(xn, xn_ref) < TOL
+        assert dot_test(phys, x.to(dev), y) < 1e-5
+        outs[force] = (y.cpu(), xa.cpu(), xn.cpu())
+    for a, b in zip(outs[True], outs[False]):
+        assert rel_err(a, b) < 1e-5
+
+
 def test_mask_update_persists_and_autograd(dev):
     import deepinv_amd as dinv
 
