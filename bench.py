@@ -194,7 +194,7 @@ def main():
     op_row("MultiCoilMRI.A_adjoint_A", "cfg2", B_local, lambda: physics.A_adjoint_A(x_true), 2 * B_local * 2 * H * W * 4
            + args.coils * H * W * 8 + 2 * H * W * 4)
     if world == 1 and not args.no_other_configs:
-        other_config_ops(dinv, device, op_row, lambda: ops[-1], loop_row)
+        other_config_ops(dinv, device, op_row, lambda: ops[-1], loop_row, ops.append)
 
     if rank == 0:
         slices_per_s = args.batch * args.steps / elapsed
@@ -403,7 +403,7 @@ def drunet3d_forward_flops(den, vol):
     return total
 
 
-def other_config_ops(dinv, device, op_row, ops_last, loop_row):
+def other_config_ops(dinv, device, op_row, ops_last, loop_row, loop_rows_append):
     """operator rows of BASELINE configs[2..4] at their per-GPU shard shapes (SURVEY 8d byte counts);
     the Radon rows also carry bilinear samples/s (that operator is gather-rate bound, not HBM bound)"""
     g = torch.Generator().manual_seed(0)
@@ -491,17 +491,27 @@ def other_config_ops(dinv, device, op_row, ops_last, loop_row):
     op_row("Downsampling.A", "cfg5", B, lambda: phys.A(x), alg)
     op_row("Downsampling.A_adjoint", "cfg5", B, lambda: phys.A_adjoint(y), alg)
     op_row("Downsampling.prox_l2", "cfg5", B, lambda: phys.prox_l2(z, y, 0.7), 2 * B * 3 * 256 * 256 * 4 + B * 3 * 64 * 64 * 4)
-    # cfg5's loop at its per-GPU shard: DiffPIR, 100 steps, DRUNet(3->3) (277.6 GFLOP per 256x256 call), closed-form prox
-    torch.manual_seed(0)
-    den5 = dinv.models.DRUNet(3, 3, pretrained=None).to(device).eval()
-    nphys = dinv.physics.Downsampling(img_size=img, filter="bicubic", factor=4, padding="circular", device=device,
-                                      noise_model=dinv.physics.GaussianNoise(0.05))
-    sampler = dinv.sampling.DiffPIR(den5, dinv.optim.L2(), sigma=0.05, max_iter=100, zeta=0.1, lambda_=7.0, device=device)
-    yn = nphys(x)
-    for prec in ("fp32", "bf16split"):
-        den5.conv_precision = prec
-        loop_row("DiffPIR 100 steps + DRUNet(3->3): loop" + ("" if prec == "fp32" else " [bf16split]"), "cfg5", B,
-                 lambda: sampler(yn, nphys, seed=0), 100 * 277.6 * B, unit="images_per_s", precision=prec)
+    # cfg5's loop at its per-GPU shard: DiffPIR, 100 steps, DRUNet(3->3) (277.6 GFLOP per 256x256 call), closed-form prox.  The
+    # problem is the one of tests/golden/cfg5_full.npz (made by tests/golden/make_golden_r5.py through the REAL reference: image 0,
+    # its measurement noise, the denoiser weights and the torch.randn_like stream are regenerated from the stored seeds), so the row
+    # carries the FULL-LENGTH parity of image 0 against deepinv.sampling.DiffPIR and against the fp64 evaluation of the same sample
+    # path (checker only; the same helper is the body of tests/test_named_shapes_gpu.py::test_cfg5_diffpir_full_length_100_steps).
+    del phys, x, y, z
+    fixture = os.path.join(ROOT, "tests", "golden", "cfg5_full.npz")
+    if os.path.exists(fixture):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_named_shapes_gpu as NS
+        d5 = NS.load("cfg5_full")
+        res5 = NS.full_length_cfg5(dinv, device, d5, B=B, precisions=("fp32", "bf16split"), runs=2)
+        for prec, r in res5.items():
+            loop_rows_append({"op": "DiffPIR 100 steps + DRUNet(3->3): loop" + ("" if prec == "fp32" else " [bf16split]"), "config": "cfg5",
+                              "batch": B, "ms": round(r["seconds"] * 1e3, 1), "images_per_s": round(B / r["seconds"], 3),
+                              "denoiser_TFLOP_per_s": round(100 * 277.6 * B / r["seconds"] / 1e3, 1), "conv_precision": prec,
+                              "finite": r["finite"], "parity_rel_err": float(f"{r['vs_reference']:.3e}"),
+                              "parity_rel_err_vs_fp64": float(f"{r['vs_fp64']:.3e}"),
+                              "parity": "image 0 of the shard after all 100 steps against deepinv.sampling.DiffPIR on the same seeds "
+                                        "(tests/golden/cfg5_full.npz); the reference's own fp32 rounding along this path is "
+                                        f"{float(d5['out_err_vs_exact']):.1e} (its distance to the fp64 evaluation)"})
 
 
 def _pgd_cpu(sd, maps, mask, y, iters):

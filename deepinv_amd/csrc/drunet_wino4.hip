@@ -579,6 +579,13 @@ void conv3x3_wino4_kernel(W4Args a) {
 #undef DINV_STAMP
 }
 
+// what the calling thread's last launch did with its tail (dinv_conv3x3_winograd4_last_split: tests, diagnostics)
+struct LastSplit { int32_t split_f, ntail; };
+LastSplit& last_split() {
+    static thread_local LastSplit v{1, 0};
+    return v;
+}
+
 template <int TH, int TW, bool RELU, int NRES>
 int launch_shape(W4Args a, hipStream_t st) {
     using S = Shape4<TH, TW>;
@@ -606,6 +613,7 @@ int launch_shape(W4Args a, hipStream_t st) {
         configured.fetch_or(bit, std::memory_order_relaxed);
     }
     const int cpx = cus_per_xcd(dev);
+    DINV_REQUIRE(cpx <= 64, "winograd F(4,3) conv: the ticket area of the tail split holds 64 tiles per XCD (device has %d CUs per XCD)", cpx);
     // whole rounds of cpx tiles per XCD, then the tail: cut along the input channels when a workspace was given
     const int64_t ntail = a.per_xcd % cpx;
     a.split_f = 1;
@@ -614,6 +622,7 @@ int launch_shape(W4Args a, hipStream_t st) {
             if (ntail * f <= cpx && a.ncb % f == 0 && (a.ncb / f) % 2 == 0) { a.split_f = f; break; }
     a.ntail = a.split_f > 1 ? (int32_t)ntail : 0;
     a.full_x = (int32_t)(a.per_xcd - a.ntail);
+    last_split() = {a.split_f, a.ntail};
     if (a.full_x > 0) {
         a.slots = (int32_t)(a.full_x < cpx ? a.full_x : cpx);
         hipLaunchKernelGGL(kern, dim3((unsigned)(a.slots * 8)), dim3(NTHR), shm, st, a);
@@ -665,6 +674,12 @@ extern "C" size_t dinv_conv3x3_winograd4_workspace_bytes(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     return w4_ws_tickets() + (size_t)8 * cus_per_xcd(dev) * 8192 * 16;
+}
+
+extern "C" int dinv_conv3x3_winograd4_last_split(int32_t* split_f, int32_t* n_tail_tiles) {
+    if (split_f) *split_f = last_split().split_f;
+    if (n_tail_tiles) *n_tail_tiles = last_split().ntail;
+    return 0;
 }
 
 extern "C" int dinv_conv3x3_winograd4(const dinv_act_geom* g, const float* x, const float* w_wino4, int32_t cin,

@@ -39,6 +39,7 @@ def _l():
         l.dinv_conv3x3_winograd4.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp, ctypes.c_size_t, vp]
         l.dinv_conv3x3_winograd4_workspace_bytes.restype = ctypes.c_size_t
         l.dinv_conv3x3_winograd4_workspace_bytes.argtypes = []
+        l.dinv_conv3x3_winograd4_last_split.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(i32)]
         l.dinv_conv3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_wsplit.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3x3_split.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, i32, vp]
@@ -431,13 +432,27 @@ _W4_WS: dict = {}
 
 
 def winograd4_workspace(device) -> torch.Tensor:
-    """the per-device workspace of dinv_conv3x3_winograd4's tail split (zero-filled once; the library keeps its ticket words
-    zero between launches; launches on one stream are ordered, so one buffer serves every layer)"""
-    key = torch.device(device)
+    """the workspace of dinv_conv3x3_winograd4's tail split for the CURRENT stream of `device` (zero-filled once; the library
+    keeps its ticket words zero between launches).  Launches on one stream are ordered, so one buffer serves every layer issued
+    there; two streams of a device must not share one (their tail parts would take each other's tickets and partial outputs),
+    hence the key (device, stream)."""
+    device = torch.device(device)
+    if device.type == "cuda":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    else:
+        key = (str(device), 0)
     ws = _W4_WS.get(key)
     if ws is None:
         ws = _W4_WS[key] = torch.zeros(_l().dinv_conv3x3_winograd4_workspace_bytes(), device=device, dtype=torch.uint8)
     return ws
+
+
+def winograd4_last_split():
+    """(parts per tail tile, tail tiles per XCD) of this thread's last conv3x3_winograd4 launch"""
+    f, n = ctypes.c_int32(0), ctypes.c_int32(0)
+    check(_l().dinv_conv3x3_winograd4_last_split(ctypes.byref(f), ctypes.byref(n)))
+    return f.value, n.value
 
 
 def conv3x3_winograd4(g, x, wino4, cin, cout, y, res1=None, relu=False, workspace=None):

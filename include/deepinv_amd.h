@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 6 = this header (adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 7 = this header (adds dinv_conv3x3_winograd4_last_split and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -183,6 +183,9 @@ size_t dinv_conv3x3_winograd4_workspace_bytes(void);
 int dinv_conv3x3_winograd4(const dinv_act_geom* g, const float* x, const float* w_wino4, int32_t cin, int32_t cout,
                            float* y, const float* res1, int32_t relu, void* workspace, size_t workspace_bytes,
                            dinv_stream_t stream);
+/* What the calling thread's last dinv_conv3x3_winograd4 did with its incomplete last round: the number of parts each tail tile
+ * was cut into (1 = not cut) and the tail tiles per XCD (tests and diagnostics; either pointer may be NULL). */
+int dinv_conv3x3_winograd4_last_split(int32_t* split_f, int32_t* n_tail_tiles);
 /* Same operator on the BF16 matrix cores with a two-part exact operand split (x = xh + xl with xh = bf16(x),
  * xl = bf16(x - xh); three products ah*bl + al*bh + ah*bh, fp32 accumulate): per output
  * |y - y_exact| <= 3 * 2^-16 * (|w| conv |x|), 2-4e-6 relative per layer on random data (csrc/drunet_split2d.hip: 2-D pixel

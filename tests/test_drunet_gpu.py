@@ -162,6 +162,96 @@ def test_winograd4_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
     assert full[:, :, :, 0].abs().max() == 0 and full[:, :, :, W + 1:].abs().max() == 0
 
 
+def _w4_case(dev, B, H, W, cin, cout, seed):
+    from deepinv_amd.hip import drunet as K
+
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)).to(dev)
+    r = torch.randn(B, cout, H, W, generator=g).to(dev)
+    geo = K.geom(B, H, W)
+
+    def to_act(t):
+        a = K.alloc(geo, t.shape[1], dev)
+        a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:W + 1] = t.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    return geo, to_act(x), to_act(r), K.pack_winograd4_weight(w), x, w, r
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,parts", [(4, 40, 40, 128, 64, 8), (8, 40, 40, 64, 64, 4), (8, 40, 40, 32, 64, 2),
+                                                   (32, 40, 40, 512, 512, 8), (4, 80, 80, 256, 256, 4)])
+@pytest.mark.parametrize("mode", ["relu", "res"])
+def test_winograd4_tail_split_direct(dev, B, H, W, cin, cout, parts, mode):
+    """The tail split of the F(4x4) kernel (csrc/drunet_wino4.hip, SPLIT = true: the tiles of the last incomplete round cut into
+    2 / 4 / 8 parts along the input channels, partial outputs + ticket + ordered combine - the only cross-workgroup
+    release / acquire protocol in the product) called DIRECTLY: shapes that force every split factor (checked through
+    dinv_conv3x3_winograd4_last_split), against the un-split launch of the same kernel (same arithmetic, other summation
+    order: 1e-6) and an fp64 convolution, 100 back-to-back launches re-using one workspace (bit-identical every time), and
+    the ticket words back at zero afterwards."""
+    from deepinv_amd.hip import drunet as K
+
+    geo, xa, ra, wp, x, w, r = _w4_case(dev, B, H, W, cin, cout, seed=B * 7 + cin)
+    res = ra if mode == "res" else None
+    y0, y1 = K.alloc(geo, cout, dev), K.alloc(geo, cout, dev)
+    K.conv3x3_winograd4(geo, xa, wp, cin, cout, y0, res1=res, relu=mode == "relu")                # no workspace: never split
+    assert K.winograd4_last_split()[0] == 1
+    ws = torch.zeros(K._l().dinv_conv3x3_winograd4_workspace_bytes(), device=dev, dtype=torch.uint8)
+    K.conv3x3_winograd4(geo, xa, wp, cin, cout, y1, res1=res, relu=mode == "relu", workspace=ws)
+    f, ntail = K.winograd4_last_split()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    if cus == 256:
+        assert f == parts and ntail > 0, (f, ntail)
+    else:
+        assert f >= 1
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    ref = ref.relu() if mode == "relu" else ref + r.double()
+    got = y1[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W)
+    assert rel_err(got, ref) < 1e-5
+    assert rel_err(y1, y0) < 1e-6                     # partial sums combined in part order: same products, other association
+    tickets = ws[:8 * 64 * 4].view(torch.int32)
+    assert int(tickets.abs().max()) == 0              # every ticket word reset by the last arriver
+    for _ in range(100):                              # back to back on one stream, one workspace
+        y2 = K.alloc(geo, cout, dev)
+        K.conv3x3_winograd4(geo, xa, wp, cin, cout, y2, res1=res, relu=mode == "relu", workspace=ws)
+        assert torch.equal(y2, y1)
+    assert int(tickets.abs().max()) == 0
+
+
+def test_winograd4_tail_split_two_streams(dev):
+    """two convolutions with tail splits in flight on two streams at once, each with the workspace of its own stream
+    (hip/drunet.py: winograd4_workspace is keyed by device AND stream): results bit-identical to the serial ones"""
+    from deepinv_amd.hip import drunet as K
+
+    cases = [_w4_case(dev, 4, 40, 40, 128, 64, seed=1), _w4_case(dev, 8, 40, 40, 64, 128, seed=2)]
+    dims = [(128, 64), (64, 128)]
+    serial = []
+    for (geo, xa, ra, wp, *_), (ci, co) in zip(cases, dims):
+        y = K.alloc(geo, co, dev)
+        K.conv3x3_winograd4(geo, xa, wp, ci, co, y, res1=ra, workspace=K.winograd4_workspace(dev))
+        assert K.winograd4_last_split()[0] > 1
+        serial.append(y)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = [[], []]
+    for rep in range(20):
+        for i, ((geo, xa, ra, wp, *_), (ci, co)) in enumerate(zip(cases, dims)):
+            with torch.cuda.stream(streams[i]):
+                y = K.alloc(geo, co, dev)
+                ws = K.winograd4_workspace(dev)
+                K.conv3x3_winograd4(geo, xa, wp, ci, co, y, res1=ra, workspace=ws)
+                outs[i].append(y)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(streams[0]):
+        w0 = K.winograd4_workspace(dev)
+    with torch.cuda.stream(streams[1]):
+        w1 = K.winograd4_workspace(dev)
+    assert w0.data_ptr() != w1.data_ptr() != K.winograd4_workspace(dev).data_ptr()
+    for i in range(2):
+        for y in outs[i]:
+            assert torch.equal(y, serial[i])
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,skip", [(2, 9, 21, 16, 2, True), (1, 19, 70, 8, 1, False), (1, 8, 130, 16, 3, True),
                                                  (3, 17, 62, 24, 4, True), (4, 320, 320, 64, 2, True), (1, 5, 63, 8, 2, False)])
 def test_tail_conv_lane_shift(dev, B, H, W, cin, cout, skip):

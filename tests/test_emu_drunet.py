@@ -706,6 +706,13 @@ def test_winograd4_conv_matches_fp64(B, H, W, cin, cout, mode, split):
                                          E.p(ra) if mode == "res" else None, 1 if mode == "relu" else 0, E.p(ws),
                                          ctypes.c_size_t(0 if ws is None else ws.numel()), None))
     assert not torch.isnan(ya).any()
+    f, nt = ctypes.c_int32(0), ctypes.c_int32(0)
+    E.check(l.dinv_conv3x3_winograd4_last_split(ctypes.byref(f), ctypes.byref(nt)))
+    if split:
+        assert int(ws[:8 * 64 * 4].view(torch.int32).abs().max()) == 0      # the last arriver of every tile reset its ticket
+        assert (f.value > 1) == (nt.value > 0)
+    else:
+        assert f.value == 1 and nt.value == 0
     out = from_act(ya, g, cout)
     err = float((out.double() - ref).norm() / ref.norm())
     assert err < 1e-5, err

@@ -134,7 +134,7 @@ def test_cfg5_downsampling_diffpir_256(dev, monkeypatch):
     assert rel_err(sub(out, st), d["out_exact"]) < TOL       # ... and against the fp64 evaluation of the same sample path
 
 
-def full_length_cfg5(dinv, dev, d, B=16, precisions=None):
+def full_length_cfg5(dinv, dev, d, B=16, precisions=None, runs=1):
     """BASELINE configs[4] at FULL length on the per-GPU shard (16 images 3x256x256): 100-step DiffPIR, unit 0 = the fixture's
     seeded image with the fixture's torch.randn_like draws replayed (the other units get different images and draws).  Returns
     {precision: (rel. error vs the reference's sample, vs the fp64 evaluation of the same sample path, trace errors)}.
@@ -157,26 +157,34 @@ def full_length_cfg5(dinv, dev, d, B=16, precisions=None):
     from deepinv_amd.models.drunet import CONV_PRECISIONS
     for prec in precisions or CONV_PRECISIONS:
         den.conv_precision = prec
-        trace = []
-        hook = den.register_forward_hook(lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt].cpu()))
-        g0, g1 = gen(74), gen(704)
+        import time
+        sampler = dinv.sampling.DiffPIR(den, dinv.optim.L2(), sigma=0.05, max_iter=int(d["steps"]), zeta=0.1, lambda_=7.0, device=dev)
+        assert torch.equal(sampler.seq.cpu(), d["seq"])
+        for _ in range(runs):       # (the last run is the one timed and compared: the first also packs weights and allocates)
+            trace = []
+            hook = den.register_forward_hook(lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt]))
+            # the Gaussian draws of the whole run, made BEFORE the timed region (unit 0 replays the reference's generator stream,
+            # the rest of the shard has its own): resident in HBM like every other input
+            g0, g1 = gen(74), gen(704)
+            pool = [torch.cat((torch.randn(1, *img, generator=g0), torch.randn(B - 1, *img, generator=g1))).to(dev)
+                    for _ in range(int(d["steps"]) + 1)]
+            pool.reverse()
 
-        def draws(t, **kw):      # unit 0 replays the reference's generator stream, the rest of the shard has its own
-            return torch.cat((torch.randn(1, *t.shape[1:], generator=g0), torch.randn(t.shape[0] - 1, *t.shape[1:], generator=g1))).to(t.device)
+            def draws(t, **kw):
+                assert tuple(t.shape) == (B, *img)
+                return pool.pop()
 
-        torch.randn_like = draws
-        try:
-            sampler = dinv.sampling.DiffPIR(den, dinv.optim.L2(), sigma=0.05, max_iter=int(d["steps"]), zeta=0.1, lambda_=7.0, device=dev)
-            assert torch.equal(sampler.seq.cpu(), d["seq"])
-            torch.cuda.synchronize()
-            import time
-            t0 = time.perf_counter()
-            out = sampler(yn, p)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-        finally:
-            torch.randn_like = orig
-            hook.remove()
+            torch.randn_like = draws
+            try:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = sampler(yn, p)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            finally:
+                torch.randn_like = orig
+                hook.remove()
+        trace = [t.cpu() for t in trace]
         tr = torch.stack(trace)
         res[prec] = {"vs_reference": rel_err(sub(out[:1], st), d["out"]), "vs_fp64": rel_err(sub(out[:1], st), d["out_exact"]),
                      "trace_vs_fp64_max": max(rel_err(a, b) for a, b in zip(tr, d["den_outs_exact"])), "seconds": dt,
