@@ -13,9 +13,7 @@ where it serves as an independent GPU reference).
 """
 from __future__ import annotations
 
-from itertools import chain
 
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -63,29 +61,40 @@ def weights_init_drunet(m):
         nn.init.orthogonal_(m.weight.data, gain=0.2)
 
 
-def test_pad(model, L, modulo=16):
-    """replicate-pad bottom/right to a multiple of `modulo`, run, crop (models/utils.py:49-61)"""
-    spatials = L.size()[2:]
-    padding = tuple(int(np.ceil(s / modulo) * modulo - s) for s in spatials)
-    padding = tuple(chain.from_iterable((0, v) for v in reversed(padding)))
-    L = {2: nn.ReplicationPad2d, 3: nn.ReplicationPad3d}[len(spatials)](padding)(L)
-    E = model(L)
-    return E[(...,) + tuple(slice(0, s) for s in spatials)]
+def run_replicate_padded(net, x, multiple=16):
+    """Evaluate `net` on `x` grown (edge replication, at the far end of every spatial axis) to the next multiple of `multiple`,
+    and give back the original extent - what the reference does for shapes its U-Net cannot take directly
+    (deepinv/models/drunet.py:252-256 -> models/utils.py:49-61)."""
+    extent = tuple(x.shape[2:])
+    grow = [(-n) % multiple for n in extent]
+    pads = []
+    for extra in reversed(grow):            # F.pad lists the last axis first, (near, far) per axis
+        pads += [0, extra]
+    out = net(nn.functional.pad(x, pads, mode="replicate")) if any(grow) else net(x)
+    return out[(slice(None), slice(None)) + tuple(slice(0, n) for n in extent)]
 
 
-def test_onesplit(model, L, refield=32, sf=1):
-    """four overlapping quadrants (models/utils.py:64-98)"""
-    h, w = L.size()[-2:]
-    hh, ww = (h // 2 // refield + 1) * refield, (w // 2 // refield + 1) * refield
-    top, bottom, left, right = slice(0, hh), slice(h - hh, h), slice(0, ww), slice(w - ww, w)
-    Es = [model(L[..., a, b]) for a in (top, bottom) for b in (left, right)]
-    b, c = Es[0].size()[:2]
-    E = torch.zeros(b, c, sf * h, sf * w).type_as(L)
-    E[..., : h // 2 * sf, : w // 2 * sf] = Es[0][..., : h // 2 * sf, : w // 2 * sf]
-    E[..., : h // 2 * sf, w // 2 * sf: w * sf] = Es[1][..., : h // 2 * sf, (-w + w // 2) * sf:]
-    E[..., h // 2 * sf: h * sf, : w // 2 * sf] = Es[2][..., (-h + h // 2) * sf:, : w // 2 * sf]
-    E[..., h // 2 * sf: h * sf, w // 2 * sf: w * sf] = Es[3][..., (-h + h // 2) * sf:, (-w + w // 2) * sf:]
-    return E
+def run_four_windows(net, x, field=32):
+    """Evaluate `net` on the four corner windows of a 2-D input - each reaching `field`-aligned past the centre, so that the half
+    of the image a window is responsible for lies at least a receptive field away from its cut - and stitch the four owned
+    halves together (the reference's strategy for large shapes that are not multiples of 8: drunet.py:257-262 ->
+    models/utils.py:64-98)."""
+    H, W = x.shape[-2:]
+    span = lambda n: (n // 2 // field + 1) * field
+    out = None
+    for top in (True, False):
+        rows = slice(0, span(H)) if top else slice(H - span(H), H)
+        for left in (True, False):
+            cols = slice(0, span(W)) if left else slice(W - span(W), W)
+            piece = net(x[..., rows, cols])
+            if out is None:
+                out = piece.new_zeros(*piece.shape[:2], H, W)
+            # a near window owns the first half of the axis (the first n // 2 entries of its output), a far window the rest
+            # (the last n - n // 2 entries of its output)
+            pr = slice(0, H // 2) if top else slice(piece.shape[-2] - (H - H // 2), piece.shape[-2])
+            pc = slice(0, W // 2) if left else slice(piece.shape[-1] - (W - W // 2), piece.shape[-1])
+            out[..., slice(0, H // 2) if top else slice(H // 2, H), slice(0, W // 2) if left else slice(W // 2, W)] = piece[..., pr, pc]
+    return out
 
 
 class DRUNet(Denoiser):
@@ -189,10 +198,10 @@ class DRUNet(Denoiser):
         if safe:
             return run(xin)
         if self.training or any(xin.size(2 + i) < 64 for i in range(self.dim)):
-            return test_pad(run, xin, modulo=16)
+            return run_replicate_padded(run, xin, multiple=16)
         if self.dim == 3:
-            raise NotImplementedError("test_onesplit is not implemented yet for 3D.")
-        return test_onesplit(run, xin, refield=64)
+            raise NotImplementedError("the four-window evaluation of large shapes that are not multiples of 8 is 2-D only (as in the reference)")
+        return run_four_windows(run, xin, field=64)
 
     # ------------------------------------------------------------------ MFMA inference engine
     def _weights_version(self):

@@ -74,14 +74,21 @@ class MRIMixin:
         torchvision ``CenterCrop``; odd heights adjusted by one pixel to match FastMRI)."""
         if rescale and crop:
             raise ValueError("Only one of rescale or crop can be used.")
-        if rescale:
-            raise NotImplementedError("rescale=True needs torchvision Resize; not on the accelerated path")
-        if not crop:
+        if not crop and not rescale:
             return x
         ch, cw = (shape[-2:] if shape is not None else self.img_size[-2:])
         odd_h = ch % 2 == 1
         if odd_h:
             ch += 1
+        if rescale:
+            # the reference calls torchvision.transforms.Resize on the (..., H, W) tensor (mixins.py:236-240): for tensors that
+            # is bilinear interpolation with half-pixel centres and, since torchvision 0.17, antialiasing when shrinking -
+            # the same ATen kernel, called directly (display-side helper, not on the hot path; torchvision is not installed
+            # in the build container, so this branch has no reference fixture: tests pin it to the defining sums instead)
+            flat = x.reshape(-1, 1, *x.shape[-2:])
+            out = torch.nn.functional.interpolate(flat, size=(ch, cw), mode="bilinear", align_corners=False, antialias=True)
+            out = out.reshape(*x.shape[:-2], ch, cw)
+            return out[..., :-1, :] if odd_h else out
         H, W = x.shape[-2:]
         if ch > H or cw > W:  # CenterCrop zero-pads when the crop is larger
             ph, pw = max(ch - H, 0), max(cw - W, 0)

@@ -79,3 +79,24 @@ def radon_forward(x, angles_deg, circle=False):
                     if 0 <= yy < G and 0 <= xx < G:
                         out[j, a] += w * xp[yy, xx]
     return out
+
+
+def resize_bilinear_antialias(x: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """What torchvision.transforms.Resize does to a (..., H, W) tensor since 0.17 (the call MRIMixin.crop(rescale=True) makes,
+    deepinv/utils/mixins.py:236-240): separable triangle-filter resampling with half-pixel centres; the filter support is
+    1 output pixel when enlarging and `scale` input pixels when shrinking (antialiasing), weights normalised per output sample.
+    fp64, straight from the defining sums."""
+    def matrix(n_in, n_out):
+        scale = n_in / n_out
+        support = max(scale, 1.0)
+        M = np.zeros((n_out, n_in))
+        for o in range(n_out):
+            centre = (o + 0.5) * scale
+            lo, hi = max(int(centre - support + 0.5), 0), min(int(centre + support + 0.5), n_in)
+            for i in range(lo, hi):
+                M[o, i] = max(0.0, 1.0 - abs((i + 0.5 - centre) / support))
+            M[o] /= M[o].sum()
+        return M
+
+    x = np.asarray(x, dtype=np.float64)
+    return np.einsum("oh,...hw,pw->...op", matrix(x.shape[-2], out_h), x, matrix(x.shape[-1], out_w))

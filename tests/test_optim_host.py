@@ -432,3 +432,27 @@ def test_trainer_loop_host():
         bad = dinv.Trainer(model=net, physics=P(), optimizer=opt, train_dataloader=torch.utils.data.DataLoader(list(x), batch_size=4),
                            epochs=1, device="cpu", verbose=False)
         bad.train()
+
+
+def test_mri_crop_rescale_matches_the_defining_sums():
+    """MRIMixin.crop(rescale=True) (deepinv/utils/mixins.py:208-246: torchvision Resize of the last two dims, odd heights adjusted
+    by one pixel) against an fp64 evaluation of antialiased bilinear resampling (oracle/naive.py); crop and rescale exclude each
+    other.  (No reference fixture: torchvision is not installed where the reference can be imported.)"""
+    import numpy as np
+    import pytest
+
+    from deepinv_amd.physics.mri import MRIMixin
+    from oracle.naive import resize_bilinear_antialias
+
+    m = MRIMixin()
+    x = torch.randn(2, 3, 40, 52, generator=torch.Generator().manual_seed(3))
+    for shape, out_shape in (((20, 26), (20, 26)), ((64, 70), (64, 70)), ((25, 30), (25, 30)), ((40, 52), (40, 52))):
+        m.img_size = (2, *shape)
+        out = m.crop(x, crop=False, rescale=True)
+        assert tuple(out.shape) == (2, 3, *out_shape)
+        hh = shape[0] + (shape[0] % 2)
+        ref = resize_bilinear_antialias(x.numpy(), hh, shape[1])[..., :shape[0], :]
+        assert np.abs(out.numpy() - ref).max() < 5e-5      # (ATen evaluates in fp32)
+    with pytest.raises(ValueError):
+        m.crop(x, crop=True, rescale=True)
+    assert m.crop(x, crop=False) is x

@@ -5,7 +5,7 @@ import contextlib
 
 import torch
 
-from deepinv_amd.models.drunet import test_onesplit, test_pad
+from deepinv_amd.models.drunet import run_four_windows, run_replicate_padded
 
 
 def forward_unet_torch(model, x0):
@@ -28,8 +28,8 @@ def torch_forward(model, x, sigma):
     if all(s % 8 == 0 and s > 31 for s in xin.shape[2:]):
         return run(xin)
     if model.training or any(xin.size(2 + i) < 64 for i in range(model.dim)):
-        return test_pad(run, xin, modulo=16)
-    return test_onesplit(run, xin, refield=64)
+        return run_replicate_padded(run, xin, multiple=16)
+    return run_four_windows(run, xin, field=64)
 
 
 @contextlib.contextmanager
