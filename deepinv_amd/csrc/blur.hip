@@ -124,6 +124,34 @@ __global__ __launch_bounds__(256) void conv2d_pad_transpose_kernel(ConvGeom g, c
     x[((int64_t)bc * g.H + r) * g.W + cc] = acc;
 }
 
+// gradient of the convolution w.r.t. its filter (what autograd through F.conv2d gives the reference: blind / learned kernels,
+// least_squares_implicit_backward, deepinv/optim/linear/least_squares.py:315-339):
+//   dk[b,c,h-1-u,w-1-v] = sum_{io,jo} gy[b,c,io,jo] * xpad[io*s+u, jo*s+v]      per (b, c) plane, fixed summation order
+// one workgroup per (filter tap, plane): the taps of a plane read the same two images, shifted (L2)
+__global__ __launch_bounds__(256) void conv2d_filter_grad_kernel(ConvGeom g, const float* __restrict__ x,
+                                                                 const float* __restrict__ gy, float* __restrict__ dk) {
+    __shared__ float red[4];
+    const int tap = blockIdx.x, u = tap / g.w, v = tap - u * g.w;
+    const int bc = blockIdx.y;
+    const float* img = x + (int64_t)bc * g.H * g.W;
+    const float* go = gy + (int64_t)bc * g.Ho * g.Wo;
+    float acc = 0.f;
+    for (int io = threadIdx.x >> 6; io < g.Ho; io += 4) {
+        const int r = pad_map(io * g.stride + u - g.pt, g.H, g.mode);
+        if (r < 0) continue;
+        const float* row = img + (int64_t)r * g.W;
+        for (int jo = threadIdx.x & 63; jo < g.Wo; jo += 64) {
+            const int cc = pad_map(jo * g.stride + v - g.pl, g.W, g.mode);
+            if (cc >= 0) acc = fmaf(go[(int64_t)io * g.Wo + jo], row[cc], acc);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dk[(int64_t)bc * g.h * g.w + (g.h * g.w - 1 - tap)] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 int make_geom(const dinv_conv_desc* d, ConvGeom* g) {
     DINV_REQUIRE(d != nullptr, "null descriptor");
     DINV_REQUIRE(d->batch >= 0 && d->channels >= 1 && d->height >= 1 && d->width >= 1, "bad image geometry");
@@ -150,6 +178,144 @@ int make_geom(const dinv_conv_desc* d, ConvGeom* g) {
     g->Wo = (fullW + d->stride - 1) / d->stride;
     DINV_REQUIRE((int64_t)g->B * g->C <= 65535, "too many (batch*channel) planes per call");
     DINV_REQUIRE((size_t)g->h * g->w * sizeof(float) <= 64 * 1024, "filter too large for LDS");
+    return 0;
+}
+
+// ------------------------------------------------------------------ 3-D (volumes [B,C,D,H,W]; conv3d / conv_transpose3d,
+// convolution.py:333-452: the same padding rule per axis, stride 1)
+struct ConvGeom3 {
+    int32_t B, C, D, H, W;
+    int32_t fb, fc, d, h, w;
+    int32_t mode;
+    int32_t pf, pt, pl, pk, pb, pr;   // pads front / top / left / back / bottom / right
+    int32_t Do, Ho, Wo;
+};
+
+// y[b,c,ko,io,jo] = sum_{t,u,v} kf[t,u,v] * xpad[ko+t, io+u, jo+v],  kf = k flipped along all three axes
+__global__ __launch_bounds__(256) void conv3d_pad_kernel(ConvGeom3 g, const float* __restrict__ x, const float* __restrict__ k,
+                                                         float* __restrict__ y) {
+    DINV_DYN_LDS(float, ks);
+    const int nk = g.d * g.h * g.w;
+    const int z = blockIdx.z, bc = z / g.Do, ko = z - bc * g.Do, b = bc / g.C, c = bc % g.C;
+    const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * nk;
+    for (int i = threadIdx.x; i < nk; i += 256) ks[i] = kf[nk - 1 - i];
+    __syncthreads();
+    const int jo = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int io = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (io >= g.Ho || jo >= g.Wo) return;
+    const float* vol = x + (int64_t)bc * g.D * g.H * g.W;
+    float acc = 0.f;
+    for (int t = 0; t < g.d; ++t) {
+        const int dd = pad_map(ko + t - g.pf, g.D, g.mode);
+        if (dd < 0) continue;
+        for (int u = 0; u < g.h; ++u) {
+            const int r = pad_map(io + u - g.pt, g.H, g.mode);
+            if (r < 0) continue;
+            const float* row = vol + ((int64_t)dd * g.H + r) * g.W;
+            for (int v = 0; v < g.w; ++v) {
+                const int cc = pad_map(jo + v - g.pl, g.W, g.mode);
+                if (cc >= 0) acc = fmaf(ks[(t * g.h + u) * g.w + v], row[cc], acc);
+            }
+        }
+    }
+    y[(((int64_t)bc * g.Do + ko) * g.Ho + io) * g.Wo + jo] = acc;
+}
+
+// exact transpose as a gather over the pre-images of the output voxel under the padding map (fixed summation order)
+__global__ __launch_bounds__(256) void conv3d_pad_transpose_kernel(ConvGeom3 g, const float* __restrict__ y,
+                                                                   const float* __restrict__ k, float* __restrict__ x) {
+    DINV_DYN_LDS(float, ks);
+    const int nk = g.d * g.h * g.w;
+    const int z = blockIdx.z, bc = z / g.D, dd = z - bc * g.D, b = bc / g.C, c = bc % g.C;
+    const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * nk;
+    for (int i = threadIdx.x; i < nk; i += 256) ks[i] = kf[nk - 1 - i];
+    __syncthreads();
+    const int cc = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= g.H || cc >= g.W) return;
+    const float* meas = y + (int64_t)bc * g.Do * g.Ho * g.Wo;
+    const Pre pdep = preimages(dd, g.D, g.pf, g.pk, g.mode);
+    const Pre prow = preimages(r, g.H, g.pt, g.pb, g.mode);
+    const Pre pcol = preimages(cc, g.W, g.pl, g.pr, g.mode);
+    float acc = 0.f;
+    for (int id = 0; id < pdep.n; ++id)
+        for (int pd = pdep.lo[id]; pd <= pdep.hi[id]; ++pd)
+            for (int t = 0; t < g.d; ++t) {
+                const int ko = pd - t;
+                if (ko < 0) break;
+                if (ko >= g.Do) continue;
+                for (int ir = 0; ir < prow.n; ++ir)
+                    for (int pr = prow.lo[ir]; pr <= prow.hi[ir]; ++pr)
+                        for (int u = 0; u < g.h; ++u) {
+                            const int io = pr - u;
+                            if (io < 0) break;
+                            if (io >= g.Ho) continue;
+                            const float* mrow = meas + ((int64_t)ko * g.Ho + io) * g.Wo;
+                            for (int ic = 0; ic < pcol.n; ++ic)
+                                for (int pc = pcol.lo[ic]; pc <= pcol.hi[ic]; ++pc)
+                                    for (int v = 0; v < g.w; ++v) {
+                                        const int jo = pc - v;
+                                        if (jo < 0) break;
+                                        if (jo < g.Wo) acc = fmaf(ks[(t * g.h + u) * g.w + v], mrow[jo], acc);
+                                    }
+                        }
+            }
+    x[(((int64_t)bc * g.D + dd) * g.H + r) * g.W + cc] = acc;
+}
+
+// filter gradient per (b, c) plane: one workgroup per (tap, plane)
+__global__ __launch_bounds__(256) void conv3d_filter_grad_kernel(ConvGeom3 g, const float* __restrict__ x,
+                                                                 const float* __restrict__ gy, float* __restrict__ dk) {
+    __shared__ float red[4];
+    const int nk = g.d * g.h * g.w;
+    const int tap = blockIdx.x, t = tap / (g.h * g.w), uv = tap - t * g.h * g.w, u = uv / g.w, v = uv - u * g.w;
+    const int bc = blockIdx.y;
+    const float* vol = x + (int64_t)bc * g.D * g.H * g.W;
+    const float* go = gy + (int64_t)bc * g.Do * g.Ho * g.Wo;
+    float acc = 0.f;
+    for (int ko = 0; ko < g.Do; ++ko) {
+        const int dd = pad_map(ko + t - g.pf, g.D, g.mode);
+        if (dd < 0) continue;
+        for (int io = threadIdx.x >> 6; io < g.Ho; io += 4) {
+            const int r = pad_map(io + u - g.pt, g.H, g.mode);
+            if (r < 0) continue;
+            const float* row = vol + ((int64_t)dd * g.H + r) * g.W;
+            const float* grow = go + ((int64_t)ko * g.Ho + io) * g.Wo;
+            for (int jo = threadIdx.x & 63; jo < g.Wo; jo += 64) {
+                const int cc = pad_map(jo + v - g.pl, g.W, g.mode);
+                if (cc >= 0) acc = fmaf(grow[jo], row[cc], acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dk[(int64_t)bc * nk + (nk - 1 - tap)] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int make_geom3(const dinv_conv3d_desc* d, ConvGeom3* g) {
+    DINV_REQUIRE(d != nullptr, "null descriptor");
+    DINV_REQUIRE(d->batch >= 0 && d->channels >= 1 && d->depth >= 1 && d->height >= 1 && d->width >= 1, "bad volume geometry");
+    DINV_REQUIRE(d->fd >= 1 && d->fh >= 1 && d->fw >= 1 && (d->fbatch == 1 || d->fbatch == d->batch) &&
+                 (d->fchannels == 1 || d->fchannels == d->channels), "filter shape not broadcastable");
+    DINV_REQUIRE(d->mode >= PAD_VALID && d->mode <= PAD_CONSTANT, "unknown padding mode %d", d->mode);
+    g->B = d->batch; g->C = d->channels; g->D = d->depth; g->H = d->height; g->W = d->width;
+    g->fb = d->fbatch; g->fc = d->fchannels; g->d = d->fd; g->h = d->fh; g->w = d->fw;
+    g->mode = d->mode;
+    if (d->mode == PAD_VALID) {
+        g->pf = g->pt = g->pl = g->pk = g->pb = g->pr = 0;
+        DINV_REQUIRE(d->depth >= d->fd && d->height >= d->fh && d->width >= d->fw, "filter larger than volume in 'valid' mode");
+        g->Do = d->depth - d->fd + 1; g->Ho = d->height - d->fh + 1; g->Wo = d->width - d->fw + 1;
+    } else {
+        const int pd = d->fd / 2, ph = d->fh / 2, pw = d->fw / 2;
+        g->pf = pd - (d->fd - 1) % 2; g->pk = pd; g->pt = ph - (d->fh - 1) % 2; g->pb = ph; g->pl = pw - (d->fw - 1) % 2; g->pr = pw;
+        if (d->mode == PAD_CIRCULAR) DINV_REQUIRE(pd <= d->depth && ph <= d->height && pw <= d->width, "circular padding wider than the volume");
+        if (d->mode == PAD_REFLECT) DINV_REQUIRE(pd < d->depth && ph < d->height && pw < d->width, "reflect padding must be smaller than the volume");
+        g->Do = d->depth; g->Ho = d->height; g->Wo = d->width;
+    }
+    DINV_REQUIRE((int64_t)g->B * g->C * std::max(g->D, g->Do) <= 65535, "too many (batch * channel * depth) planes per call");
+    DINV_REQUIRE((size_t)g->d * g->h * g->w * sizeof(float) <= 64 * 1024, "filter too large for LDS");
     return 0;
 }
 
@@ -219,6 +385,59 @@ extern "C" int dinv_conv2d_transpose(const dinv_conv_desc* d, const float* y, co
     DINV_REQUIRE(x && filter && y, "null pointer");
     hipLaunchKernelGGL(conv2d_pad_transpose_kernel, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.B * g.C), dim3(256),
                        g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y, filter, x);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_conv2d_filter_grad(const dinv_conv_desc* d, const float* x, const float* gy, float* dk_planes,
+                                       dinv_stream_t stream) {
+    ConvGeom g;
+    if (int e = make_geom(d, &g)) return e;
+    if (g.B == 0) return 0;
+    DINV_REQUIRE(x && gy && dk_planes, "null pointer");
+    hipLaunchKernelGGL(conv2d_filter_grad_kernel, dim3(g.h * g.w, g.B * g.C), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g,
+                       x, gy, dk_planes);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_conv3d_out_size(const dinv_conv3d_desc* d, int32_t* dout, int32_t* ho, int32_t* wo) {
+    ConvGeom3 g;
+    if (int e = make_geom3(d, &g)) return e;
+    *dout = g.Do; *ho = g.Ho; *wo = g.Wo;
+    return 0;
+}
+
+extern "C" int dinv_conv3d(const dinv_conv3d_desc* d, const float* x, const float* filter, float* y, dinv_stream_t stream) {
+    ConvGeom3 g;
+    if (int e = make_geom3(d, &g)) return e;
+    if (g.B == 0) return 0;
+    DINV_REQUIRE(x && filter && y, "null pointer");
+    hipLaunchKernelGGL(conv3d_pad_kernel, dim3((g.Wo + 63) / 64, (g.Ho + 3) / 4, g.B * g.C * g.Do), dim3(256),
+                       g.d * g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, x, filter, y);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_conv3d_transpose(const dinv_conv3d_desc* d, const float* y, const float* filter, float* x, dinv_stream_t stream) {
+    ConvGeom3 g;
+    if (int e = make_geom3(d, &g)) return e;
+    if (g.B == 0) return 0;
+    DINV_REQUIRE(x && filter && y, "null pointer");
+    hipLaunchKernelGGL(conv3d_pad_transpose_kernel, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.B * g.C * g.D), dim3(256),
+                       g.d * g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y, filter, x);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_conv3d_filter_grad(const dinv_conv3d_desc* d, const float* x, const float* gy, float* dk_planes,
+                                       dinv_stream_t stream) {
+    ConvGeom3 g;
+    if (int e = make_geom3(d, &g)) return e;
+    if (g.B == 0) return 0;
+    DINV_REQUIRE(x && gy && dk_planes, "null pointer");
+    hipLaunchKernelGGL(conv3d_filter_grad_kernel, dim3(g.d * g.h * g.w, g.B * g.C), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       g, x, gy, dk_planes);
     DINV_CHECK_LAUNCH();
     return 0;
 }

@@ -269,10 +269,14 @@ __global__ __launch_bounds__(256) void radon_fan_fwd_kernel(RadonGeom g, int n_d
     }
 }
 
-// exact adjoint as a gather: one thread = one image pixel of NB images.  For every angle the pixel is rotated back into
-// the fan frame (qx along the central ray, qy across); only the 4 march indices around qx and, for each of them, the
-// detector pixels within the rotated pixel footprint divided by the local stretch can touch it; each candidate is
-// re-evaluated with the forward kernel's coordinate code and its tap weights are selected by integer comparison.
+// exact adjoint as a gather: one thread = one image pixel of NB images.  For every angle the pixel is rotated back into the fan
+// frame (qx along the central ray, qy across).  A sample (march index i, detector d) touches the pixel iff both of its
+// coordinates lie within one pixel of it, i.e. iff its offset, seen in the fan frame, lies inside the rotated unit square: the
+// march indices within |c| + |s| pixels of qx (two or three of them) and, for each, the detectors within (|c| + |s|) / stretch_i
+// detector pitches of qy / stretch_i (one or two at the usual geometries).  Both index ranges follow in closed form - no search,
+// no division (the reciprocal stretch is tabulated) - and every candidate is evaluated with the FORWARD kernel's coordinate
+// code; its weight is the product of the two hat functions clamp(1 - |t - p|), i.e. exactly the bilinear tap weight the
+// forward gives that pixel (zero outside the support, so a candidate too many costs nothing but its instructions).
 template <int NB>
 __global__ __launch_bounds__(256) void radon_fan_adj_kernel(RadonGeom g, int n_det, const float* __restrict__ sp,
                                                             const float* __restrict__ xm, const float* __restrict__ sc,
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void radon_fan_adj_kernel(RadonGeom g, int n_d
     DINV_DYN_LDS(float, tab);      // xm [G], sc [G], 1 / sc [G], yd [n_det]
     float* xm_s = tab;
     float* sc_s = tab + g.G;
-    float* rsc_s = tab + 2 * g.G;  // reciprocal stretch: the candidate window below needs two quotients per (angle, march index)
+    float* rsc_s = tab + 2 * g.G;  // reciprocal stretch (0 where the stretch vanishes: that march index sees every detector)
     float* yd_s = tab + 3 * g.G;
     for (int i = threadIdx.x; i < g.G; i += 256) {
         const float v = sc[i];
@@ -294,8 +298,9 @@ __global__ __launch_bounds__(256) void radon_fan_adj_kernel(RadonGeom g, int n_d
     const int grp = blockIdx.z;
     if (col >= g.W || row >= g.W) return;
     const int px = col + g.pad, py = row + g.pad;
-    const float gm1 = (float)(g.G - 1), dm1 = (float)(n_det - 1);
-    const float gx = 2.0f * (float)px / gm1 - 1.0f, gy = 2.0f * (float)py / gm1 - 1.0f;   // pixel centre, normalised
+    const float fpx = (float)px, fpy = (float)py;
+    const float gm1 = (float)(g.G - 1), dm1 = (float)(n_det - 1), hgm1 = 0.5f * gm1, hdm1 = 0.5f * dm1;
+    const float gx = 2.0f * fpx / gm1 - 1.0f, gy = 2.0f * fpy / gm1 - 1.0f;   // pixel centre, normalised
     float acc[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) acc[k] = 0.f;
@@ -308,34 +313,31 @@ __global__ __launch_bounds__(256) void radon_fan_adj_kernel(RadonGeom g, int n_d
     if (live) {
         for (int a = 0; a < g.A; ++a) {
             const float c = cs[a].x, s = cs[a].y;
-            const float qx = c * gx - s * gy, qy = s * gx + c * gy;          // inverse rotation (candidates only)
-            const int i0 = (int)floorf((qx + 1.0f) * 0.5f * gm1) - 1;
-            const float reach = (fabsf(c) + fabsf(s)) * (2.0f / gm1);        // footprint of the pixel's bilinear support
+            const float qx = c * gx - s * gy, qy = s * gx + c * gy;          // inverse rotation (candidate ranges only)
+            const float reach = fabsf(c) + fabsf(s);                         // half width of the rotated unit square, in pixels
+            const float qi = (qx + 1.0f) * hgm1;                             // march coordinate of the pixel
+            // march indices within reach (+ 0.01 for the rounding of this inverse map) of qi
+            int ilo = (int)ceilf(qi - reach - 0.01f), ihi = (int)floorf(qi + reach + 0.01f);
+            ilo = ilo < 0 ? 0 : ilo;
+            ihi = ihi > g.G - 1 ? g.G - 1 : ihi;
+            const float reach_n = reach / hgm1;                              // the same in normalised units
             const float* sa = sp + ((int64_t)grp * g.A + a) * n_det * NB;
-            for (int di = 0; di < 4; ++di) {
-                const int i = i0 + di;
-                if (i < 0 || i >= g.G) continue;
-                const float sci = sc_s[i], xmi = xm_s[i];
+            for (int i = ilo; i <= ihi; ++i) {
+                const float sci = sc_s[i], xmi = xm_s[i], rsc = rsc_s[i];
                 int dlo = 0, dhi = n_det - 1;
-                if (fabsf(sci) > 1e-20f && n_det > 1) {
-                    const float rsc = rsc_s[i];
-                    const float dc = (qy * rsc + 1.0f) * 0.5f * dm1;
-                    // (floor / ceil below already widen the window by up to one detector on each side; the extra 0.01 covers
-                    // the rounding of this inverse map - the candidates are re-tested with the forward's own coordinates)
-                    const float m = reach * fabsf(rsc) * 0.5f * dm1 + 0.01f;
-                    const float lo = floorf(dc - m), hi = ceilf(dc + m);
+                if (rsc != 0.f && n_det > 1) {
+                    const float dc = fmaf(qy * rsc, hdm1, hdm1);             // detector coordinate of the pixel at this march index
+                    const float m = fmaf(reach_n * fabsf(rsc), hdm1, 0.01f); // half width of its support there, in detector pitches
+                    const float lo = ceilf(dc - m), hi = floorf(dc + m);
                     if (!(hi >= 0.0f && lo <= dm1)) continue;
                     dlo = lo > 0.0f ? (int)lo : 0;
                     dhi = hi < dm1 ? (int)hi : n_det - 1;
                 }
                 for (int d = dlo; d <= dhi; ++d) {
                     float ix, iy;
-                    sample_pos(c, s, xmi, yd_s[d] * sci, gm1, ix, iy);
-                    const float fx = floorf(ix), fy = floorf(iy);
-                    const float ex = (float)px - fx, ey = (float)py - fy;   // 0 -> tap weight (1-t), 1 -> t
-                    if (!((ex == 0.0f || ex == 1.0f) && (ey == 0.0f || ey == 1.0f))) continue;
-                    const float tx = ix - fx, ty = iy - fy;
-                    const float w = (ex == 0.0f ? 1.0f - tx : tx) * (ey == 0.0f ? 1.0f - ty : ty);
+                    sample_pos(c, s, xmi, yd_s[d] * sci, gm1, ix, iy);       // the forward's coordinates, bit for bit
+                    const float wx = fmaxf(1.0f - fabsf(ix - fpx), 0.0f), wy = fmaxf(1.0f - fabsf(iy - fpy), 0.0f);
+                    const float w = wx * wy;
                     const float* v = sa + (int64_t)d * NB;
 #pragma unroll
                     for (int k = 0; k < NB; ++k) acc[k] = fmaf(w, v[k], acc[k]);

@@ -16,6 +16,11 @@ class ConvDesc(ctypes.Structure):
                                               "fw", "mode", "stride")]
 
 
+class Conv3dDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("batch", "channels", "depth", "height", "width", "fbatch", "fchannels", "fd", "fh",
+                                              "fw", "mode", "reserved")]
+
+
 _declared = False
 
 
@@ -28,6 +33,11 @@ def _l():
         l.dinv_conv2d_out_size.argtypes = [D, ctypes.POINTER(i32), ctypes.POINTER(i32)]
         l.dinv_conv2d.argtypes = [D, vp, vp, vp, vp]
         l.dinv_conv2d_transpose.argtypes = [D, vp, vp, vp, vp]
+        l.dinv_conv2d_filter_grad.argtypes = [D, vp, vp, vp, vp]
+        D3 = ctypes.POINTER(Conv3dDesc)
+        l.dinv_conv3d_out_size.argtypes = [D3, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        for name in ("dinv_conv3d", "dinv_conv3d_transpose", "dinv_conv3d_filter_grad"):
+            getattr(l, name).argtypes = [D3, vp, vp, vp, vp]
         l.dinv_rfft2.argtypes = [vp, vp, i64, P, vp, P, vp, f32, vp]
         l.dinv_irfft2.argtypes = [vp, vp, i64, P, vp, P, vp, f32, vp, sz, vp]
         _declared = True
@@ -42,42 +52,69 @@ def pad_mode(padding: str) -> int:
     return _MODES[p]
 
 
-def _desc(B, C, H, W, filt, padding, stride):
-    b, c, h, w = filt.shape
+def _check_broadcast(B, C, filt):
+    b, c = filt.shape[:2]
     if c != C and c != 1:
         raise AssertionError(f"Number of channels of the kernel is not matched for broadcasting, got c={c} and C={C}")
     if b != B and b != 1:
         raise AssertionError(f"Batch size of the kernel is not matched for broadcasting, got b={b} and B={B}")
-    d = ConvDesc(B, C, H, W, b, c, h, w, pad_mode(padding), int(stride))
-    ho, wo = ctypes.c_int32(), ctypes.c_int32()
-    check(_l().dinv_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)))
-    return d, ho.value, wo.value
 
 
-def _chunks(n, step=65535):
-    return [(s, min(n, s + step)) for s in range(0, n, step)]
+def _desc(B, C, spatial, filt, padding, stride):
+    """descriptor + output spatial size of y = conv(x, filt) for x [B, C, *spatial] (2 or 3 spatial dims)"""
+    _check_broadcast(B, C, filt)
+    if len(spatial) == 2:
+        d = ConvDesc(B, C, *spatial, *filt.shape, pad_mode(padding), int(stride))
+        ho, wo = ctypes.c_int32(), ctypes.c_int32()
+        check(_l().dinv_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)))
+        return d, (ho.value, wo.value)
+    if int(stride) != 1:
+        raise ValueError("strided convolution is 2-D only (Downsampling)")
+    d = Conv3dDesc(B, C, *spatial, *filt.shape, pad_mode(padding), 0)
+    do, ho, wo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    check(_l().dinv_conv3d_out_size(ctypes.byref(d), ctypes.byref(do), ctypes.byref(ho), ctypes.byref(wo)))
+    return d, (do.value, ho.value, wo.value)
+
+
+def _entry(nd, name):
+    return getattr(_l(), f"dinv_conv{nd}d{name}")
 
 
 def _conv_fwd(x, filt, padding, stride):
     dev = require_hip(x, filt)
     x, filt = f32c(x), f32c(filt)
-    B, C, H, W = x.shape
-    d, ho, wo = _desc(B, C, H, W, filt, padding, stride)
-    y = torch.empty((B, C, ho, wo), device=dev, dtype=torch.float32)
-    check(_l().dinv_conv2d(ctypes.byref(d), ptr(x), ptr(filt), ptr(y), stream_ptr(dev)))
+    B, C, *sp = x.shape
+    d, out = _desc(B, C, sp, filt, padding, stride)
+    y = torch.empty((B, C, *out), device=dev, dtype=torch.float32)
+    check(_entry(len(sp), "")(ctypes.byref(d), ptr(x), ptr(filt), ptr(y), stream_ptr(dev)))
     return y
 
 
-def _conv_adj(y, filt, padding, stride, H, W):
+def _conv_adj(y, filt, padding, stride, size):
     dev = require_hip(y, filt)
     y, filt = f32c(y), f32c(filt)
     B, C = y.shape[:2]
-    d, ho, wo = _desc(B, C, H, W, filt, padding, stride)
-    if (ho, wo) != tuple(y.shape[-2:]):
-        raise ValueError(f"measurement of spatial size {tuple(y.shape[-2:])} does not match the operator output {(ho, wo)}")
-    x = torch.empty((B, C, H, W), device=dev, dtype=torch.float32)
-    check(_l().dinv_conv2d_transpose(ctypes.byref(d), ptr(y), ptr(filt), ptr(x), stream_ptr(dev)))
+    d, out = _desc(B, C, tuple(size), filt, padding, stride)
+    if out != tuple(y.shape[2:]):
+        raise ValueError(f"measurement of spatial size {tuple(y.shape[2:])} does not match the operator output {out}")
+    x = torch.empty((B, C, *size), device=dev, dtype=torch.float32)
+    check(_entry(len(size), "_transpose")(ctypes.byref(d), ptr(y), ptr(filt), ptr(x), stream_ptr(dev)))
     return x
+
+
+def _filter_grad(x, gy, filt, padding, stride):
+    """d<gy, conv(x, k)>/dk in the shape of `filt` (the planes a broadcast filter is shared by are summed)"""
+    dev = require_hip(x, gy)
+    x, gy = f32c(x), f32c(gy)
+    B, C, *sp = x.shape
+    d, _ = _desc(B, C, sp, filt, padding, stride)
+    planes = torch.empty((B, C, *filt.shape[2:]), device=dev, dtype=torch.float32)
+    check(_entry(len(sp), "_filter_grad")(ctypes.byref(d), ptr(x), ptr(gy), ptr(planes), stream_ptr(dev)))
+    if filt.shape[0] == 1 and B > 1:
+        planes = planes.sum(0, keepdim=True)
+    if filt.shape[1] == 1 and C > 1:
+        planes = planes.sum(1, keepdim=True)
+    return planes
 
 
 class _Conv(torch.autograd.Function):
@@ -88,50 +125,77 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def setup_context(ctx, inputs, output):
         x, filt, padding, stride = inputs
-        ctx.save_for_backward(filt)
-        ctx.cfg = (padding, stride, x.shape[-2], x.shape[-1])
+        ctx.save_for_backward(filt, x)
+        ctx.cfg = (padding, stride, tuple(x.shape[2:]))
 
     @staticmethod
     def backward(ctx, g):
-        (filt,) = ctx.saved_tensors
-        padding, stride, H, W = ctx.cfg
-        return _ConvT.apply(g, filt, padding, stride, H, W), None, None, None
+        filt, x = ctx.saved_tensors
+        padding, stride, size = ctx.cfg
+        gx = _ConvT.apply(g, filt, padding, stride, size) if ctx.needs_input_grad[0] else None
+        gk = _FilterGrad.apply(x, g, filt, padding, stride) if ctx.needs_input_grad[1] else None
+        return gx, gk, None, None
 
 
 class _ConvT(torch.autograd.Function):
     @staticmethod
-    def forward(y, filt, padding, stride, H, W):
-        return _conv_adj(y, filt, padding, stride, H, W)
+    def forward(y, filt, padding, stride, size):
+        return _conv_adj(y, filt, padding, stride, size)
 
     @staticmethod
     def setup_context(ctx, inputs, output):
-        _, filt, padding, stride, _, _ = inputs
-        ctx.save_for_backward(filt)
+        y, filt, padding, stride, _ = inputs
+        ctx.save_for_backward(filt, y)
         ctx.cfg = (padding, stride)
 
     @staticmethod
     def backward(ctx, g):
-        (filt,) = ctx.saved_tensors
+        filt, y = ctx.saved_tensors
         padding, stride = ctx.cfg
-        return _Conv.apply(g, filt, padding, stride), None, None, None, None, None
+        gy = _Conv.apply(g, filt, padding, stride) if ctx.needs_input_grad[0] else None
+        # <g, A_k^T y> = <A_k g, y>: the filter gradient of the forward convolution with image g and output gradient y
+        gk = _FilterGrad.apply(g, y, filt, padding, stride) if ctx.needs_input_grad[1] else None
+        return gy, gk, None, None, None
 
 
-def _no_filter_grad(filt):
-    """the reference gets d/d(filter) from autograd through F.conv2d; these kernels differentiate w.r.t. the image
-    only, so a filter that asks for a gradient fails loudly instead of silently receiving None"""
-    if torch.is_grad_enabled() and isinstance(filt, torch.Tensor) and filt.requires_grad:
-        raise NotImplementedError("gradients w.r.t. the blur filter are not implemented on the HIP path "
-                                  "(blind / learned kernels): detach the filter or differentiate w.r.t. the image")
+class _FilterGrad(torch.autograd.Function):
+    """k -> d<gy, conv(x, k)>/dk is bilinear in (x, gy) and does not depend on k: its own derivatives are convolutions again"""
+
+    @staticmethod
+    def forward(x, gy, filt, padding, stride):
+        return _filter_grad(x, gy, filt, padding, stride)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x, gy, filt, padding, stride = inputs
+        ctx.save_for_backward(x, gy)
+        ctx.cfg = (padding, stride, tuple(filt.shape))
+
+    @staticmethod
+    def backward(ctx, gk):
+        x, gy = ctx.saved_tensors
+        padding, stride, fshape = ctx.cfg
+        gk = gk.expand(fshape) if tuple(gk.shape) != fshape else gk
+        # <gk, dk(x, gy)> = <gy, conv(x, gk)>: linear in x (transpose conv of gy with gk) and in gy (conv of x with gk)
+        gx = _ConvT.apply(gy, gk, padding, stride, tuple(x.shape[2:])) if ctx.needs_input_grad[0] else None
+        ggy = _Conv.apply(x, gk, padding, stride) if ctx.needs_input_grad[1] else None
+        return gx, ggy, None, None, None
 
 
 def conv2d_strided(x, filt, padding="valid", stride=1):
-    _no_filter_grad(filt)
     return _Conv.apply(x, filt, padding, int(stride))
 
 
 def conv2d_strided_transpose(y, filt, padding, stride, H, W):
-    _no_filter_grad(filt)
-    return _ConvT.apply(y, filt, padding, int(stride), int(H), int(W))
+    return _ConvT.apply(y, filt, padding, int(stride), (int(H), int(W)))
+
+
+def conv3d(x, filt, padding="valid"):
+    return _Conv.apply(x, filt, padding, 1)
+
+
+def conv3d_transpose(y, filt, padding, size):
+    return _ConvT.apply(y, filt, padding, 1, tuple(int(v) for v in size))
 
 
 # --------------------------------------------------------------------------- rfft2 / irfft2

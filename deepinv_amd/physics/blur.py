@@ -30,16 +30,17 @@ class Blur(LinearPhysics):
 
     def A(self, x: Tensor, filter: Tensor = None, **kwargs) -> Tensor:
         self.update_parameters(filter=filter, **kwargs)
-        if x.dim() != 4:
-            raise ValueError(f"Expected Tensor dimension to be 4 (3-D blur is not on the accelerated path), is {x.dim()}")
-        fn = dF.conv2d_fft if self.use_fft else dF.conv2d
+        if x.dim() not in (4, 5):       # images or volumes (blur.py:535-546)
+            raise ValueError(f"Expected Tensor dimension to be 4 or 5, is {x.dim()}")
+        fn = {4: dF.conv2d_fft if self.use_fft else dF.conv2d, 5: dF.conv3d_fft if self.use_fft else dF.conv3d}[x.dim()]
         return fn(x, filter=self.filter, padding=self.padding)
 
     def A_adjoint(self, y: Tensor, filter: Tensor = None, **kwargs) -> Tensor:
         self.update_parameters(filter=filter, **kwargs)
-        if y.dim() != 4:
-            raise ValueError(f"Expected Tensor dimension to be 4 (3-D blur is not on the accelerated path), is {y.dim()}")
-        fn = dF.conv_transpose2d_fft if self.use_fft else dF.conv_transpose2d
+        if y.dim() not in (4, 5):
+            raise ValueError(f"Expected Tensor dimension to be 4 or 5, is {y.dim()}")
+        fn = {4: dF.conv_transpose2d_fft if self.use_fft else dF.conv_transpose2d,
+              5: dF.conv_transpose3d_fft if self.use_fft else dF.conv_transpose3d}[y.dim()]
         return fn(y, filter=self.filter, padding=self.padding)
 
 

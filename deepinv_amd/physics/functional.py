@@ -120,7 +120,7 @@ def _crop(p, i):
 def _fold_padding(x, padding, p, i):
     """adjoint of the padding: fold the border of the full transposed convolution back
     (convolution.py:689-758), written axis by axis."""
-    for axis, (pk, ik) in zip((-2, -1), zip(p, i)):
+    for axis, (pk, ik) in zip(range(-len(p), 0), zip(p, i)):
         n_full = x.shape[axis]
         lo, hi = pk - ik, pk           # border widths on each side
         n = n_full - lo - hi
@@ -149,6 +149,90 @@ def _fold_padding(x, padding, p, i):
             raise ValueError(f"padding = '{padding}' not implemented.")
         x = core
     return x
+
+
+# --------------------------------------------------------------------------- volumes (convolution.py:333-640)
+def _check5(x, filter):
+    if x.dim() != filter.dim() or filter.dim() != 5:
+        raise ValueError("Input and filter must be 5D tensors")
+
+
+def conv3d(x, filter, padding="valid", correlation=False):
+    """True 3-D convolution with the 2-D padding conventions on every axis (convolution.py:333-393)."""
+    _check5(x, filter)
+    if correlation:
+        filter = filter.flip(dims=(-3, -2, -1))
+    return hc.conv3d(x, filter, padding)
+
+
+def conv_transpose3d(y, filter, padding="valid", correlation=False):
+    """Exact transpose of :func:`conv3d` (convolution.py:396-452, 689-758)."""
+    _check5(y, filter)
+    if correlation:
+        filter = filter.flip(dims=(-3, -2, -1))
+    size = tuple(y.shape[2:]) if hc.pad_mode(padding) != 0 else tuple(n + f - 1 for n, f in zip(y.shape[2:], filter.shape[2:]))
+    return hc.conv3d_transpose(y, filter, padding, size)
+
+
+def _rfft3(x):
+    """rfftn over the last three dims (backward norm): the 2-D real transform of every slice, then a complex pass along depth"""
+    return hfft.fftn(hc.rfft2(x, norm="backward"), dim=(-3,), norm="backward")
+
+
+def _irfft3(xc, s):
+    return hc.irfft2(hfft.ifftn(xc, dim=(-3,), norm="backward").contiguous(), s[-2:], norm="backward")
+
+
+def _circular_conv_fft3(x, filter, s, shift_filter=False, transpose=False):
+    """convolution.py:837-865 with dims = (-3, -2, -1)"""
+    D, H, W = x.shape[-3:]
+    if (D, H, W) != tuple(s):
+        x = F.pad(x, (0, s[2] - W, 0, s[1] - H, 0, s[0] - D))
+    fd, fh, fw = filter.shape[-3:]
+    k = F.pad(filter, (0, s[2] - fw, 0, s[1] - fh, 0, s[0] - fd))
+    if shift_filter:    # centre of the filter to index 0 on every axis (filter_fft, convolution.py:790-812)
+        k = torch.roll(k, shifts=(-(fd // 2), -(fh // 2), -(fw // 2)), dims=(-3, -2, -1))
+    ff = _rfft3(k)
+    prod = _rfft3(x) * (torch.conj(ff) if transpose else ff)
+    return _irfft3(prod, s)
+
+
+def conv3d_fft(x, filter, real_fft=True, padding="valid"):
+    """convolution.py:455-541"""
+    _check5(x, filter)
+    hc.pad_mode(padding)
+    D, H, W = x.shape[-3:]
+    d, h, w = filter.shape[-3:]
+    pd, ph, pw = d // 2, h // 2, w // 2
+    if padding == "circular":
+        return _circular_conv_fft3(x, filter, (D, H, W), shift_filter=True).contiguous()
+    if padding == "valid":
+        full = _circular_conv_fft3(x, filter, (D + d - 1, H + h - 1, W + w - 1))
+        return full[:, :, d - 1:D, h - 1:H, w - 1:W].contiguous()
+    mode = "constant" if padding in ("zeros", "constant") else padding
+    xp = F.pad(x, (pw, pw, ph, ph, pd, pd), mode=mode, value=0)
+    out = _circular_conv_fft3(xp, filter, xp.shape[-3:], shift_filter=True)
+    return out[:, :, _crop(pd, 0), _crop(ph, 0), _crop(pw, 0)].contiguous()
+
+
+def conv_transpose3d_fft(y, filter, real_fft=True, padding="valid"):
+    """convolution.py:544-640"""
+    _check5(y, filter)
+    hc.pad_mode(padding)
+    D, H, W = y.shape[-3:]
+    d, h, w = filter.shape[-3:]
+    pd, ph, pw = d // 2, h // 2, w // 2
+    idp, ih, iw = (d - 1) % 2, (h - 1) % 2, (w - 1) % 2
+    if padding == "circular":
+        return _circular_conv_fft3(y, filter, (D, H, W), shift_filter=True, transpose=True).contiguous()
+    if padding == "valid":
+        yf = F.pad(y, (w - 1, w - 1, h - 1, h - 1, d - 1, d - 1))
+        out = _circular_conv_fft3(yf, filter, (D + d - 1, H + h - 1, W + w - 1), transpose=True)
+        return out[:, :, :D + d - 1, :H + h - 1, :W + w - 1].contiguous()
+    yb = F.pad(y, (pw, pw, ph, ph, pd, pd))
+    z = _circular_conv_fft3(yb, filter, (D + 2 * pd, H + 2 * ph, W + 2 * pw), shift_filter=True, transpose=True)
+    z = z[..., idp:, ih:, iw:]
+    return _fold_padding(z, "constant" if padding == "zeros" else padding, (pd, ph, pw), (idp, ih, iw)).contiguous()
 
 
 # --------------------------------------------------------------------------- filters (host side)

@@ -404,6 +404,25 @@ int dinv_conv2d(const dinv_conv_desc* d, const float* x, const float* filter, fl
  * (conv_transpose2d + _apply_transpose_padding, convolution.py:110-164, 689-758) */
 int dinv_conv2d_transpose(const dinv_conv_desc* d, const float* y, const float* filter, float* x,
                           dinv_stream_t stream);
+/* gradient of dinv_conv2d w.r.t. the filter, per (batch, channel) plane: dk_planes [B,C,fh,fw] from x [B,C,H,W] and the output
+ * gradient gy [B,C,Ho,Wo]; the caller sums the planes a broadcast filter is shared by (what autograd through F.conv2d gives
+ * the reference: convolution.py:42-107, consumed by least_squares_implicit_backward, least_squares.py:315-339).  By adjointness
+ * the same call with (x := gradient w.r.t. the transpose's output, gy := the transpose's input) is the filter gradient of
+ * dinv_conv2d_transpose. */
+int dinv_conv2d_filter_grad(const dinv_conv_desc* d, const float* x, const float* gy, float* dk_planes, dinv_stream_t stream);
+
+/* The same three operators on volumes [B,C,D,H,W] with filters [fb,fc,fd,fh,fw] (conv3d / conv_transpose3d, convolution.py:333-452;
+ * Blur on 5-D tensors, blur.py:535-561): the 2-D padding rule on every axis, stride 1. */
+typedef struct {
+    int32_t batch, channels, depth, height, width;
+    int32_t fbatch, fchannels, fd, fh, fw;
+    int32_t mode;    /* as dinv_conv_desc */
+    int32_t reserved;
+} dinv_conv3d_desc;
+int dinv_conv3d_out_size(const dinv_conv3d_desc* d, int32_t* dout, int32_t* ho, int32_t* wo);
+int dinv_conv3d(const dinv_conv3d_desc* d, const float* x, const float* filter, float* y, dinv_stream_t stream);
+int dinv_conv3d_transpose(const dinv_conv3d_desc* d, const float* y, const float* filter, float* x, dinv_stream_t stream);
+int dinv_conv3d_filter_grad(const dinv_conv3d_desc* d, const float* x, const float* gy, float* dk_planes, dinv_stream_t stream);
 
 /* rfft2 / irfft2 over the last two dims of a real [P,H,W] tensor (half spectrum [P,H,W/2+1] complex);
  * unnormalised transforms times `scale`. */

@@ -296,6 +296,29 @@ def conv2d(x, filter, padding="valid"):
     return out.view(B, C, out.size(-2), -1).contiguous()
 
 
+def conv3d(x, filter, padding="valid"):
+    """dF.conv3d (convolution.py:333-393): flipped filter, pad (pw-iw, pw, ph-ih, ph, pd-id, pd), grouped conv."""
+    if padding == "zeros":
+        padding = "constant"
+    B, C = x.shape[:2]
+    b, c, d, h, w = filter.shape
+    filter = filter.flip(dims=(-3, -2, -1)).expand(B if b == 1 else b, C if c == 1 else c, d, h, w).contiguous()
+    if padding != "valid":
+        pd, ph, pw = d // 2, h // 2, w // 2
+        x = F.pad(x, (pw - (w - 1) % 2, pw, ph - (h - 1) % 2, ph, pd - (d - 1) % 2, pd), mode=padding, value=0)
+    out = F.conv3d(x.reshape(1, -1, *x.shape[2:]), filter.reshape(B * C, 1, d, h, w), padding="valid", groups=B * C)
+    return out.view(B, C, *out.shape[2:]).contiguous()
+
+
+def conv_transpose3d(y, filter, padding, size):
+    """exact transpose of conv3d, by autograd (the reference's conv_transpose3d + _apply_transpose_padding, convolution.py:396-452,
+    689-758, is tested against exactly this adjointness)"""
+    B, C = y.shape[:2]
+    x = torch.zeros(B, C, *size, dtype=y.dtype, requires_grad=True)
+    _, vjp = torch.func.vjp(lambda v: conv3d(v, filter, padding), x)
+    return vjp(y)[0]
+
+
 def conv_transpose2d(y, filter, padding, H, W):
     """exact transpose of conv2d: obtained by autograd, which is what the reference's own adjointness tests
     (test_physics_functional.py:158-246) pin conv_transpose2d + _apply_transpose_padding against."""

@@ -36,6 +36,61 @@ def test_conv2d_and_transpose(dev, padding, img, filt):
 
 
 @pytest.mark.parametrize("padding", PADS)
+@pytest.mark.parametrize("img,filt", [((2, 3, 17, 19), (1, 1, 5, 5)), ((2, 3, 12, 16), (1, 3, 5, 4)), ((2, 2, 16, 16), (2, 1, 6, 6)),
+                                      ((3, 2, 20, 11), (3, 2, 3, 3))])
+def test_filter_gradients_match_autograd_oracle(dev, padding, img, filt):
+    """d/d(filter) of conv2d and conv_transpose2d (blind / learned kernels; the reference gets it from autograd through F.conv2d,
+    convolution.py:42-164) against autograd through the CPU oracle: shared and per-sample / per-channel filters, every padding;
+    and the image gradients through the same graph (a filter that requires grad no longer switches anything off)"""
+    import deepinv_amd.physics.functional as dF
+
+    g = _g(5)
+    x = torch.randn(*img, generator=g)
+    k = torch.rand(*filt, generator=g)
+    y_shape = O.conv2d(x, k, padding).shape
+    wy, wx = torch.randn(*y_shape, generator=g), torch.randn(*img, generator=g)
+    yin = torch.randn(*y_shape, generator=g)
+
+    def grads(conv, convT, to):
+        xs, ks, ys = (t.clone().to(to).requires_grad_() for t in (x, k, yin))
+        g1 = torch.autograd.grad((conv(xs, ks) * wy.to(to)).sum(), (xs, ks))
+        g2 = torch.autograd.grad((convT(ys, ks) * wx.to(to)).sum(), (ys, ks))
+        return [t.cpu() for t in (*g1, *g2)]
+
+    ref = grads(lambda a, b: O.conv2d(a, b, padding), lambda a, b: O.conv_transpose2d(a, b, padding, img[2], img[3]), "cpu")
+    got = grads(lambda a, b: dF.conv2d(a, b, padding=padding), lambda a, b: dF.conv_transpose2d(a, b, padding=padding), dev)
+    for name, r, o in zip(("conv/x", "conv/filter", "convT/y", "convT/filter"), ref, got):
+        assert o.shape == r.shape, name
+        assert rel_err(o, r) < TOL, name
+
+
+@pytest.mark.parametrize("padding", PADS)
+@pytest.mark.parametrize("vol,filt", [((2, 2, 9, 17, 19), (1, 1, 3, 5, 5)), ((1, 3, 8, 12, 10), (1, 3, 4, 3, 2)), ((2, 1, 16, 16, 16), (2, 1, 3, 3, 3))])
+def test_volume_blur(dev, padding, vol, filt):
+    """Blur on 5-D tensors (blur.py:535-561 -> conv3d / conv_transpose3d and their FFT forms, convolution.py:333-640) against the
+    CPU oracle, the dot test, spatial == FFT, and the filter gradient against autograd through the oracle"""
+    import deepinv_amd as dinv
+    import deepinv_amd.physics.functional as dF
+
+    g = _g(9)
+    x = torch.randn(*vol, generator=g)
+    k = torch.rand(*filt, generator=g)
+    phys = dinv.physics.Blur(filter=k, padding=padding, device=dev)
+    y = phys.A(x.to(dev))
+    y_ref = O.conv3d(x, k, padding)
+    assert y.shape == y_ref.shape and rel_err(y, y_ref) < TOL
+    v = torch.randn(y_ref.shape, generator=g)
+    assert rel_err(phys.A_adjoint(v.to(dev)), O.conv_transpose3d(v, k, padding, vol[2:])) < TOL
+    assert dot_test(phys, x.to(dev), y) < 1e-5
+    pf = dinv.physics.Blur(filter=k, padding=padding, use_fft=True, device=dev)
+    assert rel_err(pf.A(x.to(dev)), y_ref) < TOL and rel_err(pf.A_adjoint(v.to(dev)), phys.A_adjoint(v.to(dev))) < TOL
+    ks, kd = k.clone().requires_grad_(), k.clone().to(dev).requires_grad_()
+    (O.conv3d(x, ks, padding) * v).sum().backward()
+    (dF.conv3d(x.to(dev), kd, padding=padding) * v.to(dev)).sum().backward()
+    assert rel_err(kd.grad, ks.grad) < TOL
+
+
+@pytest.mark.parametrize("padding", PADS)
 def test_blur_fft_path_matches_spatial(dev, padding):
     """reference test_physics_functional.py:158-246 (spatial == FFT implementation)"""
     import deepinv_amd.physics.functional as dF

@@ -230,3 +230,39 @@ def test_unsafe_shape_strategies_equal_the_reference(ref, shape):
         if nd == 2:
             assert torch.equal(run_four_windows(net, x, field=64), ref_split(net, x, refield=64))
             assert torch.equal(run_four_windows(net, x, field=16), ref_split(net, x, refield=16))
+
+
+@pytest.mark.parametrize("padding", ["valid", "circular", "reflect", "replicate", "constant"])
+@pytest.mark.parametrize("fshape", [(1, 1, 3, 3, 3), (1, 2, 2, 4, 3), (2, 1, 3, 5, 2), (1, 2, 4, 3, 4)])
+def test_volume_blur_equals_the_reference(ref, padding, fshape):
+    """3-D blur (deepinv/physics/functional/convolution.py:333-640, Blur on 5-D tensors blur.py:535-561): the product's conv3d,
+    conv_transpose3d, their FFT forms and Blur.A / A_adjoint on volumes (its kernels on the host emulation) against the
+    reference's own functions on the same inputs, every padding, broadcast and per-sample / per-channel filters, even sizes"""
+    import deepinv_amd as A
+    from emu_backend import emu_backend
+
+    dinv, _ = ref
+    rF = dinv.physics.functional
+    g = rng()
+    x = torch.randn(2, 2, 6, 9, 8, generator=g)
+    k = torch.rand(*fshape, generator=g)
+    y_ref = rF.conv3d(x, k, padding=padding)
+    v = torch.randn(y_ref.shape, generator=g)
+    try:
+        xt_ref = rF.conv_transpose3d(v, k, padding=padding)
+    except RuntimeError as e:       # (its border folding breaks on a size-2 axis, convolution.py:756: nothing to compare with)
+        pytest.skip(f"the reference's conv_transpose3d fails on this filter shape: {e}")
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    from oracle import physics_cpu as O
+    assert rel(O.conv3d(x, k, padding), y_ref) < 1e-6 and rel(O.conv_transpose3d(v, k, padding, x.shape[2:]), xt_ref) < 1e-5   # pins the oracle
+    with emu_backend():
+        pF = A.physics.functional
+        assert rel(pF.conv3d(x, k, padding=padding), y_ref) < 1e-5
+        assert rel(pF.conv_transpose3d(v, k, padding=padding), xt_ref) < 1e-5
+        assert rel(pF.conv3d(x, k, padding=padding, correlation=True), rF.conv3d(x, k, padding=padding, correlation=True)) < 1e-5
+        assert rel(pF.conv3d_fft(x, k, padding=padding), rF.conv3d_fft(x, k, padding=padding)) < 1e-4
+        assert rel(pF.conv_transpose3d_fft(v, k, padding=padding), rF.conv_transpose3d_fft(v, k, padding=padding)) < 1e-4
+        for use_fft in (False, True):
+            p = A.physics.Blur(filter=k, padding=padding, use_fft=use_fft, device="cpu")
+            q = dinv.physics.Blur(filter=k, padding=padding, use_fft=use_fft, device="cpu")
+            assert rel(p.A(x), q.A(x)) < 1e-4 and rel(p.A_adjoint(v), q.A_adjoint(v)) < 1e-4

@@ -60,6 +60,12 @@ def test_conv2d_and_transpose_emulated(mode, shape):
     E.check(l.dinv_conv2d_transpose(ctypes.byref(d), E.p(v), E.p(k), E.p(xt), None))
     lhs, rhs = float((y.double() * v.double()).sum()), float((x.double() * xt.double()).sum())
     assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0)
+    # gradient w.r.t. the filter, per (b, c) plane, against autograd through the fp64 reference convolution with a per-plane filter
+    kp = k.expand(B, C, fh, fw).clone().double().requires_grad_(True)
+    (_ref_conv(x, kp, mode, s) * v.double()).sum().backward()
+    dk = torch.full((B, C, fh, fw), float("nan"))
+    E.check(l.dinv_conv2d_filter_grad(ctypes.byref(d), E.p(x), E.p(v), E.p(dk), None))
+    assert float((dk.double() - kp.grad).norm() / kp.grad.norm()) < 2e-6
 
 
 @pytest.mark.parametrize("H,W", [(16, 32), (12, 20), (32, 64), (9, 14)])
@@ -80,3 +86,50 @@ def test_rfft2_irfft2_emulated(H, W):
     E.check(l.dinv_irfft2(E.p(out), E.p(back), ctypes.c_int64(P), ctypes.byref(ph), E.p(th), ctypes.byref(pw), E.p(tw),
                           ctypes.c_float(1.0 / (H * W)), E.p(ws), ctypes.c_size_t(ws.size), None))
     assert float((back.double() - x.double()).norm() / x.double().norm()) < 2e-6
+
+
+class Conv3dDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("batch", "channels", "depth", "height", "width", "fbatch", "fchannels", "fd", "fh", "fw",
+                                              "mode", "reserved")]
+
+
+def _ref_conv3(x, k, mode):
+    """true 3-D convolution of the padded volume, deepinv's conv3d (convolution.py:333-393)"""
+    B, C = x.shape[:2]
+    fd, fh, fw = k.shape[-3:]
+    if mode != "valid":
+        pad = ((fw - 1) // 2, fw // 2, (fh - 1) // 2, fh // 2, (fd - 1) // 2, fd // 2)
+        x = torch.nn.functional.pad(x, pad, mode=mode if mode != "constant" else "constant", value=0)
+    k = k.expand(B, C, fd, fh, fw)
+    out = torch.nn.functional.conv3d(x.reshape(1, B * C, *x.shape[2:]), torch.flip(k, (-3, -2, -1)).reshape(B * C, 1, fd, fh, fw), groups=B * C)
+    return out.reshape(B, C, *out.shape[2:])
+
+
+@pytest.mark.parametrize("mode", ["valid", "circular", "reflect", "replicate", "constant"])
+@pytest.mark.parametrize("shape", [(2, 2, 6, 9, 11, 1, 1, 3, 3, 3), (1, 3, 7, 8, 10, 1, 3, 2, 4, 3), (2, 1, 5, 12, 9, 2, 1, 3, 5, 2)])
+def test_conv3d_transpose_and_filter_grad_emulated(mode, shape):
+    """the volume kernels of csrc/blur.hip (conv3d / conv_transpose3d, convolution.py:333-452): against an fp64 grouped conv3d of
+    the padded volume, the dot test, and autograd of the reference form for the filter gradient; even and odd filter sizes"""
+    B, C, D, H, W, fb, fc, fd, fh, fw = shape
+    gen = torch.Generator().manual_seed(D * H * W + fd)
+    x = torch.randn(B, C, D, H, W, generator=gen)
+    k = torch.randn(fb, fc, fd, fh, fw, generator=gen)
+    l = E.lib()
+    d = Conv3dDesc(B, C, D, H, W, fb, fc, fd, fh, fw, MODES[mode], 0)
+    do, ho, wo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    E.check(l.dinv_conv3d_out_size(ctypes.byref(d), ctypes.byref(do), ctypes.byref(ho), ctypes.byref(wo)))
+    y = torch.full((B, C, do.value, ho.value, wo.value), float("nan"))
+    E.check(l.dinv_conv3d(ctypes.byref(d), E.p(x), E.p(k), E.p(y), None))
+    kp = k.expand(B, C, fd, fh, fw).clone().double().requires_grad_(True)
+    ref = _ref_conv3(x.double(), kp, mode)
+    assert tuple(ref.shape) == tuple(y.shape)
+    assert float((y.double() - ref.detach()).norm() / ref.detach().norm()) < 2e-6
+    v = torch.randn(*y.shape, generator=gen)
+    xt = torch.full((B, C, D, H, W), float("nan"))
+    E.check(l.dinv_conv3d_transpose(ctypes.byref(d), E.p(v), E.p(k), E.p(xt), None))
+    lhs, rhs = float((y.double() * v.double()).sum()), float((x.double() * xt.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0)
+    (ref * v.double()).sum().backward()
+    dk = torch.full((B, C, fd, fh, fw), float("nan"))
+    E.check(l.dinv_conv3d_filter_grad(ctypes.byref(d), E.p(x), E.p(v), E.p(dk), None))
+    assert float((dk.double() - kp.grad).norm() / kp.grad.norm()) < 2e-6

@@ -131,6 +131,10 @@ FAN_CASES = [
      {"pixel_spacing": 0.05, "source_radius": 3.0, "detector_radius": 5.0, "n_detector_pixels": 47, "detector_spacing": 0.11}),
     (24, torch.linspace(0, 360, 9)[:-1], 9, True,                     # detector finer than the pixels: many d per pixel
      {"pixel_spacing": 0.1, "source_radius": 8.0, "detector_radius": 2.0, "n_detector_pixels": 150, "detector_spacing": 0.03}),
+    (20, torch.linspace(0, 360, 13)[:-1], 2, False,                   # source close to the image: the stretch varies 10x along a ray
+     {"pixel_spacing": 0.1, "source_radius": 1.6, "detector_radius": 12.0, "n_detector_pixels": 40, "detector_spacing": 0.9}),
+    (20, torch.linspace(0, 360, 13)[:-1], 2, True,                    # very coarse detector: a detector pixel covers many image pixels
+     {"pixel_spacing": 0.02, "source_radius": 5.0, "detector_radius": 5.0, "n_detector_pixels": 6, "detector_spacing": 0.5}),
 ]
 
 
