@@ -35,6 +35,7 @@ PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # {kerne
 MFMA_BF16_PEAK = 2500e12     # FLOP/s dense bf16 matrix (v_mfma_f32_32x32x16_bf16), MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12   # FLOP/s dense fp32 matrix (v_mfma_f32_32x32x2_f32)
 LDS_READ_PEAK_TBPS = 150.0  # aggregate ds_read_b64/b128 rate with every CU streaming, MI355X_MICROARCH.md (LDS section)
+VALU_PEAK_TINSTR = 78.6     # 1e12 lane-instructions/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (the fp32 vector peak / 2 flops per FMA)
 
 
 def make_problem(dinv, B_local, offset, H, W, coils, device):
@@ -173,6 +174,9 @@ def main():
         if "lds_model_TB_per_s" in row:
             row["frac_of_lds_model"] = round(row["lds_model_TB_per_s"] / LDS_READ_PEAK_TBPS, 4)
             row.pop("frac_hbm_peak")    # meaningless for this operator
+        if "valu_model_Tinstr_per_s" in row:
+            row["frac_of_valu_model"] = round(row["valu_model_Tinstr_per_s"] / VALU_PEAK_TINSTR, 4)
+            row.pop("frac_hbm_peak")
         ops.append(row)
 
     def loop_row(name, cfg, batch, fn, gflop, unit, precision):
@@ -415,27 +419,55 @@ def other_config_ops(dinv, device, op_row, ops_last, loop_row, loop_rows_append)
     G = y.shape[2]
     alg = B * (W * W + G * A) * 4
     smp = float(B) * G * G * A
-    # Radon is a gather-rate problem, not an HBM one: every bilinear sample reads 4 taps x 4 B per image from
-    # the LDS window, so the model is the chip's aggregate ds_read rate (~150 TB/s for b64/b128 reads, MI355X_MICROARCH.md)
+    # Radon is a gather-rate problem, not an HBM one.  ONE model per kernel, the same in DESIGN 3.3:
+    #   forward: every bilinear sample reads 4 taps x 4 B per image from the LDS window with ds_read_b128 - the chip's aggregate
+    #            rate for that instruction is ~150 TB/s (256 B/clk/CU x 256 CUs x 2.4 GHz = 157, measured 150: MI355X_MICROARCH.md,
+    #            LDS section); `frac_of_lds_model` = (samples x 16 B / time) / 150 TB/s  (upper bound of the traffic: the march
+    #            skips the out-of-image part of the lattice);
+    #   adjoint: vector-ALU work - ~150 instructions per (pixel of 8 images, angle) (3 x 3 candidate lattice points, 9 per
+    #            candidate + staging) against 256 CUs x 128 lanes x 2.4 GHz = 78.6e12 lane-instructions/s; `frac_of_valu_model`.
     op_row("Tomography.A", "cfg3", B, lambda: phys.A(x), alg, n=5, Gsamples_per_s=smp / 1e9, lds_model_TB_per_s=smp * 16 / 1e12)
     op_row("Tomography.A_adjoint", "cfg3", B, lambda: phys.A_adjoint(y), alg, n=5, Gsamples_per_s=smp / 1e9,
-           lds_model_TB_per_s=smp * 16 / 1e12)
+           valu_model_Tinstr_per_s=float(-(-B // 8)) * W * W * A * 150.0 / 1e12)
     op_row("Tomography.fbp", "cfg3", B, lambda: phys.A_dagger(y, fbp=True), alg + 2 * B * G * A * 4, n=5)
-    # cfg3's loop at its per-GPU shard: FBP-initialised PnP-HQS, 30 iterations (prox by CG), DRUNet(1->1), DPIR-style schedules
-    # stretched to 30 iterations; DRUNet 1109 GFLOP per 512x512 call
-    import numpy as np
-    torch.manual_seed(0)
-    den3 = dinv.models.DRUNet(1, 1, pretrained=None).to(device).eval()
-    s30 = np.logspace(np.log10(49 / 255.0), np.log10(0.02), 30).astype("float32")
-    st30 = ((s30 / 0.02) ** 2 / 0.23).astype("float32")
-    hqs = dinv.optim.HQS(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den3), stepsize=list(map(float, st30)),
-                         g_param=list(map(float, s30)), max_iter=30, early_stop=False,
-                         custom_init=lambda yy, p: p.A_dagger(yy, fbp=True))
-    for prec in ("fp32", "bf16split"):      # the model default (the reference's arithmetic type), then the throughput setting
-        den3.conv_precision = prec
-        loop_row("FBP + PnP-HQS 30 it (CG prox) + DRUNet(1->1): loop" + ("" if prec == "fp32" else " [bf16split]"), "cfg3", B,
-                 lambda: hqs(y, phys), 30 * 1109.0 * B, unit="images_per_s", precision=prec)
-    del phys, y, den3, hqs
+    # cfg3's loop at its per-GPU shard: FBP-initialised PnP-HQS, 30 iterations (prox by CG with the reference's default stopping rule),
+    # DRUNet(1->1) (1109 GFLOP per 512x512 call), DPIR-style schedules stretched to 30 iterations.  With the fixture
+    # tests/golden/cfg3_full.npz (made by tests/golden/make_golden_r5.py through the REAL reference) the shard is 8 copies of the
+    # fixture's image - the reference's CG stops on `torch.all(residual < tol)` over the batch, so identical units stop where its
+    # single-image run stopped - and the row carries the FULL-LENGTH parity of the reconstruction (checker only; the same helper is
+    # the body of tests/test_named_shapes_gpu.py::test_cfg3_fbp_pnp_hqs_full_length_30_iterations).
+    del phys, y
+    fixture = os.path.join(ROOT, "tests", "golden", "cfg3_full.npz")
+    if os.path.exists(fixture):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_named_shapes_gpu as NS
+        d3 = NS.load("cfg3_full")
+        res3 = NS.full_length_cfg3(dinv, device, d3, B=B, precisions=("fp32", "bf16split"), runs=2)
+        for prec, r in res3.items():
+            loop_rows_append({"op": "FBP + PnP-HQS 30 it (CG prox) + DRUNet(1->1): loop" + ("" if prec == "fp32" else " [bf16split]"),
+                              "config": "cfg3", "batch": B, "ms": round(r["seconds"] * 1e3, 1), "images_per_s": round(B / r["seconds"], 3),
+                              "denoiser_TFLOP_per_s": round(30 * 1109.0 * B / r["seconds"] / 1e3, 1), "conv_precision": prec,
+                              "finite": r["finite"], "parity_rel_err": float(f"{r['vs_reference']:.3e}"),
+                              "parity_rel_err_max_over_iterations": float(f"{r['trace_max']:.3e}"),
+                              "A_adjoint_A_calls": r["ata_calls"], "A_adjoint_A_calls_reference": r["ata_calls_reference"],
+                              "parity": "image 0 of the shard after all 30 iterations against deepinv.optim.HQS on the same seeds "
+                                        "(tests/golden/cfg3_full.npz), and the worst iteration of the denoiser-output trace"})
+    else:
+        import numpy as np
+        phys = dinv.physics.Tomography(angles=A, img_width=W, circle=False, normalize=True, device=device)
+        y = phys.A(x)
+        torch.manual_seed(0)
+        den3 = dinv.models.DRUNet(1, 1, pretrained=None).to(device).eval()
+        s30 = np.logspace(np.log10(49 / 255.0), np.log10(0.02), 30).astype("float32")
+        st30 = ((s30 / 0.02) ** 2 / 0.23).astype("float32")
+        hqs = dinv.optim.HQS(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den3), stepsize=list(map(float, st30)),
+                             g_param=list(map(float, s30)), max_iter=30, early_stop=False,
+                             custom_init=lambda yy, p: p.A_dagger(yy, fbp=True))
+        for prec in ("fp32", "bf16split"):
+            den3.conv_precision = prec
+            loop_row("FBP + PnP-HQS 30 it (CG prox) + DRUNet(1->1): loop" + ("" if prec == "fp32" else " [bf16split]"), "cfg3", B,
+                     lambda: hqs(y, phys), 30 * 1109.0 * B, unit="images_per_s", precision=prec)
+        del phys, y, den3, hqs
     # the same geometry with fan-beam rays (first-generation gather kernels: stated, not tuned)
     fphys = dinv.physics.Tomography(angles=A, img_width=W, circle=False, normalize=False, fan_beam=True, device=device)
     fy = fphys.A(x)

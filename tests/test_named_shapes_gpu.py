@@ -134,6 +134,79 @@ def test_cfg5_downsampling_diffpir_256(dev, monkeypatch):
     assert rel_err(sub(out, st), d["out_exact"]) < TOL       # ... and against the fp64 evaluation of the same sample path
 
 
+def full_length_cfg3(dinv, dev, d, B=8, precisions=None, runs=1):
+    """BASELINE configs[2] at FULL length on the per-GPU shard (8 images 512x512, 720 angles): FBP-initialised PnP-HQS, 30
+    iterations, the prox by CG with the reference's DEFAULT settings (max_iter 50, tol 1e-4: the number of CG iterations is
+    decided by `torch.all(residual < tol)` over the BATCH, conjugate_gradient.py:61), DRUNet(1->1), the schedules of bench.py.
+    The shard holds 8 copies of the fixture's image: the batch-coupled stopping test then stops every prox where the reference's
+    single-image run stopped it, and the batched kernel paths (8 images per Radon pixel group) are still the ones that run.
+    Returns {precision: errors of image 0 against the reference's reconstruction / denoiser outputs, CG counts, seconds}."""
+    import time
+
+    from oracle import drunet_cpu as OD
+
+    st, stt, iters = int(d["stride"]), int(d["stride_trace"]), int(d["iters"])
+    W, nang = 512, 720
+    x = torch.rand(1, 1, W, W, generator=gen(50)).expand(B, 1, W, W).contiguous().to(dev)
+    p = dinv.physics.Tomography(angles=nang, img_width=W, circle=False, normalize=True, device=dev)
+    assert abs(float(p.operator_norm) - float(d["operator_norm"])) < 1e-4 * float(d["operator_norm"])
+    assert (p.max_iter, p.tol) == (int(d["cg_max_iter"]), float(d["cg_tol"]))
+    y = p.A(x)
+    den = dinv.models.DRUNet(1, 1, pretrained=None).to(dev).eval()
+    den.load_state_dict(OD.init_state_dict(1, 1, seed=int(d["drunet_seed"])))
+    model = dinv.optim.HQS(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=[float(v) for v in d["steps"]],
+                           g_param=[float(v) for v in d["sigs"]], max_iter=iters, early_stop=False,
+                           custom_init=lambda yy, pp: pp.A_dagger(yy, fbp=True))
+    res = {}
+    from deepinv_amd.models.drunet import CONV_PRECISIONS
+    ata = p.A_adjoint_A
+    for prec in precisions or CONV_PRECISIONS:
+        den.conv_precision = prec
+        for _ in range(runs):
+            trace, calls = [], [0]
+            hook = den.register_forward_hook(lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt]))
+
+            def counting(v, **kw):
+                calls[0] += 1
+                return ata(v, **kw)
+
+            p.A_adjoint_A = counting
+            try:
+                with torch.no_grad():
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    rec = model(y, p)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+            finally:
+                hook.remove()
+                del p.A_adjoint_A
+        tr = torch.stack([t.cpu() for t in trace])
+        res[prec] = {"vs_reference": rel_err(sub(rec[:1], st), d["rec"]),
+                     "trace_max": max(rel_err(a, b) for a, b in zip(tr, d["den_outs"])),
+                     "copies_identical": bool(torch.equal(rec[:1].expand_as(rec), rec)),
+                     "ata_calls": calls[0], "ata_calls_reference": int(d["n_ata"].sum()), "seconds": dt,
+                     "finite": bool(torch.isfinite(rec).all())}
+    return res
+
+
+def test_cfg3_fbp_pnp_hqs_full_length_30_iterations(dev):
+    """configs[2] at its FULL length against the REAL reference (tests/golden/cfg3_full.npz, make_golden_r5.py: deepinv.optim.HQS,
+    deepinv/optim/optimizers.py:1459-1593, prox by deepinv's CG with its default stopping rule): the reconstruction after 30
+    iterations and the denoiser output of every iteration, both conv_precision settings"""
+    import deepinv_amd as dinv
+
+    if not os.path.exists(os.path.join(G, "cfg3_full.npz")):
+        pytest.skip("tests/golden/cfg3_full.npz not generated (tests/golden/make_golden_r5.py cfg3: ~1.5 h of CPU)")
+    d = load("cfg3_full")
+    res = full_length_cfg3(dinv, dev, d)
+    print("cfg3 full length:", {k: {a: (f"{b:.2e}" if isinstance(b, float) else b) for a, b in v.items()} for k, v in res.items()})
+    for prec, r in res.items():
+        assert r["finite"] and r["copies_identical"]
+        assert r["vs_reference"] < TOL, (prec, r)
+        assert r["trace_max"] < 10 * TOL, (prec, r)
+
+
 def full_length_cfg5(dinv, dev, d, B=16, precisions=None, runs=1):
     """BASELINE configs[4] at FULL length on the per-GPU shard (16 images 3x256x256): 100-step DiffPIR, unit 0 = the fixture's
     seeded image with the fixture's torch.randn_like draws replayed (the other units get different images and draws).  Returns
