@@ -21,6 +21,9 @@
 #ifndef DINV_MRIW_MINW
 #define DINV_MRIW_MINW 2      // waves per SIMD the rows kernels are compiled for
 #endif
+#ifndef DINV_MRIW_WPB
+#define DINV_MRIW_WPB 4       // waves per workgroup of the rows kernels (they share the LDS allocation and the twiddle table)
+#endif
 
 namespace dinv {
 namespace mriw {
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(64 * WPB, DINV_MRIW_MINW) void rows_dif_kernel(cons
         const int64_t pim = YIN ? (int64_t)ncoil * vol : vol;
         const float2* sp = (!YIN && maps) ? maps + ((int64_t)(aux_batch > 1 ? b : 0) * ncoil + n) * vol : nullptr;
         const float* mre = (YIN && mask) ? mask + (int64_t)(aux_batch > 1 ? b : 0) * 2 * vol : nullptr;
+        const float2 wq = twh[u];          // column twiddle of the epilogue, requested here: its latency hides behind the stages
         wave_lds_sync();     // the previous tile's epilogue has read `buf`
         // ---------------- stage 1: x * S (or M * y) straight from global memory -> LDS (x and the maps of a slice are shared by
         // the waves that run its coils at the same time: L2 / Infinity-Cache hits)
@@ -120,7 +124,6 @@ __global__ __launch_bounds__(64 * WPB, DINV_MRIW_MINW) void rows_dif_kernel(cons
         TF::last_inplace(buf, R, scale, lane);
         wave_lds_sync();
         // ---------------- epilogue: radix-R butterfly over the R rows + column twiddle W_H^(u q), store block rows q * 64 + u
-        const float2 wq = twh[u];
         float2* tout = t + (int64_t)p * vol + (int64_t)u * N;
 #pragma unroll
         for (int s = 0; s < NSE; ++s) {
@@ -512,21 +515,27 @@ inline int resident_waves_grid(int64_t wave_tiles, int wpb) {
     int cus = 256, dev = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-    const int64_t resident = (int64_t)cus * (4 * DINV_MRIW_MINW / wpb);       // DINV_MRIW_MINW waves per SIMD
+    const int64_t resident = std::max<int64_t>((int64_t)cus * 4 * DINV_MRIW_MINW / wpb, cus);       // DINV_MRIW_MINW waves per SIMD
     return (int)std::min<int64_t>(ceil_div(wave_tiles, wpb), resident);
 }
 
 #define DINV_MRIW_WIDTHS(X) X(256) X(320) X(512)
 
+// waves per workgroup of a rows kernel: DINV_MRIW_WPB where that many tiles (+ the twiddle table) fit the 160 KB of LDS, else 4
+template <class P, int R>
+constexpr int rows_wpb() {
+    using TF = TileFft<P, false, true, R, 64>;
+    constexpr size_t per_wave = ((TF::lds_floats2 + 1) / 2 * 2) * sizeof(float2), tab = TF::TAB * sizeof(float2);
+    return per_wave * DINV_MRIW_WPB + tab <= 160 * 1024 ? DINV_MRIW_WPB : 4;
+}
+
 template <int R, bool YIN>
 int launch_rows_dif(int W, const float* in, const float2* maps, const float* mask, float2* t, int64_t images, int ncoil, int aux_batch,
                     const void* tw, const void* th, hipStream_t s) {
-    constexpr int WPB = 4;
     const int64_t ntiles = images * CB;
-    const unsigned grid = (unsigned)resident_waves_grid(ntiles, WPB);
     const float sc = 1.0f / sqrtf((float)W);
     switch (W) {
-#define DINV_CASE(NN) case NN: hipLaunchKernelGGL((rows_dif_kernel<typename PlanForS<NN>::P, R, YIN, WPB>), dim3(grid), dim3(64 * WPB), 0, s, in, maps, mask, t, ncoil, aux_batch, ntiles, tw, th, sc); break;
+#define DINV_CASE(NN) case NN: { constexpr int WPB = rows_wpb<typename PlanForS<NN>::P, R>(); hipLaunchKernelGGL((rows_dif_kernel<typename PlanForS<NN>::P, R, YIN, WPB>), dim3((unsigned)resident_waves_grid(ntiles, WPB)), dim3(64 * WPB), 0, s, in, maps, mask, t, ncoil, aux_batch, ntiles, tw, th, sc); } break;
         DINV_MRIW_WIDTHS(DINV_CASE)
 #undef DINV_CASE
         default: return fail(2, "mri wave pipeline: unsupported width %d", W);
@@ -550,12 +559,10 @@ int launch_cols64_combine(int W, const float2* t, const float2* maps, float* x, 
 template <int R>
 int launch_rows_combine(int W, const float2* t, const float2* maps, float* x, int64_t batch, int ncoil, int maps_batch, const void* tw,
                         const void* th, hipStream_t s) {
-    constexpr int WPB = 4;
     const int64_t ntiles = batch * CB;
-    const unsigned grid = (unsigned)resident_waves_grid(ntiles, WPB);
     const float sc = 1.0f / sqrtf((float)W);
     switch (W) {
-#define DINV_CASE(NN) case NN: hipLaunchKernelGGL((rows_combine_kernel<typename PlanForS<NN>::P, R, WPB>), dim3(grid), dim3(64 * WPB), 0, s, t, maps, x, ncoil, maps_batch, ntiles, tw, th, sc); break;
+#define DINV_CASE(NN) case NN: { constexpr int WPB = rows_wpb<typename PlanForS<NN>::P, R>(); hipLaunchKernelGGL((rows_combine_kernel<typename PlanForS<NN>::P, R, WPB>), dim3((unsigned)resident_waves_grid(ntiles, WPB)), dim3(64 * WPB), 0, s, t, maps, x, ncoil, maps_batch, ntiles, tw, th, sc); } break;
         DINV_MRIW_WIDTHS(DINV_CASE)
 #undef DINV_CASE
         default: return fail(2, "mri wave pipeline: unsupported width %d", W);
