@@ -451,7 +451,9 @@ def other_config_ops(dinv, device, op_row, ops_last, loop_row, loop_rows_append)
                               "parity_rel_err_max_over_iterations": float(f"{r['trace_max']:.3e}"),
                               "A_adjoint_A_calls": r["ata_calls"], "A_adjoint_A_calls_reference": r["ata_calls_reference"],
                               "parity": "image 0 of the shard after all 30 iterations against deepinv.optim.HQS on the same seeds "
-                                        "(tests/golden/cfg3_full.npz), and the worst iteration of the denoiser-output trace"})
+                                        "(tests/golden/cfg3_full.npz), and the worst iteration of the denoiser-output trace (it follows a prox whose "
+                                        "truncated CG stopped one or two iterations apart from the reference's: "
+                                        "tests/test_named_shapes_gpu.py::test_cfg3_fbp_pnp_hqs_full_length_30_iterations)"})
     else:
         import numpy as np
         phys = dinv.physics.Tomography(angles=A, img_width=W, circle=False, normalize=True, device=device)

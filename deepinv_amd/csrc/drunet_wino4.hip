@@ -31,6 +31,7 @@
 //   cover 1 KB per wave instruction.  The next tile's first two raw blocks are requested as soon as all accumulators are dead
 //   and land in registers behind the second exchange round.  The first block of a tile accumulates onto the constant 0.
 #include "drunet_common.hpp"
+#include "drunet_split_common.hpp"
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -42,9 +43,15 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NTHR = 512;
-constexpr int VP = 148;                  // floats of one (lane half, position) row of V: 36 points x 4 K steps + 4 pad
-constexpr int VHALF = 32 * VP;
-constexpr int VBUF = 2 * VHALF;          // floats per V stage (37.9 KB)
+// One (lane half, position) row of V = 36 points x 4 K steps in 43 16-byte slots: 3 / 1 / 3 empty slots behind the points 8 / 17 / 26
+// and 4 empty slots between the two lane halves.  Reads (16 bytes per lane, 32 rows): any odd slot pitch is conflict-free.  Writes
+// (4 bytes; a 32-lane group = 8 channels x 2 neighbouring positions x the 2 row halves): the slot of a lane is
+// 43 position + d row_half + 4 lane_half (mod 8) with d = 34, 22, 10 for the three write rows - eight different slots, no conflicts
+// (the dense 37-slot row made every V write 2- to 4-way conflicted)
+constexpr int VP = 172;
+constexpr int VHALF = 32 * VP + 16;
+constexpr int VBUF = 2 * VHALF;          // floats per V stage (44.2 KB)
+__host__ __device__ constexpr int vslot(int k) { return k + (k >= 9 ? 3 : 0) + (k >= 18 ? 1 : 0) + (k >= 27 ? 3 : 0); }   // 16-byte slot of point k
 constexpr int EXCH = 4 * 8 * 8 * 32 * 4; // floats of the epilogue exchange: [q 4][value 8][cout quad 8][position 32][4]
 constexpr int UBLK = 8 * 9 * 64 * 4;     // floats of U per (cout tile, channel block): [wave 8][point 9][lane 64][4]
 
@@ -104,6 +111,40 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 b) {
     return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
 }
 
+// two fp32 -> one register of two bf16 (round to nearest even): v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+#ifdef DINV_EMU
+    return f2bf(a) | (f2bf(b) << 16);
+#else
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+#endif
+}
+// x = xh + xm + xl, three bf16 parts (round to nearest even each; the two differences are exact), as packed pairs of ADJACENT
+// channels: h.x = (h0 | h1 << 16), h.y = (h2 | h3 << 16).  11 vector instructions per two values.
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hp, unsigned& mp, unsigned& lp) {
+    hp = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hp << 16), rb = b - __uint_as_float(hp & 0xffff0000u);
+    mp = cvt_pk_bf16(ra, rb);
+    lp = cvt_pk_bf16(ra - __uint_as_float(mp << 16), rb - __uint_as_float(mp & 0xffff0000u));
+}
+__device__ __forceinline__ void split3(const float4& x, uint2& h, uint2& m, uint2& l) {
+    split3_pair(x.x, x.y, h.x, m.x, l.x);
+    split3_pair(x.z, x.w, h.y, m.y, l.y);
+}
+// the 8 K slots of a lane in one 16-deep bf16 step: [X of its channels 0..3 | Y of its channels 0..3] - the packed pairs as they
+// are, no byte shuffles (A and B use the same slot order, any order is as good as another)
+__device__ __forceinline__ uint4 pair(const uint2& X, const uint2& Y) { return make_uint4(X.x, X.y, Y.x, Y.y); }
+
+#ifdef DINV_EMU
+#define DINV_PIN(x) ((void)0)
+#define DINV_PIN2(x, y) ((void)0)
+#else
+#define DINV_PIN(x) asm volatile("" : "+v"(x))
+#define DINV_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
+#endif
 #ifdef DINV_EMU
 #define DINV_W4_ATTR
 #else
@@ -112,7 +153,23 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 b) {
 
 // SPLIT = false: the whole tiles jt = j, j + slots, ... < full_x of the workgroup's XCD range.  SPLIT = true (a second launch): one
 // part (split_f-th of the input channels) of one tail tile per workgroup; it publishes partial outputs and the last part combines
-template <int TH, int TW, bool RELU, int NRES, bool SPLIT>
+// BF3 = true (dinv_conv3x3_winograd4_bf16x3): the same kernel with every fp32 multiply evaluated on the BF16 matrix cores as a
+// THREE-part operand split x = xh + xm + xl (round to nearest even each; exact to 2^-24) and SIX products
+//   um vm + uh vh,   um vh + uh vl,   uh vm + ul vh
+// (dropped: um vl, ul vm, ul vl - <= 2^-23 |u||v| when both operands sit at the half-ulp extremes of their bf16 parts, ~2^-26
+// rms; tests/test_emu_drunet.py::test_winograd4_bf16x3_worst_case), fp32 accumulation: three v_mfma_f32_32x32x16_bf16 per point
+// and 8-channel block instead of four v_mfma_f32_32x32x2_f32, 3/8 of their matrix-pipe time.  A 16-deep bf16 step holds 8
+// channels x 2 parts (the 8 K slots of a lane half = part X of its 4 channels, then part Y), and with the parts kept in the
+// order (m, h, l) the three operand pairs are overlapping four-register WINDOWS of six registers - nothing is duplicated:
+//   A = (um, uh) x B = (vm, vh),   A = (um, uh) x B = (vh, vl),   A = (uh, ul) x B = (vm, vh).
+// U arrives already split (hip/drunet.py: pack_winograd4_bf16x3_weight; 24 bytes per lane and point, loaded as 16 + 8 three points
+// ahead); V is split in the registers of the wave that multiplies it, one point ahead of its use.  V stage, staging, transform
+// and epilogue are the fp32 kernel's.  Measured (round 5, scripts/r05/wino4_bench.cpp, profiles/r05_wino4_*): per-layer error
+// 1.1 / 1.5 / 2.0 / 2.9e-6 at the four DRUNet levels (fp32 form: 1.2 / 1.6 / 2.4 / 3.2e-6); main loop 4500 cycles per block
+// against 5500 (matrix pipe alone: 1750 against 4600) - and the SAME wall time at 32 slices, because the package sits at its
+// 1400 W cap under either form: the clock settles at 1.95 GHz under this one and at 2.32 GHz under the fp32 one
+// (profiles/r05_wino4_power_cap_smi.log).  Faster only where the cap is not reached (4 slices: 12-14 %).  Opt-in.
+template <int TH, int TW, bool RELU, int NRES, bool SPLIT, bool BF3 = false>
 __global__ __launch_bounds__(NTHR) DINV_W4_ATTR
 void conv3x3_wino4_kernel(W4Args a) {
     using S = Shape4<TH, TW>;
@@ -127,8 +184,12 @@ void conv3x3_wino4_kernel(W4Args a) {
     const int64_t xcs = a.g.cs * 8;
 
     // ---- MFMA role: this lane's B-operand row of the V stage and its A fragments inside one (cout tile, block) slab of U
-    int vrd = S::VOFF + (h * 32 + l31) * VP + q * 36;   // (float index into lds: the V stages sit behind the raw stages; this wave reads points 9q..)
-    const uint32_t uoff = (uint32_t)(wave * 9 * 1024 + lane * 16);
+    int vrd = S::VOFF + h * VHALF + l31 * VP + (9 * q + 3 * (q & 1) + 4 * (q >> 1)) * 4;   // (float index into lds: the V stages sit behind the raw stages; this wave reads points 9q..)
+    // (BF3: a point of a wave = [lane 64][um 4 | uh 4] then [lane 64][ul 4] bf16: 1536 bytes)
+    constexpr int UB = BF3 ? UBLK * 3 / 2 : UBLK;               // floats of U per (cout tile, channel block)
+    constexpr int UPT = BF3 ? 1536 : 1024;                      // bytes per (wave, point)
+    const uint32_t uoff = (uint32_t)(wave * 9 * UPT + lane * 16);
+    const uint32_t uoff_l = (uint32_t)(wave * 9 * UPT + 1024 + lane * 8);
 
     // ---- transform role: thread = (position, channel of the block, row half)
     const int tch = tid & 7, trh = (tid >> 3) & 1, tpos = tid >> 4;
@@ -144,9 +205,10 @@ void conv3x3_wino4_kernel(W4Args a) {
     //   0-5 row 0 | 6-8 row 1 cols 0-2 | 9-14 row 2 | 15-17 row 1 cols 3-5 | 18-23 row 3 | 24-26 row 4 cols 0-2 | 27-32 row 5 | 33-35 row 4 cols 3-5
     // so that the SAME six accumulators die first in every wave's epilogue.  V write rows (A, B, C) = (0, 1, 2) / (5, 4, 3):
     // B is the row that is stored in two pieces (its columns 3-5 sit 9 slots behind its columns 0-2)
-    const int vwbase = ((tch >> 2) * 32 + tpos) * VP + (tch & 3);
-    int vwa = S::VOFF + vwbase + (trh ? 27 : 0) * 4, vwb = S::VOFF + vwbase + (trh ? 24 : 6) * 4,
-        vwc = S::VOFF + vwbase + (trh ? 18 : 9) * 4;
+    const int vwbase = (tch >> 2) * VHALF + tpos * VP + (tch & 3);
+    int vwa = S::VOFF + vwbase + (trh ? vslot(27) : vslot(0)) * 4, vwb = S::VOFF + vwbase + (trh ? vslot(24) : vslot(6)) * 4,
+        vwc = S::VOFF + vwbase + (trh ? vslot(18) : vslot(9)) * 4;
+    static_assert(vslot(9) == 12 && vslot(18) == 22 && vslot(27) == 34 && vslot(15) - vslot(6) == vslot(33) - vslot(24), "V row layout");
     // LDS map: [raw stage 0][raw stage 1][V stage 0][V stage 1].  The V bases are beyond the 64 KB reach of a ds immediate
     // offset: they are folded into the per-lane offsets above, which are made opaque so that the compiler addresses every
     // access as (one base register + immediate) instead of hoisting one address register per distinct constant
@@ -172,7 +234,7 @@ void conv3x3_wino4_kernel(W4Args a) {
             pw = a.d_nct.div((uint32_t)logical);
             ct = (int)((uint32_t)logical - pw * (uint32_t)a.nct);
         }
-        wsrc = a.w + (int64_t)ct * a.ncb * UBLK;
+        wsrc = a.w + (int64_t)ct * a.ncb * UB;
         int t = tid;
         DINV_OPAQUE(t);   // recompute the per-lane constants per tile instead of keeping them live
 #pragma unroll
@@ -206,11 +268,17 @@ void conv3x3_wino4_kernel(W4Args a) {
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, 0xffffffff, 0x00020000);
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, (int)soff, 0));
     };
-    auto ld_u = [&](const float* wt, int cb, int k) { return ld4_so(wt, uoff, (uint32_t)(cb * (UBLK * 4) + k * 1024)); };
+    auto ld_u = [&](const float* wt, int cb, int k) { return ld4_so(wt, uoff, (uint32_t)(cb * (UB * 4) + k * UPT)); };
+    auto ld_ul = [&](const float* wt, int cb, int k) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 0xffffffff, 0x00020000);
+        return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, uoff_l, (int)(cb * (UB * 4) + k * UPT), 0));
+    };
     auto ld_x = [&](int cb, int i) { return ld4_so(a.x + cb * xcs, goff[i], 0u); };
 
     f32x16 acc[9];
     float4 u[3], v[2];
+    uint2 ulo[3];                     // (BF3) u[] holds (um, uh) of a point as four registers of bf16 pairs, ulo[] its ul
+    uint2 vm[2], vh[2], vl[2];        // (BF3) the three bf16 parts of the current and of the next point's V
     float t[3][6];
     float e7[7];
     float4 pr[S::NLD], pr2[S::NLD];
@@ -236,7 +304,7 @@ void conv3x3_wino4_kernel(W4Args a) {
     // row i of (B^T d) B: outputs 0..2 (part 0) or 3..5 (part 1), written to the V stage
     auto tr_cols = [&](float* vst, int i, int part) {
         const int wr = i == 0 ? vwa : i == 1 ? vwb : vwc;
-        const int hi = i == 1 ? 36 : 12;          // float offset of columns 3-5 behind columns 0-2
+        const int hi = i == 1 ? (vslot(15) - vslot(6)) * 4 : 12;          // float offset of columns 3-5 behind columns 0-2
         const float* tt = t[i];
         if (part == 0) {
             const float o0 = fmaf(-5.f, tt[2], fmaf(4.f, tt[0], tt[4]));
@@ -312,6 +380,7 @@ void conv3x3_wino4_kernel(W4Args a) {
             if (stage_ok(i)) { st4(R0 + loff(i), pr[i]); st4(R0 + S::RAWF + loff(i), pr2[i]); }
         u[0] = ld_u(wt, ecb0, 0);
         u[1] = ld_u(wt, ecb0, 1);
+        if constexpr (BF3) { ulo[0] = ld_ul(wt, ecb0, 0); ulo[1] = ld_ul(wt, ecb0, 1); u[2] = ld_u(wt, ecb0, 2); ulo[2] = ld_ul(wt, ecb0, 2); }
         lds_barrier();
         DINV_STAMP(1);
 #pragma unroll
@@ -321,6 +390,10 @@ void conv3x3_wino4_kernel(W4Args a) {
         lds_barrier();
         DINV_STAMP(2);
         v[0] = ld4(V0 + vrd);
+        if constexpr (BF3) {
+            v[1] = ld4(V0 + vrd + 4);
+            split3(v[0], vh[0], vm[0], vl[0]);
+        }
 
         // ---- one 8-channel block = 36 slots of one MFMA + its share of: the U ring (3 points ahead, straight from L2), the
         // V ring (1 point ahead), staging block cb+2 (loads in slots 0.., LDS writes in slots 24..), transforming block cb+1
@@ -335,6 +408,58 @@ void conv3x3_wino4_kernel(W4Args a) {
             float* rst = R0 + P * S::RAWF;
             const int cbu = cb + 1 < ecb1 ? cb + 1 : ecb1 - 1;   // past the end: re-read the last block (unused data)
             const int cbs = cb + 2 < ecb1 ? cb + 2 : ecb1 - 1;
+            if constexpr (BF3) {
+                // 27 slots = 9 points x 3 bf16 MFMAs.  The 8 K slots of a lane = [part X of its 4 channels | part Y of its 4 channels];
+                // with U = (um, uh, ul) and V = (vm, vh, vl) as six registers each, the three operand pairs are register WINDOWS:
+                //   A = (um, uh) x B = (vm, vh)  ->  um vm + uh vh
+                //   A = (um, uh) x B = (vh, vl)  ->  um vh + uh vl
+                //   A = (uh, ul) x B = (vm, vh)  ->  uh vm + ul vh          = the six products, nothing duplicated
+                // U arrives split (packed on the host), two points ahead; V: raw fp32 from the stage two points ahead, split one
+                // point ahead (point pt's slots split point pt + 1), so that no MFMA waits for the conversion of its own operand
+                static_for<27>([&](auto s_) {
+                    constexpr int SL = decltype(s_)::value, pt = SL / 3, j = SL % 3;
+                    constexpr int cur = (pt + P) % 2, nx = (pt + 1 + P) % 2, ur = pt % 3;
+                    if constexpr (SL == 24) lds_barrier();
+                    uint4 A, B;
+                    if constexpr (j == 0) { A = __builtin_bit_cast(uint4, u[ur]); B = pair(vm[cur], vh[cur]); }
+                    if constexpr (j == 1) { A = __builtin_bit_cast(uint4, u[ur]); B = pair(vh[cur], vl[cur]); }
+                    if constexpr (j == 2) {
+                        A = make_uint4(__float_as_uint(u[ur].z), __float_as_uint(u[ur].w), ulo[ur].x, ulo[ur].y);
+                        B = pair(vm[cur], vh[cur]);
+                    }
+                    // (the matrix instruction is a pure value to the compiler and would drift across the slot boundaries: its
+                    // accumulator is made opaque on both sides, which ties it to this slot)
+                    if constexpr (FIRST && j == 0) acc[pt] = mfma_bf16(A, B, (f32x16)(0.f));
+                    else { DINV_PIN(acc[pt]); acc[pt] = mfma_bf16(A, B, acc[pt]); }
+                    DINV_PIN(acc[pt]);
+                    if constexpr (j == 2) {           // U ring: three points ahead, straight from L2 (this point's entry is free now)
+                        constexpr int k = pt + 3;
+                        if constexpr (k < 9) { u[k % 3] = ld_u(wt, cb, k); ulo[k % 3] = ld_ul(wt, cb, k); }
+                        else { u[k % 3] = ld_u(wt, cbu, k - 9); ulo[k % 3] = ld_ul(wt, cbu, k - 9); }
+                    }
+                    // V ring: raw(pt + 2) replaces raw(pt) (split during point pt - 1); the next block's first two points are
+                    // behind the barrier
+                    if constexpr (pt < 7 && j == 0) v[cur] = ld4(vcur + vrd + (pt + 2) * 4);
+                    if constexpr (pt == 8 && j == 0) { v[nx] = ld4(vnxt + vrd); v[cur] = ld4(vnxt + vrd + 4); }
+                    // (the inputs of every piece of vector work are made opaque in its slot: pure arithmetic would drift to the
+                    // slot of its operands' loads and wait for them there)
+                    if constexpr (pt < 8 && j == 0) { DINV_PIN2(v[nx].x, v[nx].y); split3_pair(v[nx].x, v[nx].y, vh[nx].x, vm[nx].x, vl[nx].x); }
+                    if constexpr (pt < 8 && j == 1) { DINV_PIN2(v[nx].z, v[nx].w); split3_pair(v[nx].z, v[nx].w, vh[nx].y, vm[nx].y, vl[nx].y); }
+                    if constexpr (pt == 8 && j == 2) { DINV_PIN2(v[nx].x, v[nx].z); split3(v[nx], vh[nx], vm[nx], vl[nx]); }
+                    if constexpr (SL < S::NLD) pr[SL] = ld_x(cbs, SL);
+                    if constexpr (SL < 18 && SL % 3 == 0) tr_read(rnxt, SL / 3);
+                    if constexpr (SL < 18 && SL % 3 == 2) { DINV_PIN2(e7[0], e7[3]); DINV_PIN2(e7[4], e7[5]); tr_rows(SL / 3); }
+                    if constexpr (SL >= 18 && SL < 24) {
+                        constexpr int ti = (SL - 18) / 2;
+                        DINV_PIN2(t[ti][1], t[ti][2]); DINV_PIN2(t[ti][3], t[ti][4]);
+                        tr_cols(vnxt, ti, (SL - 18) % 2);
+                    }
+                    if constexpr (SL >= 20 && SL < 20 + S::NLD)
+                        if (stage_ok(SL - 20)) st4(rst + loff(SL - 20), pr[SL - 20]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                return;
+            }
             static_for<36>([&](auto s_) {
                 constexpr int SL = decltype(s_)::value, pt = SL / 4, m = SL % 4;
                 if constexpr (SL == 30) lds_barrier();
@@ -586,7 +711,7 @@ LastSplit& last_split() {
     return v;
 }
 
-template <int TH, int TW, bool RELU, int NRES>
+template <int TH, int TW, bool RELU, int NRES, bool BF3>
 int launch_shape(W4Args a, hipStream_t st) {
     using S = Shape4<TH, TW>;
     a.nty = (int32_t)ceil_div(a.g.h / 4, TH);
@@ -603,7 +728,7 @@ int launch_shape(W4Args a, hipStream_t st) {
     a.d_nct = make_fastdiv((uint32_t)a.nct);
     const size_t shm = S::LDSF * sizeof(float) + 16;   // + the ticket word of the tail split
     static std::atomic<uint64_t> configured{0};   // per instantiation: bit d = attribute set on device d
-    auto kern = conv3x3_wino4_kernel<TH, TW, RELU, NRES, false>;
+    auto kern = conv3x3_wino4_kernel<TH, TW, RELU, NRES, false, BF3>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(3, "hipGetDevice failed");
     const uint64_t bit = 1ull << (dev & 63);
@@ -629,7 +754,7 @@ int launch_shape(W4Args a, hipStream_t st) {
         DINV_CHECK_LAUNCH();
     }
     if (a.split_f > 1) {
-        auto kern_s = conv3x3_wino4_kernel<TH, TW, RELU, NRES, true>;
+        auto kern_s = conv3x3_wino4_kernel<TH, TW, RELU, NRES, true, BF3>;
         static std::atomic<uint64_t> configured_s{0};
         if (!(configured_s.load(std::memory_order_relaxed) & bit)) {
             if (hipFuncSetAttribute((const void*)kern_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
@@ -643,7 +768,7 @@ int launch_shape(W4Args a, hipStream_t st) {
     return 0;
 }
 
-template <bool RELU, int NRES>
+template <bool RELU, int NRES, bool BF3>
 int launch_any(const W4Args& a, hipStream_t st) {
     const int tyn = a.g.h / 4, txn = a.g.w / 4;
     // rectangle shape with the least padded-tile waste; ties go to the largest rectangle (fewest halo loads)
@@ -655,9 +780,9 @@ int launch_any(const W4Args& a, hipStream_t st) {
         if (w < bw * 0.999) { bw = w; best = i; }
     }
     switch (best) {
-        case 0: return launch_shape<4, 8, RELU, NRES>(a, st);
-        case 1: return launch_shape<4, 4, RELU, NRES>(a, st);
-        default: return launch_shape<2, 2, RELU, NRES>(a, st);
+        case 0: return launch_shape<4, 8, RELU, NRES, BF3>(a, st);
+        case 1: return launch_shape<4, 4, RELU, NRES, BF3>(a, st);
+        default: return launch_shape<2, 2, RELU, NRES, BF3>(a, st);
     }
 }
 
@@ -682,7 +807,7 @@ extern "C" int dinv_conv3x3_winograd4_last_split(int32_t* split_f, int32_t* n_ta
     return 0;
 }
 
-extern "C" int dinv_conv3x3_winograd4(const dinv_act_geom* g, const float* x, const float* w_wino4, int32_t cin,
+static int winograd4_any(bool bf3, const dinv_act_geom* g, const float* x, const float* w_wino4, int32_t cin,
                                       int32_t cout, float* y, const float* res1, int32_t relu, void* workspace,
                                       size_t workspace_bytes, dinv_stream_t stream) {
     if (check_geom(g)) return 1;
@@ -707,7 +832,24 @@ extern "C" int dinv_conv3x3_winograd4(const dinv_act_geom* g, const float* x, co
     a.stagger = getenv("DINV_W4_STAGGER") ? atoi(getenv("DINV_W4_STAGGER")) : 0;
 #endif
     hipStream_t st = (hipStream_t)stream;
-    if (relu) return launch_any<true, 0>(a, st);
-    if (res1) return launch_any<false, 1>(a, st);
-    return launch_any<false, 0>(a, st);
+    if (bf3) {
+        if (relu) return launch_any<true, 0, true>(a, st);
+        if (res1) return launch_any<false, 1, true>(a, st);
+        return launch_any<false, 0, true>(a, st);
+    }
+    if (relu) return launch_any<true, 0, false>(a, st);
+    if (res1) return launch_any<false, 1, false>(a, st);
+    return launch_any<false, 0, false>(a, st);
+}
+
+extern "C" int dinv_conv3x3_winograd4(const dinv_act_geom* g, const float* x, const float* w_wino4, int32_t cin,
+                                      int32_t cout, float* y, const float* res1, int32_t relu, void* workspace,
+                                      size_t workspace_bytes, dinv_stream_t stream) {
+    return winograd4_any(false, g, x, w_wino4, cin, cout, y, res1, relu, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dinv_conv3x3_winograd4_bf16x3(const dinv_act_geom* g, const float* x, const void* w_wino4x3, int32_t cin,
+                                             int32_t cout, float* y, const float* res1, int32_t relu, void* workspace,
+                                             size_t workspace_bytes, dinv_stream_t stream) {
+    return winograd4_any(true, g, x, static_cast<const float*>(w_wino4x3), cin, cout, y, res1, relu, workspace, workspace_bytes, stream);
 }

@@ -22,6 +22,10 @@ _declared = False
 # 32 tile positions) a launch must have for the F(4x4,3x3) kernel (one persistent workgroup per CU: 256 on MI355X)
 FP32_WINOGRAD_TILE = 4
 WINOGRAD4_MIN_TILES = 64
+# True: the F(4x4,3x3) launches of the fp32 setting evaluate their multiplies as a three-part bf16 split, six products on the bf16
+# matrix cores (dinv_conv3x3_winograd4_bf16x3: same per-layer accuracy, 3/8 of the matrix-pipe time).  Off by default: at the
+# BASELINE batch the package power cap makes both forms equally fast; it pays at small per-GPU batches
+FP32_WINOGRAD4_BF16X3 = False
 
 
 def _l():
@@ -37,6 +41,7 @@ def _l():
         l.dinv_conv3x3_tail.argtypes = [G, vp, vp, vp, i32, i32, vp, vp]
         l.dinv_conv3x3_winograd.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp]
         l.dinv_conv3x3_winograd4.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp, ctypes.c_size_t, vp]
+        l.dinv_conv3x3_winograd4_bf16x3.argtypes = [G, vp, vp, i32, i32, vp, vp, i32, vp, ctypes.c_size_t, vp]
         l.dinv_conv3x3_winograd4_workspace_bytes.restype = ctypes.c_size_t
         l.dinv_conv3x3_winograd4_workspace_bytes.argtypes = []
         l.dinv_conv3x3_winograd4_last_split.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(i32)]
@@ -193,6 +198,21 @@ def pack_winograd4_weight(w: torch.Tensor) -> torch.Tensor:
     u = u.reshape(cout, cin, 36)[:, :, list(WINOGRAD4_POINT_SLOTS)]     # slot order: see WINOGRAD4_POINT_SLOTS
     u = u.reshape(cout // 64, 2, 32, cin // 8, 2, 4, 4, 9)              # ct, c2, r, cb, h, m, q, k
     return u.permute(0, 3, 1, 6, 7, 4, 2, 5).contiguous()               # ct, cb, c2, q, k, h, r, m
+
+
+def pack_winograd4_bf16x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW [Cout,Cin,3,3] -> the U of pack_winograd4_weight (fp64, rounded once to fp32) as its exact THREE-part bf16 split
+    u = uh + um + ul (round to nearest even each), packed for dinv_conv3x3_winograd4_bf16x3: per (cout tile, channel block, wave,
+    point) 1536 bytes = [lane 64][um 4 | uh 4] then [lane 64][ul 4] (bf16): the (um, uh) and (uh, ul) operand windows of the
+    wave's three bf16 MFMAs, loaded as 16 + 8 bytes per lane.  Returns a bfloat16 tensor [Cout/64][Cin/8][8][9][768]"""
+    u = pack_winograd4_weight(w)                                        # ct, cb, c2, q, k, h, r, m   (fp32)
+    hi = u.bfloat16()
+    r1 = u - hi.float()
+    mid = r1.bfloat16()
+    lo = (r1 - mid.float()).bfloat16()
+    ct, cb = u.shape[:2]
+    mh = torch.stack((mid, hi), dim=-2).reshape(ct, cb, 8, 9, 512)      # [h, r][part 2][m 4]
+    return torch.cat((mh, lo.reshape(ct, cb, 8, 9, 256)), dim=-1).contiguous()
 
 
 def pack_down_weight(w: torch.Tensor) -> torch.Tensor:
@@ -468,6 +488,22 @@ def conv3x3_winograd4(g, x, wino4, cin, cout, y, res1=None, relu=False, workspac
         tiles = g.batch * (g.height // 4) * (g.width // 4)
         _prof.append((e0, e1, "conv3x3_wino4_kernel", 2.0 * 9 * cin * cout * g.batch * g.height * g.width,
                       2.0 * 36 * cin * cout * tiles))
+
+
+def conv3x3_winograd4_bf16x3(g, x, wino4x3, cin, cout, y, res1=None, relu=False, workspace=None):
+    """conv3x3_winograd4 with the multiplies as a three-part bf16 split, six products on the bf16 matrix cores (fp32-equivalent:
+    csrc/drunet_wino4.hip, BF3); wino4x3 from pack_winograd4_bf16x3_weight"""
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_l().dinv_conv3x3_winograd4_bf16x3(ctypes.byref(g), ptr(x), ptr(wino4x3), cin, cout, ptr(y), ptr(res1), int(relu),
+                                             ptr(workspace), 0 if workspace is None else workspace.numel(), stream_ptr(y.device)))
+    if _prof is not None:
+        e1.record()
+        tiles = g.batch * (g.height // 4) * (g.width // 4)
+        # executed: 6 bf16 products per fp32 multiply of the F(4x4) form
+        _prof.append((e0, e1, "conv3x3_wino4_kernel<bf16x3>", 2.0 * 9 * cin * cout * g.batch * g.height * g.width,
+                      2.0 * 6 * 36 * cin * cout * tiles))
 
 
 def down2x2(gi, go, x, w, cin, cout, y):

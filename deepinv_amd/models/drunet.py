@@ -210,7 +210,7 @@ class DRUNet(Denoiser):
                 + tuple(p.data_ptr() for p in self.parameters()))
 
     def _prepare(self, device):
-        ver = (self._weights_version(), self._precision())     # the packs depend on the precision
+        ver = (self._weights_version(), self._precision(), K.FP32_WINOGRAD4_BF16X3)     # the packs depend on the precision
         if self._engine is not None and self._engine["ver"] == ver and self._engine["device"] == device:
             return self._engine
         e = {"ver": ver, "device": device, "ws": {}, "split": self._precision() == "bf16split"}
@@ -227,7 +227,8 @@ class DRUNet(Denoiser):
             wino = K.pack_winograd_weight(w) if (not split and ok and w.shape[1] >= 32) else None
             wsp = K.pack_wsplit_weight(w) if (split and ok) else None
             wino4 = K.pack_winograd4_weight(w) if (not split and ok) else None
-            return (p64, p32, wino, s2d, wsp, wino4)
+            wino4x3 = K.pack_winograd4_bf16x3_weight(w) if (not split and ok and K.FP32_WINOGRAD4_BF16X3) else None
+            return (p64, p32, wino, s2d, wsp, wino4, wino4x3)
 
         e["head"] = c3(self.m_head)
         e["tail"] = c3(self.m_tail)
@@ -284,7 +285,10 @@ class DRUNet(Denoiser):
         F(2x2,3x3) kernel, else the direct MFMA kernel"""
         if (pk[5] is not None and K.FP32_WINOGRAD_TILE == 4 and g.height % 4 == 0 and g.width % 4 == 0
                 and -(-g.batch * (g.height // 4) * (g.width // 4) // 32) * (pk[0][2] // 64) >= K.WINOGRAD4_MIN_TILES):
-            K.conv3x3_winograd4(g, x, pk[5], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=K.winograd4_workspace(x.device))
+            if pk[6] is not None:       # (K.FP32_WINOGRAD4_BF16X3 when the packs were built)
+                K.conv3x3_winograd4_bf16x3(g, x, pk[6], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=K.winograd4_workspace(x.device))
+            else:
+                K.conv3x3_winograd4(g, x, pk[5], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=K.winograd4_workspace(x.device))
             return
         if pk[2] is not None:
             K.conv3x3_winograd(g, x, pk[2], pk[0][1], pk[0][2], y, res1=res1, relu=relu)

@@ -183,6 +183,16 @@ size_t dinv_conv3x3_winograd4_workspace_bytes(void);
 int dinv_conv3x3_winograd4(const dinv_act_geom* g, const float* x, const float* w_wino4, int32_t cin, int32_t cout,
                            float* y, const float* res1, int32_t relu, void* workspace, size_t workspace_bytes,
                            dinv_stream_t stream);
+/* The same operator, workspace and tail split with every fp32 multiply evaluated on the BF16 matrix cores as a THREE-part operand
+ * split (x = xh + xm + xl, round to nearest even each: exact to 2^-24) and SIX products (um vm + uh vh, um vh + uh vl, uh vm +
+ * ul vh; the three dropped cross terms are <= 2^-23 |u||v| in the worst case, ~2^-26 rms), fp32 accumulation: per-layer error at or
+ * below the fp32 form's (1.1-2.9e-6 against 1.2-3.2e-6 at the DRUNet levels) at 3/8 of its matrix-pipe time
+ * (csrc/drunet_wino4.hip, BF3 = true).  Opt-in: at 32 slices the package power cap makes both forms equally fast.
+ * w_wino4x3: the U of dinv_conv3x3_winograd4, already split, in the same [cout/64][cin/8][wave 8][slot 9] order; per slot
+ *   1536 bytes = [lane 64][um 4 | uh 4] then [lane 64][ul 4] as bf16 (deepinv_amd/hip/drunet.py: pack_winograd4_bf16x3_weight). */
+int dinv_conv3x3_winograd4_bf16x3(const dinv_act_geom* g, const float* x, const void* w_wino4x3, int32_t cin, int32_t cout,
+                                  float* y, const float* res1, int32_t relu, void* workspace, size_t workspace_bytes,
+                                  dinv_stream_t stream);
 /* What the calling thread's last dinv_conv3x3_winograd4 did with its incomplete last round: the number of parts each tail tile
  * was cut into (1 = not cut) and the tail tiles per XCD (tests and diagnostics; either pointer may be NULL). */
 int dinv_conv3x3_winograd4_last_split(int32_t* split_f, int32_t* n_tail_tiles);

@@ -43,6 +43,7 @@ inline float4 make_float4(float x, float y, float z, float w) { return float4{x,
 inline int2 make_int2(int x, int y) { return int2{x, y}; }
 inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
@@ -244,6 +245,12 @@ typedef unsigned int emu_u32x4 __attribute__((ext_vector_type(4)));
 inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned off, int soff, int) {
     emu_u32x4 v = {0, 0, 0, 0};
     if ((uint64_t)off + soff + 16 <= r.num) std::memcpy(&v, r.base + off + soff, 16);
+    return v;
+}
+typedef unsigned int emu_u32x2 __attribute__((ext_vector_type(2)));
+inline emu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, unsigned off, int soff, int) {
+    emu_u32x2 v = {0, 0};
+    if ((uint64_t)off + soff + 8 <= r.num) std::memcpy(&v, r.base + off + soff, 8);
     return v;
 }
 inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off, int soff, int) {

@@ -162,6 +162,77 @@ def test_winograd4_conv_matches_fp64_conv(dev, B, H, W, cin, cout, mode):
     assert full[:, :, :, 0].abs().max() == 0 and full[:, :, :, W + 1:].abs().max() == 0
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(4, 320, 320, 64, 64), (4, 160, 160, 128, 128), (4, 80, 80, 256, 256), (4, 40, 40, 512, 512),
+                                              (32, 40, 40, 512, 512), (1, 36, 52, 64, 64), (3, 4, 4, 16, 64), (2, 16, 16, 48, 64)])
+@pytest.mark.parametrize("mode", ["relu", "res"])
+def test_winograd4_bf16x3_is_fp32_equivalent(dev, B, H, W, cin, cout, mode):
+    """dinv_conv3x3_winograd4_bf16x3 (csrc/drunet_wino4.hip, BF3: U pre-split on the host, V split in registers, three bf16 MFMAs per
+    point and 8-channel block = six products) at the four DRUNet level shapes and the odd shapes of the fp32 form's test: per-layer
+    error against the fp64 convolution at or below the fp32-MFMA form's (3.2e-6 is that form's worst level), with and without the
+    tail split, and 20 back-to-back launches bit-identical"""
+    from deepinv_amd.hip import drunet as K
+
+    geo, xa, ra, wp, x, w, r = _w4_case(dev, B, H, W, cin, cout, seed=B + H + cin)
+    w3 = K.pack_winograd4_bf16x3_weight(w)
+    assert w3.dtype == torch.bfloat16 and w3.numel() * 2 == wp.numel() * 6
+    res = ra if mode == "res" else None
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    ref = ref.relu() if mode == "relu" else ref + r.double()
+
+    def unpack(a):
+        return a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W)
+
+    y32, y3, y3s = (K.alloc(geo, cout, dev) for _ in range(3))
+    K.conv3x3_winograd4(geo, xa, wp, cin, cout, y32, res1=res, relu=mode == "relu")
+    K.conv3x3_winograd4_bf16x3(geo, xa, w3, cin, cout, y3, res1=res, relu=mode == "relu")
+    ws = torch.zeros(K._l().dinv_conv3x3_winograd4_workspace_bytes(), device=dev, dtype=torch.uint8)
+    K.conv3x3_winograd4_bf16x3(geo, xa, w3, cin, cout, y3s, res1=res, relu=mode == "relu", workspace=ws)
+    e32, e3, e3s = (rel_err(unpack(a), ref) for a in (y32, y3, y3s))
+    assert e3 < 3.2e-6 and e3s < 3.2e-6, (e3, e3s, e32)
+    assert e3 < 1.15 * e32 + 1e-7, (e3, e32)
+    assert int(ws[:8 * 64 * 4].view(torch.int32).abs().max()) == 0
+    full = y3[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)     # the zero frame is never written
+    assert full[:, :, 0].abs().max() == 0 and full[:, :, H + 1:].abs().max() == 0
+    assert full[:, :, :, 0].abs().max() == 0 and full[:, :, :, W + 1:].abs().max() == 0
+    for _ in range(20):
+        y = K.alloc(geo, cout, dev)
+        K.conv3x3_winograd4_bf16x3(geo, xa, w3, cin, cout, y, res1=res, relu=mode == "relu", workspace=ws)
+        assert torch.equal(y, y3s)
+
+
+@pytest.mark.parametrize("case", ["wide", "he_scale"])
+def test_winograd4_bf16x3_worst_case_bound(dev, case):
+    """the hardware twin of tests/test_emu_drunet.py::test_winograd4_bf16x3_worst_case (derivation there): element by element
+    |y - y_exact| <= 2^-22 winograd4_magnitude() for activations spanning 2^-20 .. 2^8 and weights 2^-12 .. 2^2 - the two-part
+    split's bound is 3 * 2^-16 (test_wsplit_worst_case_bound)"""
+    from deepinv_amd.hip import drunet as K
+    from winograd_ref import winograd4_magnitude
+
+    gen = torch.Generator().manual_seed(21)
+    B, H, W, cin, cout = 2, 64, 96, 128, 128
+
+    def wide(shape, lo, hi):
+        e = torch.randint(lo, hi + 1, shape, generator=gen).float()
+        return (1 + torch.rand(shape, generator=gen)) * torch.exp2(e) * (torch.randint(0, 2, shape, generator=gen) * 2 - 1).float()
+
+    if case == "wide":
+        x, w = wide((B, cin, H, W), -20, 8), wide((cout, cin, 3, 3), -12, 2)
+    else:
+        x, w = torch.randn(B, cin, H, W, generator=gen), torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    mag = winograd4_magnitude(x, w).to(dev)
+    x, w = x.to(dev), w.to(dev)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    geo = K.geom(B, H, W)
+    xa, ya = K.alloc(geo, cin, dev), K.alloc(geo, cout, dev)
+    xa[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:H + 1, 1:W + 1] = x.view(B, -1, 8, H, W).permute(1, 0, 3, 4, 2)
+    K.conv3x3_winograd4_bf16x3(geo, xa, K.pack_winograd4_bf16x3_weight(w), cin, cout, ya)
+    av = ya[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)
+    out = av[:, :, 1:H + 1, 1:W + 1].permute(1, 0, 4, 2, 3).reshape(B, cout, H, W).double()
+    assert bool(((out - ref).abs() <= 2.0 ** -22 * mag).all()), float(((out - ref).abs() / mag).max())
+    if case == "he_scale":
+        assert rel_err(out, ref) < 3.2e-6
+
+
 def _w4_case(dev, B, H, W, cin, cout, seed):
     from deepinv_amd.hip import drunet as K
 
@@ -180,7 +251,7 @@ def _w4_case(dev, B, H, W, cin, cout, seed):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,parts", [(4, 40, 40, 128, 64, 8), (8, 40, 40, 64, 64, 4), (8, 40, 40, 32, 64, 2),
-                                                   (32, 40, 40, 512, 512, 8), (4, 80, 80, 256, 256, 4)])
+                                                   (32, 40, 40, 512, 512, 8), (32, 80, 80, 256, 256, 4)])
 @pytest.mark.parametrize("mode", ["relu", "res"])
 def test_winograd4_tail_split_direct(dev, B, H, W, cin, cout, parts, mode):
     """The tail split of the F(4x4) kernel (csrc/drunet_wino4.hip, SPLIT = true: the tiles of the last incomplete round cut into

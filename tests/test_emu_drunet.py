@@ -672,7 +672,8 @@ def test_tail_conv_lane_shift(B, H, W, cin, cout, skip):
                                                  (20, 16, 16, 16, 128, "res"), (2, 32, 64, 48, 64, "relu"),
                                                  (3, 16, 16, 176, 128, "plain")])     # > 3 MB of U: cout tile outermost
 @pytest.mark.parametrize("split", [False, True])
-def test_winograd4_conv_matches_fp64(B, H, W, cin, cout, mode, split):
+@pytest.mark.parametrize("bf3", [False, True])
+def test_winograd4_conv_matches_fp64(B, H, W, cin, cout, mode, split, bf3):
     """csrc/drunet_wino4.hip (Winograd F(4x4,3x3) on the fp32 matrix cores: U fragments straight from memory, V through LDS,
     wave = 9 points of a cout half, two-round exchange in the epilogue) against an fp64 convolution: every rectangle shape
     (4x8 / 4x4 / 2x2 tiles), partial rectangles (W = 12, 36, H = 20), position groups that straddle images, several tiles per
@@ -684,7 +685,7 @@ def test_winograd4_conv_matches_fp64(B, H, W, cin, cout, mode, split):
     r = torch.randn(B, cout, H, W, generator=gen)
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from deepinv_amd.hip.drunet import pack_winograd4_weight
+    from deepinv_amd.hip.drunet import pack_winograd4_weight, pack_winograd4_bf16x3_weight
     g = geom(B, H, W)
     xa = to_act(x, g)
     ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
@@ -695,14 +696,15 @@ def test_winograd4_conv_matches_fp64(B, H, W, cin, cout, mode, split):
     ra = to_act(r, g)
     ya = torch.zeros((cout // 8, g.cs, 8))
     ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, 1:H + 1, 1:W + 1] = float("nan")   # only interiors are written
-    wp = pack_winograd4_weight(w)
+    wp = pack_winograd4_bf16x3_weight(w) if bf3 else pack_winograd4_weight(w)    # (bf3: U split into three bf16 parts on the host)
     l = E.lib()
     l.dinv_conv3x3_winograd4_workspace_bytes.restype = ctypes.c_size_t
     ws = torch.zeros(l.dinv_conv3x3_winograd4_workspace_bytes(), dtype=torch.uint8) if split else None
     for _ in range(2 if split else 1):      # twice: the second launch finds the ticket words reset by the first
         if split:
             ya[:, g.sl:g.sl + g.np].view(-1, B, g.hp, g.wp, 8)[:, :, 1:H + 1, 1:W + 1] = float("nan")
-        E.check(l.dinv_conv3x3_winograd4(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya),
+        fn = l.dinv_conv3x3_winograd4_bf16x3 if bf3 else l.dinv_conv3x3_winograd4   # bf3: three-part bf16 split, six products
+        E.check(fn(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya),
                                          E.p(ra) if mode == "res" else None, 1 if mode == "relu" else 0, E.p(ws),
                                          ctypes.c_size_t(0 if ws is None else ws.numel()), None))
     assert not torch.isnan(ya).any()
@@ -730,3 +732,44 @@ def test_winograd4_rejects_bad_shapes():
     assert l.dinv_conv3x3_winograd4(ctypes.byref(g), E.p(x), E.p(w), 16, 64, E.p(y), None, 0, None, ctypes.c_size_t(0), None) != 0      # height % 4
     g = geom(1, 8, 16)
     assert l.dinv_conv3x3_winograd4(ctypes.byref(g), E.p(x), E.p(w), 24, 64, E.p(y), None, 0, None, ctypes.c_size_t(0), None) != 0      # cin % 16
+
+
+from winograd_ref import winograd4_magnitude  # noqa: E402
+
+
+@pytest.mark.parametrize("case", ["wide", "he_scale"])
+def test_winograd4_bf16x3_worst_case(case):
+    """dinv_conv3x3_winograd4_bf16x3 (three-part bf16 split of BOTH operands, six products) element by element against the fp64
+    convolution, next to the fp32-MFMA form of the same kernel, in units of winograd4_magnitude().  A bf16 part carries 8
+    significand bits, so |xm| <= 2^-8 |x| and |xl| <= 2^-16 |x|: the three products the kernel drops (um vl, ul vm, ul vl) are
+    below 2^-23 |u||v| in the worst case (both operands at half-ulp extremes; ~2^-26 rms), the split itself is exact to 2^-24:
+    bound 2^-22 of the magnitude sum, 64 x 3 times tighter than the two-part split's 3 * 2^-16 (test_wsplit_worst_case), measured
+    2^-23.2 for operands spanning 2^-20 .. 2^8 and 2^-12 .. 2^2 (the fp32 form: 2^-24.5); He-scaled weights on N(0,1) data stay
+    below the fp32 form's 3.2e-6"""
+    from deepinv_amd.hip.drunet import pack_winograd4_weight, pack_winograd4_bf16x3_weight
+    gen = torch.Generator().manual_seed(21)
+    B, H, W, cin, cout = 1, 16, 24, 32, 64
+
+    def wide(shape, lo, hi):
+        e = torch.randint(lo, hi + 1, shape, generator=gen).float()
+        return (1 + torch.rand(shape, generator=gen)) * torch.exp2(e) * (torch.randint(0, 2, shape, generator=gen) * 2 - 1).float()
+
+    if case == "wide":
+        x, w = wide((B, cin, H, W), -20, 8), wide((cout, cin, 3, 3), -12, 2)
+    else:
+        x, w = torch.randn(B, cin, H, W, generator=gen), torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    mag = winograd4_magnitude(x, w)
+    g = geom(B, H, W)
+    xa = to_act(x, g)
+    l = E.lib()
+    worst = {}
+    for name, fn, wp in (("fp32", l.dinv_conv3x3_winograd4, pack_winograd4_weight(w)),
+                         ("bf16x3", l.dinv_conv3x3_winograd4_bf16x3, pack_winograd4_bf16x3_weight(w))):
+        ya = torch.zeros((cout // 8, g.cs, 8))
+        E.check(fn(ctypes.byref(g), E.p(xa), ctypes.c_void_p(wp.data_ptr()), cin, cout, E.p(ya), None, 0, None, ctypes.c_size_t(0), None))
+        out = from_act(ya, g, cout).double()
+        worst[name] = float(((out - ref).abs() / mag).max())
+        assert worst[name] < 2.0 ** -22, (name, worst[name])
+        if case == "he_scale":
+            assert float((out - ref).norm() / ref.norm()) < 3.2e-6
