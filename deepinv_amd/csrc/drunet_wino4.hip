@@ -22,8 +22,8 @@
 //   32 positions is staged global -> registers -> LDS ([channel half][pixel][4]); thread (position, channel, row half)
 //   reads its patch with conflict-free 4-byte LDS reads, transforms it (72 vector instructions: the two row halves
 //   {0,1,2} / {5,3,4} share one instruction stream through per-lane coefficients) and writes its 18 points to the V stage
-//   [lane half][position][point][4 K steps] (pitch 148: conflict-free 16-byte reads), which the MFMA waves read as B
-//   operands.  Double buffered: during block b the workgroup multiplies V[b], transforms raw[b+1] into V[b+1] and stages
+//   [lane half][position][point][4 K steps] (43 16-byte slots per row: conflict-free 16-byte reads AND 4-byte writes, see VP),
+//   which the MFMA waves read as B operands.  Double buffered: during block b the workgroup multiplies V[b], transforms raw[b+1] into V[b+1] and stages
 //   raw[b+2]; ONE LDS-only barrier per block.  Every filler instruction is pinned between two MFMAs (sched_barrier).
 // * Epilogue: each wave reduces its points to s = M A (a full Winograd row and half a row: 8 values), the four waves of
 //   a cout half exchange s through LDS, all 512 threads finish A^T s (two output columns of four channels each), fused

@@ -60,10 +60,14 @@ def test_geometry_queries(lib):
     g = K.geom(32, 320, 320)
     assert (g.hp, g.wp) == (322, 324) and g.plane == 322 * 324 and g.np == 32 * g.plane
     assert g.sl % 4 == 0 and g.cs % 4 == 0 and g.cs >= g.sl + g.np
-    d, ho, wo = hc._desc(2, 3, 17, 19, torch.zeros(1, 1, 5, 4), "valid", 1)
-    assert (ho, wo) == (13, 16)
-    d, ho, wo = hc._desc(2, 3, 32, 24, torch.zeros(1, 1, 16, 16), "circular", 4)
-    assert (ho, wo) == (8, 6)
+    d, out = hc._desc(2, 3, (17, 19), torch.zeros(1, 1, 5, 4), "valid", 1)
+    assert out == (13, 16)
+    d, out = hc._desc(2, 3, (32, 24), torch.zeros(1, 1, 16, 16), "circular", 4)
+    assert out == (8, 6)
+    d, out = hc._desc(1, 2, (9, 17, 19), torch.zeros(1, 1, 3, 5, 4), "valid", 1)            # volumes: dinv_conv3d_out_size
+    assert out == (7, 13, 16)
+    with pytest.raises(ValueError):
+        hc._desc(1, 2, (9, 17, 19), torch.zeros(1, 1, 3, 5, 4), "valid", 2)
     with pytest.raises(ValueError):
         hc.pad_mode("wrap")
 

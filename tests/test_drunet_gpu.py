@@ -188,7 +188,9 @@ def test_winograd4_bf16x3_is_fp32_equivalent(dev, B, H, W, cin, cout, mode):
     ws = torch.zeros(K._l().dinv_conv3x3_winograd4_workspace_bytes(), device=dev, dtype=torch.uint8)
     K.conv3x3_winograd4_bf16x3(geo, xa, w3, cin, cout, y3s, res1=res, relu=mode == "relu", workspace=ws)
     e32, e3, e3s = (rel_err(unpack(a), ref) for a in (y32, y3, y3s))
-    assert e3 < 3.2e-6 and e3s < 3.2e-6, (e3, e3s, e32)
+    # (3.2e-6: the fp32 form's worst level without the ReLU; behind a ReLU the same absolute error meets half the norm - there
+    # the fp32 form's own error on the same data is the bar)
+    assert e3 < max(3.2e-6, e32) and e3s < max(3.2e-6, e32), (e3, e3s, e32)
     assert e3 < 1.15 * e32 + 1e-7, (e3, e32)
     assert int(ws[:8 * 64 * 4].view(torch.int32).abs().max()) == 0
     full = y3[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)     # the zero frame is never written
