@@ -168,7 +168,9 @@ __device__ __forceinline__ uint4 pair(const uint2& X, const uint2& Y) { return m
 // 1.1 / 1.5 / 2.0 / 2.9e-6 at the four DRUNet levels (fp32 form: 1.2 / 1.6 / 2.4 / 3.2e-6); main loop 4500 cycles per block
 // against 5500 (matrix pipe alone: 1750 against 4600) - and the SAME wall time at 32 slices, because the package sits at its
 // 1400 W cap under either form: the clock settles at 1.95 GHz under this one and at 2.32 GHz under the fp32 one
-// (profiles/r05_wino4_power_cap_smi.log).  Faster only where the cap is not reached (4 slices: 12-14 %).  Opt-in.
+// (profiles/r05_wino4_power_cap_smi.log).  Bursts of 20-40 launches run 5-20 % faster in this form at every batch; SUSTAINED (the
+// whole DRUNet for seconds, scripts/r05/bf16x3_e2e.py) it is 1-3 % slower at 4, 8, 16 and 32 slices: energy per convolution, not
+// pipe time, is what the package limit prices.  Opt-in.
 template <int TH, int TW, bool RELU, int NRES, bool SPLIT, bool BF3 = false>
 __global__ __launch_bounds__(NTHR) DINV_W4_ATTR
 void conv3x3_wino4_kernel(W4Args a) {

@@ -23,8 +23,8 @@ _declared = False
 FP32_WINOGRAD_TILE = 4
 WINOGRAD4_MIN_TILES = 64
 # True: the F(4x4,3x3) launches of the fp32 setting evaluate their multiplies as a three-part bf16 split, six products on the bf16
-# matrix cores (dinv_conv3x3_winograd4_bf16x3: same per-layer accuracy, 3/8 of the matrix-pipe time).  Off by default: at the
-# BASELINE batch the package power cap makes both forms equally fast; it pays at small per-GPU batches
+# matrix cores (dinv_conv3x3_winograd4_bf16x3: same per-layer accuracy, 3/8 of the matrix-pipe time).  Off by default: sustained,
+# the package power limit makes the two forms equally fast at every batch (scripts/r05/bf16x3_e2e.py)
 FP32_WINOGRAD4_BF16X3 = False
 
 
