@@ -45,6 +45,10 @@ if rd.get(k) and wr.get(k):
     ncall = calls("r05_pmc_drunet_rd", "TCC_EA0_RDREQ")
     row = {"bytes_per_launch": round(rd[k] / ncall * 128 + wr[k] / max(calls("r05_pmc_drunet_wr", "TCC_EA0_WRREQ"), 1) * 64),
            "launches_averaged": ncall, "commit": commit, "config": {"batch": 32, "height": 320, "width": 320},
+           "read_bytes": round(rd[k] / ncall * 128), "write_bytes_tallied": round(wr[k] / max(calls("r05_pmc_drunet_wr", "TCC_EA0_WRREQ"), 1) * 64),
+           "algorithmic_bytes_per_launch": {"read": 651e6, "write": 434e6,
+                                            "note": "mean over the 56 ResBlock convolutions of one DRUNet(2->2) forward at 32 x 320 x 320; the write "
+                                                    "counter is uncalibrated (MI355X_MICROARCH.md, HBM): requests of 64 and 128 bytes are tallied alike"},
            "sources": CONV_SRC, "sources_sha16": sha(CONV_SRC), "method": METHOD + " on scripts/bench_ops.py drunet_fp32"}
     mf, _ = collect("r05_pmc_drunet_sq", "SQ_VALU_MFMA_BUSY_CYCLES", fam)
     ga, _ = collect("r05_pmc_drunet_sq", "GRBM_GUI_ACTIVE", fam)
@@ -82,7 +86,7 @@ def op_rows(tag, ops, sources, batch):
                 break
             n = names[0]
             total += rd[n] / nrd[n] * 128 + wr.get(n, 0.0) / max(nwr.get(n, 1), 1) * 64
-            used.append(re.sub(r"\(.*$", "", n[0])[:90])
+            used.append(re.sub(r"\(.*$", "", n[0].replace("(anonymous namespace)::", "").replace("void ", ""))[:90])
         if total is not None:
             out["op:" + op] = {"bytes_per_call": round(total), "batch": batch, "commit": commit, "kernels": used, "sources": sources,
                                "sources_sha16": sha(sources), "method": METHOD}
