@@ -16,6 +16,7 @@
 // 3.0x / 4.5x / 23x and ran at 2-3.4 TB/s per pass).
 // Centred transforms: input index i sits at position (i + N/2) mod N, output k at (k + N/2) mod N, on both axes.
 #pragma once
+#include <type_traits>
 #include "fft_launch.hpp"
 
 #ifndef DINV_MRIW_MINW
@@ -186,6 +187,44 @@ __device__ __forceinline__ void col64(float2 (&v)[8][4], float2* buf, float2 w64
     }
 }
 
+// the same transform on HALF a tile (64 rows x 16 columns: 2 adjacent columns per lane) - for the pass that also keeps a coil sum
+// and a prefetched tile in registers
+constexpr int C64H_PITCH = 8 * 16 + 2;
+
+template <bool INV>
+__device__ __forceinline__ void col64_half(float2 (&v)[8][2], float2* buf, float2 w64g, int g, int cq) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float2 a[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a[m] = v[m][e];
+        Bfly<8, INV>::run(a);
+        apply_twiddle_powers<8, INV>(a, w64g);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m][e] = a[m];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2)
+        *reinterpret_cast<float4*>(buf + k2 * C64H_PITCH + g * 16 + cq * 2) = make_float4(v[k2][0].x, v[k2][0].y, v[k2][1].x, v[k2][1].y);
+    wave_lds_sync();
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const float4 r = *reinterpret_cast<const float4*>(buf + g * C64H_PITCH + n1 * 16 + cq * 2);
+        v[n1][0] = make_float2(r.x, r.y);
+        v[n1][1] = make_float2(r.z, r.w);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float2 a[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a[m] = v[m][e];
+        Bfly<8, INV>::run(a);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m][e] = a[m];
+    }
+}
+
 // MODE 0: t -> y * mask (planar)           (last pass of A)
 // MODE 1: y * mask (planar) -> t           (decimation-in-time first pass of A^T: not used by the pipelines below, kept for tests)
 // MODE 2: t -> F, M^2, F^-1 -> t in place  (middle pass of A^T A)
@@ -301,7 +340,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void cols64_kernel(float2* __restrict_
 // One wave per (slice b, residue q, 32 columns) walks the coils: the coil sum stays in the lane that owns the output positions
 // (fixed order n = 0 .. N-1: deterministic), the next coil's tile is requested as soon as the registers of the current one
 // have been consumed.
-template <int R, int WPB>
+template <int R, int WPB, bool MAPS>
 __global__ __launch_bounds__(64 * WPB, 2) void cols64_combine_kernel(const float2* __restrict__ t, const float2* __restrict__ maps,
                                                                      float* __restrict__ x, int ncoil, int maps_batch, int W,
                                                                      int64_t ntiles, const void* table_h, float scale) {
@@ -325,43 +364,61 @@ __global__ __launch_bounds__(64 * WPB, 2) void cols64_combine_kernel(const float
             if (h >= H) h -= H;
             hoff[k1] = (unsigned)h * (unsigned)W + col;
         }
+        // The tile is worked in two halves of 16 columns (lane = 2 + 2 adjacent columns): the coil sum of the whole tile (64
+        // registers), ONE half in flight through the transform (32) and the NEXT half on its way from memory (32) fit the 256
+        // registers of a wave at two per SIMD - the whole-tile form (64 + 64 + 64) spilled 50 of them.
         float2 acc[8][4];
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[k1][e] = make_float2(0.f, 0.f);
-        float4 ra[8], rb[8];
-        auto issue = [&](int n) __attribute__((always_inline)) {
-            const float2* tt = t + ((int64_t)b * ncoil + n) * vol + (int64_t)q * CB * W + col;
+        float4 rn[8], sn[8];        // the next half tile (requested before this half's transform) and the sensitivities of its
+                                    // output positions (requested behind this half's accumulation, which frees the buffer)
+        const unsigned toff = (unsigned)g * (unsigned)W + col;      // (uniform base + 32-bit lane offset: no 64-bit address registers)
+        auto issue = [&](int n, int half) __attribute__((always_inline)) {
+            const float2* tu = t + ((int64_t)b * ncoil + n) * vol + (int64_t)q * CB * W + 2 * half;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const float4* src = reinterpret_cast<const float4*>(tt + (unsigned)(g + 8 * m) * (unsigned)W);
-                ra[m] = src[0];
-                rb[m] = src[1];
+            for (int m = 0; m < 8; ++m)     // (byte offsets: base in SGPRs + a 32-bit lane offset is one addressing mode)
+                rn[m] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tu + (int64_t)m * 8 * W) + toff * 8u);
+        };
+        auto issue_maps = [&](int n, int half) __attribute__((always_inline)) {
+            if (MAPS) {
+                const float2* sp = maps + ((int64_t)(maps_batch > 1 ? b : 0) * ncoil + n) * vol + 2 * half;
+#pragma unroll
+                for (int k1 = 0; k1 < 8; ++k1) sn[k1] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sp) + hoff[k1] * 8u);
             }
         };
-        issue(0);
-        for (int n = 0; n < ncoil; ++n) {
-            const float2* sp = maps ? maps + ((int64_t)(maps_batch > 1 ? b : 0) * ncoil + n) * vol : nullptr;
-            float2 v[8][4];
+        auto half_step = [&](int n, auto half_) __attribute__((always_inline)) {
+            constexpr int HF = decltype(half_)::value;
+            float2 v[8][2];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) unpack_c4(ra[m], rb[m], v[m]);
-            if (n + 1 < ncoil) issue(n + 1);         // the next coil's tile flies during this coil's transform
-            col64<true>(v, buf, w64g, g, cq);
-            if (sp) {
+            for (int m = 0; m < 8; ++m) { v[m][0] = make_float2(rn[m].x, rn[m].y); v[m][1] = make_float2(rn[m].z, rn[m].w); }
+            __builtin_amdgcn_sched_barrier(0);                 // (a load has no reason to wait for its buffer's last reader unless told)
+            // the next half flies during this half's transform (behind the last coil: that coil again, unused - no branch, so
+            // that the buffers stay one set of registers)
+            const int nn = n + 1 < ncoil ? n + 1 : n;
+            if (HF == 0) issue(n, 1);
+            else issue(nn, 0);
+            col64_half<true>(v, buf, w64g, g, cq);
 #pragma unroll
-                for (int k1 = 0; k1 < 8; ++k1) {
-                    float2 sv[4];
-                    ld_c4(sp + hoff[k1], sv);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[k1][e] = cadd(acc[k1][e], cmulc(v[k1][e], sv[e]));       // conj(S) * v
+            for (int k1 = 0; k1 < 8; ++k1) {
+                if (MAPS) {
+                    acc[k1][2 * HF] = cadd(acc[k1][2 * HF], cmulc(v[k1][0], make_float2(sn[k1].x, sn[k1].y)));           // conj(S) * v
+                    acc[k1][2 * HF + 1] = cadd(acc[k1][2 * HF + 1], cmulc(v[k1][1], make_float2(sn[k1].z, sn[k1].w)));
+                } else {
+                    acc[k1][2 * HF] = cadd(acc[k1][2 * HF], v[k1][0]);
+                    acc[k1][2 * HF + 1] = cadd(acc[k1][2 * HF + 1], v[k1][1]);
                 }
-            } else {
-#pragma unroll
-                for (int k1 = 0; k1 < 8; ++k1)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[k1][e] = cadd(acc[k1][e], v[k1][e]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (HF == 0) issue_maps(n, 1);
+            else issue_maps(nn, 0);
+        };
+        issue(0, 0);
+        issue_maps(0, 0);
+        for (int n = 0; n < ncoil; ++n) {
+            half_step(n, std::integral_constant<int, 0>{});
+            half_step(n, std::integral_constant<int, 1>{});
         }
         float* xre = x + (int64_t)b * 2 * vol;
 #pragma unroll
@@ -551,7 +608,8 @@ int launch_cols64_combine(int W, const float2* t, const float2* maps, float* x, 
     const int64_t ntiles = batch * R * (W / CG);
     const unsigned grid = (unsigned)resident_waves_grid(ntiles, WPB);
     const float hs = 1.0f / sqrtf((float)(R * CB));
-    hipLaunchKernelGGL((cols64_combine_kernel<R, WPB>), dim3(grid), dim3(64 * WPB), 0, s, t, maps, x, ncoil, maps_batch, W, ntiles, th, hs);
+    if (maps) hipLaunchKernelGGL((cols64_combine_kernel<R, WPB, true>), dim3(grid), dim3(64 * WPB), 0, s, t, maps, x, ncoil, maps_batch, W, ntiles, th, hs);
+    else hipLaunchKernelGGL((cols64_combine_kernel<R, WPB, false>), dim3(grid), dim3(64 * WPB), 0, s, t, maps, x, ncoil, maps_batch, W, ntiles, th, hs);
     DINV_CHECK_LAUNCH();
     return 0;
 }
