@@ -376,6 +376,9 @@ def unit_gain_parity(dinv, model, denoiser, y, physics, iters):
     keep = {k: v.detach().clone() for k, v in denoiser.state_dict().items()}
     prec = denoiser.conv_precision
     res = {"res_gain": float(d["res_gain"]), "reference": "deepinv v0.4.1 (tests/golden/cfg2_named.npz), slice 0"}
+    # seven more slices of this batch through the reference (tests/golden/cfg2_slices.npz, make_golden_r5.py; gain 0.2 weights)
+    more = os.path.join(ROOT, "tests", "golden", "cfg2_slices.npz")
+    ds = np.load(more) if os.path.exists(more) and y.shape[0] == 32 else None
     try:
         for tag, gain in (("gain_0.2", None), ("unit_gain", float(d["res_gain"]))):
             denoiser.load_state_dict(OD.init_state_dict(2, 2, seed=int(d["drunet_seed"]), res_gain=gain))
@@ -383,8 +386,16 @@ def unit_gain_parity(dinv, model, denoiser, y, physics, iters):
             for p in ("fp32", "bf16split"):
                 denoiser.conv_precision = p
                 with torch.no_grad():
-                    rec = model(y, physics)[:1].detach().cpu().reshape(-1)[::st].double()
+                    full = model(y, physics).detach().cpu()
+                rec = full[:1].reshape(-1)[::st].double()
                 res[f"{tag}_{p}"] = float(f"{float((rec - ref).norm() / ref.norm()):.3e}")
+                if ds is not None and gain is None:
+                    errs = []
+                    for k, i in enumerate(ds["slices"]):
+                        r = torch.from_numpy(np.asarray(ds["rec"][k])).double()
+                        errs.append(float((full[int(i)].reshape(-1)[::int(ds["stride"])].double() - r).norm() / r.norm()))
+                    res[f"{tag}_{p}_slices"] = {"slices": [0] + [int(i) for i in ds["slices"]],
+                                                "max_rel_err": float(f"{max(errs + [res[f'{tag}_{p}']]):.3e}")}
     finally:
         denoiser.load_state_dict(keep)
         denoiser.conv_precision = prec

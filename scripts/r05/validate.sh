@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 R=gpurun_out
 T=${1:-r05}
 mkdir -p $R
-timeout 1500 python -m pytest tests -q -m gpu > $R/${T}_gpu_tests.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed" $R/${T}_gpu_tests.log | tail -2; grep -E "^FAILED|^ERROR" $R/${T}_gpu_tests.log | head
+timeout 1500 python -m pytest tests -q -m gpu -s > $R/${T}_gpu_tests.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed" $R/${T}_gpu_tests.log | tail -2; grep -E "^FAILED|^ERROR" $R/${T}_gpu_tests.log | head
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 python bench.py --steps 5 --warmup 2 > $R/${T}_bench.json 2> $R/${T}_bench.err; echo "bench rc=$?"; tail -3 $R/${T}_bench.err
 python - <<P

@@ -381,3 +381,9 @@ def test_cfg2_multicoil_pnp_pgd_320(dev, gain_tag):
         assert torch.isfinite(rec).all()
         err = rel_err(sub(rec[:1], st), d["rec" + gain_tag])
         assert err < TOL, (prec, gain_tag, err)
+        if gain_tag == "" and os.path.exists(os.path.join(G, "cfg2_slices.npz")):
+            # seven more slices of the batch through the real reference (make_golden_r5.py cfg2_slices): with slice 0 a quarter of
+            # the batch, spread over its whole range
+            ds = load("cfg2_slices")
+            errs = {int(i): rel_err(sub(rec[int(i):int(i) + 1], int(ds["stride"])), ds["rec"][k]) for k, i in enumerate(ds["slices"])}
+            assert len(errs) == 7 and max(errs.values()) < TOL, (prec, errs)
