@@ -109,10 +109,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    power_samples = []
+
     def timed(nwarm, nsteps):
         for _ in range(nwarm):
             step()
         fence()
+        # host thread: rocm-smi twice a second, no GPU work
+        sampler = PowerSampler((device.index if device.index is not None else torch.cuda.current_device()) if rank == 0 else None)
         K.profile_begin()          # HIP events around every conv3x3 launch, on the launch stream
         t0 = time.perf_counter()
         for _ in range(nsteps):
@@ -120,6 +124,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         prof = K.profile_end()
+        power_samples.append(sampler.stop())
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,6 +138,7 @@ def main():
     denoiser.conv_precision = "fp32"
     out, elapsed, conv_prof = timed(args.warmup, args.steps)
     assert torch.isfinite(out).all()
+    package = power_samples[0]
     split_leg = None
     if not args.no_split_leg:
         denoiser.conv_precision = "bf16split"
@@ -271,6 +277,9 @@ def main():
                                   "direct_equiv)",
                          "direct_equiv": round(achieved / 1e12, 2), "frac_direct_equiv": round(achieved / peak, 4),
                          "pmc_stale": stale,
+                         # the package during the timed steps of this leg (rocm-smi from a host thread): DESIGN.md 3.2 - the F(4x4)
+                         # kernel runs at the package power limit, the clock it sustains there is below the 2.4 GHz of `peak`
+                         "package_during_timed_steps": package,
                          "launches": kp["launches"] if kp else 0,
                          "avg_launch_ms": round(kp["ms"] / max(kp["launches"], 1), 4) if kp else 0.0,
                          "share_of_step": round(kp["ms"] * 1e-3 / elapsed, 4) if kp else 0.0,
@@ -294,6 +303,47 @@ def main():
                 res["parity_unit_gain_50it"] = ug
         print(json.dumps(res))
     ctx.__exit__(None, None, None)
+
+
+class PowerSampler:
+    """socket power and shader clock of one GPU, sampled by `rocm-smi` from a host thread while the timed steps run (no GPU work,
+    nothing inside the timed region waits for it); None when rocm-smi is not there"""
+
+    def __init__(self, index, period=0.5):
+        import threading
+        self.samples, self.index, self.period = [], index, period
+        self._stop = threading.Event()
+        self._thread = None
+        if index is not None:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower"], capture_output=True, text=True,
+                                     timeout=5).stdout
+                clk = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", txt)
+                pw = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+                if clk and pw:
+                    self.samples.append((int(clk.group(1)), float(pw.group(1))))
+            except (OSError, subprocess.SubprocessError):
+                return
+            self._stop.wait(self.period)
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=6)
+        if not self.samples:
+            return None
+        clk = sorted(c for c, _ in self.samples)
+        pw = sorted(p for _, p in self.samples)
+        return {"samples": len(self.samples), "sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0],
+                "socket_power_w_median": pw[len(pw) // 2], "socket_power_w_max": pw[-1], "source": "rocm-smi --showclocks --showpower"}
 
 
 def sources_sha16(files):
