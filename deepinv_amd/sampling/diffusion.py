@@ -116,6 +116,8 @@ class DiffPIR(Reconstructor):
                     x0 = x0_p * 2 - 1
                     eps = (x - st["sa_t"] * x0) / st["s1m_t"]
                     x = st["sa_p"] * x0 + st["s1m_p"] * (1 - self.zeta) ** 0.5 * eps + st["s1m_p"] * self.zeta ** 0.5 * nz
+                    if fused:       # (a prox or model that returns another memory format: the fused updates read dense memory)
+                        x = x.contiguous()
             return EW.affine(0.5, x, d=0.5) if fused else x / 2 + 0.5
 
     @property

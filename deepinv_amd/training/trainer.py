@@ -106,8 +106,11 @@ class Trainer:
                 self.optimizer.load_state_dict(ck["optimizer"])
             if ck.get("scheduler") is not None and self.scheduler is not None:     # trainer.py:592-593
                 self.scheduler.load_state_dict(ck["scheduler"])
-            self.train_loss_history = list(ck.get("loss", self.train_loss_history))
-            self.eval_metric_history = list(ck.get("eval_metrics", self.eval_metric_history))
+            # the reference stores its histories as {class name: [value per epoch]} (trainer.py:454-480, 1192-1198); this trainer
+            # keeps the total loss and the first metric: read either form
+            self.train_loss_history = self._history(ck.get("loss"), [l.__class__.__name__ for l in self.losses], self.train_loss_history, total=True)
+            self.eval_metric_history = self._history(ck.get("eval_metrics"), [m.__class__.__name__ for m in self.metrics],
+                                                     self.eval_metric_history)
             self.epoch_start = ck.get("epoch", -1) + 1
         if train and self.optimizer is None:
             raise ValueError("an optimizer is needed for training")
@@ -232,15 +235,32 @@ class Trainer:
         return loss, logs
 
     # ------------------------------------------------------------------ loops (trainer.py:1332-1600)
+    @staticmethod
+    def _history(field, names, default, total=False):
+        """a history field of a checkpoint as a flat list: this trainer's own {name: [..]} form with one entry, the reference's
+        {class name: [..]} (total = the per-epoch sum over the losses, else the first of `names` found), or a plain list"""
+        if field is None:
+            return default
+        if isinstance(field, dict):
+            lists = [list(v) for v in field.values()] if total else ([list(field[n]) for n in names if n in field] or [list(v) for v in field.values()])
+            if not lists:
+                return []
+            if total and len(lists) > 1 and len({len(v) for v in lists}) == 1:
+                return [float(sum(vals)) for vals in zip(*lists)]
+            return [float(v) for v in lists[0]]
+        return [float(v) for v in field]
+
     def save_model(self, filename, epoch):
         if self.save_path is None:
             return
         os.makedirs(self.save_path, exist_ok=True)
-        # the reference's fields (trainer.py:1192-1198): epoch, state_dict, loss history, optimizer, scheduler, eval metrics
-        torch.save({"epoch": epoch, "state_dict": self.model.state_dict(), "loss": list(self.train_loss_history),
+        # the reference's fields and their shapes (trainer.py:1192-1198): epoch, state_dict, optimizer, scheduler, and the histories
+        # as {name: [value per epoch]} - here the total training loss and the first evaluation metric
+        metric = self.metrics[0].__class__.__name__ if self.metrics else "metric"
+        torch.save({"epoch": epoch, "state_dict": self.model.state_dict(), "loss": {"TotalLoss": list(self.train_loss_history)},
                     "optimizer": self.optimizer.state_dict() if self.optimizer else None,
                     "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None,
-                    "eval_metrics": list(self.eval_metric_history)}, os.path.join(self.save_path, filename))
+                    "eval_metrics": {metric: list(self.eval_metric_history)}}, os.path.join(self.save_path, filename))
 
     def _metric_name(self, m):
         return getattr(m, "__name__", m.__class__.__name__).strip("_")

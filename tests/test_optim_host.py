@@ -428,6 +428,19 @@ def test_trainer_loop_host():
                            epochs=2, device="cpu", verbose=False, ckpt_pretrained=os.path.join(tmp, "ckp_1.pth.tar"))
         tr2.setup_train()
         assert abs(float(net2.w) - float(net.w)) < 1e-7 and tr2.epoch_start == 2
+        # the histories travel in the reference's checkpoint shape, {name: [value per epoch]} (trainer.py:1192-1198), and come back
+        # as this trainer's flat lists - also from a checkpoint the reference wrote ({loss class: [..]} per loss, several metrics)
+        ck = torch.load(os.path.join(tmp, "ckp_1.pth.tar"))
+        assert isinstance(ck["loss"], dict) and isinstance(ck["eval_metrics"], dict)
+        assert tr2.train_loss_history == pytest.approx(tr.train_loss_history) and tr2.eval_metric_history == pytest.approx(tr.eval_metric_history)
+        ck["loss"] = {"SupLoss": [1.0, 0.5], "OtherLoss": [0.25, 0.125]}
+        ck["eval_metrics"] = {"PSNR": [20.0, 21.0], "SSIM": [0.5, 0.6]}
+        ck["train_metrics"], ck["eval_loss"] = {"PSNR": [19.0, 20.0]}, {"SupLoss": []}
+        torch.save(ck, os.path.join(tmp, "ref_style.pth.tar"))
+        tr3 = dinv.Trainer(model=Net(), physics=P(), optimizer=torch.optim.SGD(Net().parameters(), lr=0.01), train_dataloader=loader,
+                           epochs=2, device="cpu", verbose=False, ckpt_pretrained=os.path.join(tmp, "ref_style.pth.tar"))
+        tr3.setup_train()
+        assert tr3.train_loss_history == [1.25, 0.625] and tr3.eval_metric_history == [20.0, 21.0]
     with pytest.raises(ValueError, match="tuple"):
         bad = dinv.Trainer(model=net, physics=P(), optimizer=opt, train_dataloader=torch.utils.data.DataLoader(list(x), batch_size=4),
                            epochs=1, device="cpu", verbose=False)
