@@ -123,6 +123,17 @@ __global__ __launch_bounds__(64) void cg_check_kernel(int batch, const float* __
     if (threadIdx.x == 0 && ok) done[0] = 1;
 }
 
+// out[i] = s[i] / (d[i mod period] + add): a complex spectrum over a real symbol that is shared by the leading (batch, channel)
+// dimensions - the pointwise division of the closed-form proxes (blur.py:331-363, forward.py:1212-1234)
+__global__ __launch_bounds__(256) void cdiv_real_kernel(int64_t n, int64_t period, const float2* __restrict__ s,
+                                                        const float* __restrict__ d, float add, float2* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float den = d[i % period] + add;
+        const float2 v = s[i];
+        out[i] = make_float2(v.x / den, v.y / den);
+    }
+}
+
 inline unsigned stream_blocks(int64_t n) { return (unsigned)std::min<int64_t>(std::max<int64_t>(ceil_div(n / 4 + 1, 256), 1), 2048); }
 
 }  // namespace
@@ -147,6 +158,18 @@ extern "C" int dinv_affine(int64_t n, float a, const float* x, float b, const fl
                            float lo, float hi, float* out, dinv_stream_t stream) {
     DINV_REQUIRE(lo <= hi, "empty clamp interval [%g, %g]", (double)lo, (double)hi);
     return affine_launch(n, a, x, b, y, c, z, d, lo, hi, out, stream);
+}
+
+extern "C" int dinv_cdiv_real(int64_t n, int64_t period, const float* s, const float* d, float add, float* out,
+                              dinv_stream_t stream) {
+    DINV_REQUIRE(n >= 0 && period > 0 && s && d && out, "bad arguments");
+    if (n == 0) return 0;
+    DINV_REQUIRE(((uintptr_t)s | (uintptr_t)out) % 8 == 0, "complex tensors must be 8-byte aligned");
+    hipLaunchKernelGGL(cdiv_real_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 2048)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), n, period, reinterpret_cast<const float2*>(s), d, add,
+                       reinterpret_cast<float2*>(out));
+    DINV_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int32_t dinv_batched_dot_blocks(int64_t n) { return (int32_t)std::min<int64_t>(std::max<int64_t>(ceil_div(n / 4 + 1, 1024), 1), 256); }

@@ -25,6 +25,7 @@ def _l():
         l.dinv_cg_update.argtypes = [i32, i32, i64, vp, vp, f32, vp, vp, vp, vp, vp]
         l.dinv_cg_update_masked.argtypes = [i32, i32, i64, vp, vp, f32, vp, vp, vp, vp, vp, vp]
         l.dinv_cg_check.argtypes = [i32, vp, vp, vp, vp]
+        l.dinv_cdiv_real.argtypes = [i64, i64, vp, vp, f32, vp, vp]
         _declared = True
     return l
 
@@ -58,6 +59,18 @@ def affine(a: float, x, b: float = 0.0, y=None, c: float = 0.0, z=None, d: float
         out = torch.empty_like(x)
     check(_l().dinv_affine(x.numel(), float(a), ptr(x), float(b), ptr(y), float(c), ptr(z), float(d), float(lo), float(hi),
                            ptr(out), stream_ptr(x.device)))
+    return out
+
+
+def cdiv_real(s, d, add: float = 0.0):
+    """s / (d + add) for a complex64 tensor s whose trailing dimensions are those of the real fp32 tensor d (d is shared by the
+    leading batch / channel dimensions of s): one launch of dinv_cdiv_real, in place of a broadcast add and a complex division"""
+    if not (s.is_cuda and s.dtype == torch.complex64 and s.is_contiguous() and d.dtype == torch.float32 and d.is_contiguous()
+            and d.numel() > 0 and s.numel() % d.numel() == 0 and tuple(s.shape[s.dim() - d.squeeze().dim():]) == tuple(d.squeeze().shape)):
+        raise ValueError(f"cdiv_real: spectrum {tuple(s.shape)} / {s.dtype} does not end in the symbol's shape {tuple(d.shape)} / {d.dtype}")
+    out = torch.empty_like(s)
+    check(_l().dinv_cdiv_real(s.numel(), d.numel(), ptr(torch.view_as_real(s)), ptr(d), float(add), ptr(torch.view_as_real(out)),
+                              stream_ptr(s.device)))
     return out
 
 

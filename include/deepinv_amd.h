@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 7 = this header (adds dinv_conv3x3_winograd4_last_split and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 7 = this header (adds dinv_conv3x3_winograd4_last_split, dinv_conv3x3_winograd4_bf16x3, dinv_conv2d/3d_filter_grad, dinv_conv3d*, dinv_cdiv_real and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -471,6 +471,11 @@ int dinv_cg_update_masked(int32_t mode, int32_t batch, int64_t n, const float* n
                           float* v0, float* v1, const float* w0, const float* w1, const int32_t* done,
                           dinv_stream_t stream);
 int dinv_cg_check(int32_t batch, const float* res, const float* tol2, int32_t* done, dinv_stream_t stream);
+/* out[i] = s[i] / (d[i mod period] + add) for n interleaved complex values s over a real symbol d of `period` entries shared by the
+ * leading (batch, channel) dimensions: the pointwise division of the closed-form proxes - Downsampling.prox_l2
+ * (deepinv/physics/blur.py:331-363: mean_blocks(|K|^2) + 1/gamma) and DecomposablePhysics.prox_l2 with a real singular-value
+ * mask (deepinv/physics/forward.py:1212-1234: |s|^2 + 1/gamma).  s and out may alias. */
+int dinv_cdiv_real(int64_t n, int64_t period, const float* s, const float* d, float add, float* out, dinv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -73,3 +73,20 @@ def test_cg_fast_path_matches_oracle_cg(dev):
     # pseudo-inverse through the same path
     xd = phys.A_dagger(y.to(dev))
     assert torch.isfinite(xd).all()
+
+
+@pytest.mark.gpu
+def test_cdiv_real_gpu(dev):
+    """dinv_cdiv_real (the division of Downsampling.prox_l2: half spectrum over aliased symbol + 1/gamma) against torch's broadcast
+    complex division, and its argument check"""
+    from deepinv_amd.hip import elementwise as EW
+
+    g = torch.Generator().manual_seed(5)
+    s = torch.randn(16, 3, 64, 33, 2, generator=g).to(dev)
+    d = (torch.rand(1, 1, 64, 33, generator=g) + 0.05).to(dev)
+    sc = torch.view_as_complex(s)
+    out = EW.cdiv_real(sc, d, 1.0 / 7e5)
+    ref = sc / (d + 1.0 / 7e5)
+    assert out.shape == ref.shape and float((out - ref).abs().max() / ref.abs().max()) < 3e-7
+    with pytest.raises(ValueError):
+        EW.cdiv_real(sc, d[..., :32].contiguous())

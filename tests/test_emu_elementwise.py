@@ -79,6 +79,23 @@ def test_lincomb_and_affine_propagate_nan():
     assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.equal(out[~torch.isnan(out)], ref[~torch.isnan(ref)])
 
 
+@pytest.mark.parametrize("shape,dshape", [((2, 3, 8, 5), (1, 1, 8, 5)), ((4, 3, 6, 4), (1, 3, 6, 4)), ((1, 1, 64, 33), (1, 1, 64, 33))])
+def test_cdiv_real_is_the_broadcast_complex_division(shape, dshape):
+    """dinv_cdiv_real: a complex spectrum over (real symbol + 1/gamma), the symbol shared by the leading dimensions - the division of
+    the closed-form proxes (blur.py:331-363), against torch's broadcast arithmetic; in place as well"""
+    l = E.lib()
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(*shape, 2, generator=g)
+    d = torch.rand(*dshape, generator=g) + 0.1
+    out = torch.empty_like(s)
+    E.check(l.dinv_cdiv_real(ctypes.c_int64(s.numel() // 2), ctypes.c_int64(d.numel()), E.p(s), E.p(d), ctypes.c_float(0.25), E.p(out), None))
+    ref = torch.view_as_real(torch.view_as_complex(s) / (d + 0.25))
+    assert torch.allclose(out, ref, rtol=2e-7, atol=0)
+    E.check(l.dinv_cdiv_real(ctypes.c_int64(s.numel() // 2), ctypes.c_int64(d.numel()), E.p(s), E.p(d), ctypes.c_float(0.25), E.p(s), None))
+    assert torch.equal(s, out)
+    assert l.dinv_cdiv_real(ctypes.c_int64(4), ctypes.c_int64(0), E.p(s), E.p(d), ctypes.c_float(0.0), E.p(out), None) != 0
+
+
 @pytest.mark.parametrize("check_every", [1, 4, 1000])
 def test_cg_with_device_side_convergence_matches_reference_cg(check_every, monkeypatch):
     """however rarely the host looks at the flag (every iteration, every 4th, never before max_iter), the iterate is
