@@ -134,6 +134,23 @@ __global__ __launch_bounds__(256) void cdiv_real_kernel(int64_t n, int64_t perio
     }
 }
 
+// real spectra (or real / imaginary planes) against a real singular-value mask m shared by the leading dimensions
+// (DecomposablePhysics, forward.py:1212-1252):  mode 0  out = x / (m m + add)   (prox_l2),
+//                                               mode 1  out = x * (m > 1e-5 ? 1 / m : 0)   (A_dagger)
+__global__ __launch_bounds__(256) void mask_solve_kernel(int mode, int64_t n, int64_t period, const float* __restrict__ x,
+                                                         const float* __restrict__ m, float add, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float mv = m[i % period];
+        // m m, then + add: two roundings, as the reference's tensor expression has them (the product is made opaque so that the
+        // compiler cannot contract it into a fused multiply-add; __fmul_rn is a plain product to it)
+        float sq = mv * mv;
+#ifndef DINV_EMU
+        asm volatile("" : "+v"(sq));
+#endif
+        out[i] = mode == 0 ? x[i] / (sq + add) : x[i] * (mv > 1e-5f ? 1.0f / mv : 0.0f);
+    }
+}
+
 inline unsigned stream_blocks(int64_t n) { return (unsigned)std::min<int64_t>(std::max<int64_t>(ceil_div(n / 4 + 1, 256), 1), 2048); }
 
 }  // namespace
@@ -168,6 +185,16 @@ extern "C" int dinv_cdiv_real(int64_t n, int64_t period, const float* s, const f
     hipLaunchKernelGGL(cdiv_real_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 2048)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), n, period, reinterpret_cast<const float2*>(s), d, add,
                        reinterpret_cast<float2*>(out));
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_mask_solve(int32_t mode, int64_t n, int64_t period, const float* x, const float* m, float add, float* out,
+                               dinv_stream_t stream) {
+    DINV_REQUIRE((mode == 0 || mode == 1) && n >= 0 && period > 0 && x && m && out, "bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_solve_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 2048)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), mode, n, period, x, m, add, out);
     DINV_CHECK_LAUNCH();
     return 0;
 }

@@ -26,6 +26,7 @@ def _l():
         l.dinv_cg_update_masked.argtypes = [i32, i32, i64, vp, vp, f32, vp, vp, vp, vp, vp, vp]
         l.dinv_cg_check.argtypes = [i32, vp, vp, vp, vp]
         l.dinv_cdiv_real.argtypes = [i64, i64, vp, vp, f32, vp, vp]
+        l.dinv_mask_solve.argtypes = [i32, i64, i64, vp, vp, f32, vp, vp]
         _declared = True
     return l
 
@@ -65,12 +66,26 @@ def affine(a: float, x, b: float = 0.0, y=None, c: float = 0.0, z=None, d: float
 def cdiv_real(s, d, add: float = 0.0):
     """s / (d + add) for a complex64 tensor s whose trailing dimensions are those of the real fp32 tensor d (d is shared by the
     leading batch / channel dimensions of s): one launch of dinv_cdiv_real, in place of a broadcast add and a complex division"""
-    if not (s.is_cuda and s.dtype == torch.complex64 and s.is_contiguous() and d.dtype == torch.float32 and d.is_contiguous()
+    if not (s.dtype == torch.complex64 and s.is_contiguous() and d.dtype == torch.float32 and d.is_contiguous()
             and d.numel() > 0 and s.numel() % d.numel() == 0 and tuple(s.shape[s.dim() - d.squeeze().dim():]) == tuple(d.squeeze().shape)):
         raise ValueError(f"cdiv_real: spectrum {tuple(s.shape)} / {s.dtype} does not end in the symbol's shape {tuple(d.shape)} / {d.dtype}")
     out = torch.empty_like(s)
     check(_l().dinv_cdiv_real(s.numel(), d.numel(), ptr(torch.view_as_real(s)), ptr(d), float(add), ptr(torch.view_as_real(out)),
                               stream_ptr(s.device)))
+    return out
+
+
+def mask_solve(x, m, add: float = 0.0, dagger: bool = False):
+    """x / (m*m + add) (dagger = False: DecomposablePhysics.prox_l2) or x * (m > 1e-5 ? 1/m : 0) (dagger = True: A_dagger) for a real
+    mask m whose shape is the trailing part of x's (shared by x's leading dimensions): one launch of dinv_mask_solve"""
+    tail = list(m.shape)
+    while len(tail) > 1 and tail[0] == 1:
+        tail = tail[1:]
+    if not (m.dtype == torch.float32 and m.is_contiguous() and x.dtype == torch.float32 and x.is_contiguous() and len(tail) <= x.dim()
+            and list(x.shape[x.dim() - len(tail):]) == tail):
+        raise ValueError(f"mask_solve: the mask {tuple(m.shape)} is not the trailing part of {tuple(x.shape)}")
+    out = torch.empty_like(x)
+    check(_l().dinv_mask_solve(1 if dagger else 0, x.numel(), m.numel(), ptr(x), ptr(m), float(add), ptr(out), stream_ptr(x.device)))
     return out
 
 

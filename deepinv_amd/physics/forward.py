@@ -278,7 +278,16 @@ class DecomposablePhysics(LinearPhysics):
 
     def prox_l2(self, z, y, gamma, **kwargs):
         r""":math:`V\big(V^\top(A^\top y + z/\gamma) / (|s|^2 + 1/\gamma)\big)` (forward.py:1212-1234)."""
-        b = self.A_adjoint(y) + 1 / gamma * z
+        from ..hip import elementwise as EW
+
+        aty = self.A_adjoint(y)
+        if (not isinstance(gamma, Tensor) and isinstance(self.mask, Tensor) and not self.mask.is_complex()
+                and EW.eligible(aty, z, self.mask) and self.mask.numel() > 1):
+            vb = self.V_adjoint(EW.lincomb(1.0, aty, 1.0 / float(gamma), z))
+            if EW.eligible(vb) and self._mask_is_trailing(vb):      # b and the division on the HIP kernels (real masks: MRI)
+                return self.V(EW.mask_solve(vb, self.mask, 1.0 / float(gamma)))
+            return self.V(vb / (self.mask * self.mask + 1 / gamma))
+        b = aty + 1 / gamma * z
         if isinstance(gamma, Tensor) and gamma.dim() < self.mask.dim():
             gamma = gamma[(...,) + (None,) * (self.mask.dim() - gamma.dim())]
             gamma = gamma.to(device=self.mask.device, dtype=self.mask.real.dtype)
@@ -288,8 +297,21 @@ class DecomposablePhysics(LinearPhysics):
     def A_dagger(self, y, mask=None, **kwargs):
         r""":math:`V(U^\top y \cdot s^{-1}[s>10^{-5}])` (forward.py:1236-1252)."""
         self.update_parameters(mask=mask, **kwargs)
+        from ..hip import elementwise as EW
+
+        uy = self.U_adjoint(y)
+        if (isinstance(self.mask, Tensor) and not self.mask.is_complex() and self.mask.numel() > 1 and EW.eligible(uy, self.mask)
+                and self._mask_is_trailing(uy)):
+            return self.V(EW.mask_solve(uy, self.mask, dagger=True))
         inv = torch.where(self.mask > 1e-5, self.mask.reciprocal(), 0.0)
-        return self.V(self.U_adjoint(y) * inv)
+        return self.V(uy * inv)
+
+    def _mask_is_trailing(self, t):
+        """the mask, up to leading singleton dimensions, is the trailing part of t's shape (shared by t's leading dimensions)"""
+        shp = list(self.mask.shape)
+        while len(shp) > 1 and shp[0] == 1:
+            shp = shp[1:]
+        return len(shp) <= t.dim() and tuple(t.shape[t.dim() - len(shp):]) == tuple(shp)
 
 
 class Denoising(DecomposablePhysics):

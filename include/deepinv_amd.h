@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 7 = this header (adds dinv_conv3x3_winograd4_last_split, dinv_conv3x3_winograd4_bf16x3, dinv_conv2d/3d_filter_grad, dinv_conv3d*, dinv_cdiv_real and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 7 = this header (adds dinv_conv3x3_winograd4_last_split, dinv_conv3x3_winograd4_bf16x3, dinv_conv2d/3d_filter_grad, dinv_conv3d*, dinv_cdiv_real, dinv_mask_solve and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -476,6 +476,13 @@ int dinv_cg_check(int32_t batch, const float* res, const float* tol2, int32_t* d
  * (deepinv/physics/blur.py:331-363: mean_blocks(|K|^2) + 1/gamma) and DecomposablePhysics.prox_l2 with a real singular-value
  * mask (deepinv/physics/forward.py:1212-1234: |s|^2 + 1/gamma).  s and out may alias. */
 int dinv_cdiv_real(int64_t n, int64_t period, const float* s, const float* d, float add, float* out, dinv_stream_t stream);
+/* The pointwise solves of DecomposablePhysics with a REAL singular-value mask m of `period` entries shared by the leading
+ * dimensions of x (deepinv/physics/forward.py:1212-1252):
+ *   mode 0 (prox_l2):  out = x / (m m + add)       (add = 1 / gamma)
+ *   mode 1 (A_dagger): out = x * (m > 1e-5 ? 1 / m : 0)
+ * x and out may alias. */
+int dinv_mask_solve(int32_t mode, int64_t n, int64_t period, const float* x, const float* m, float add, float* out,
+                    dinv_stream_t stream);
 
 #ifdef __cplusplus
 }

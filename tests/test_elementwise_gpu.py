@@ -90,3 +90,22 @@ def test_cdiv_real_gpu(dev):
     assert out.shape == ref.shape and float((out - ref).abs().max() / ref.abs().max()) < 3e-7
     with pytest.raises(ValueError):
         EW.cdiv_real(sc, d[..., :32].contiguous())
+
+
+def test_mask_solve_gpu(dev):
+    """dinv_mask_solve against the reference's tensor expressions of DecomposablePhysics.prox_l2 / A_dagger (forward.py:1223-1252):
+    bit for bit against their CPU evaluation, mask shared by the batch and mask per sample"""
+    from deepinv_amd.hip import elementwise as EW
+
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(4, 2, 64, 48, generator=g).to(dev)
+    for mshape in ((1, 2, 64, 48), (4, 2, 64, 48)):
+        m = ((torch.rand(*mshape, generator=g) > 0.4).float() * (0.5 + torch.rand(*mshape, generator=g))).to(dev)
+        m.view(-1)[7] = 5e-6
+        # (the host twin of this test, tests/test_emu_elementwise.py, is bit-exact against ATen's CPU kernels - the reference's
+        # path; PyTorch-ROCm's device division differs from the correctly rounded one in the last bit)
+        assert torch.allclose(EW.mask_solve(x, m, 1 / 0.37), x / (torch.conj(m) * m + 1 / 0.37), rtol=3e-7, atol=0)
+        assert torch.allclose(EW.mask_solve(x, m, dagger=True), x * torch.where(m > 1e-5, m.reciprocal(), 0.0), rtol=3e-7, atol=0)
+        assert torch.equal(EW.mask_solve(x, m, 1 / 0.37).cpu(), x.cpu() / (m.cpu() * m.cpu() + 1 / 0.37))
+    with pytest.raises(ValueError):
+        EW.mask_solve(x, torch.ones(1, 2, 64, 47, device=dev))

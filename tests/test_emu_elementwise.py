@@ -96,6 +96,23 @@ def test_cdiv_real_is_the_broadcast_complex_division(shape, dshape):
     assert l.dinv_cdiv_real(ctypes.c_int64(4), ctypes.c_int64(0), E.p(s), E.p(d), ctypes.c_float(0.0), E.p(out), None) != 0
 
 
+def test_mask_solve_is_the_decomposable_prox_and_pseudo_inverse():
+    """dinv_mask_solve against the reference's tensor expressions (forward.py:1223-1234: V^T b / (conj(m) m + 1/gamma);
+    forward.py:1247-1252: U^T y * where(m > 1e-5, 1/m, 0)), bit for bit"""
+    l = E.lib()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 2, 8, 6, generator=g)
+    m = (torch.rand(1, 2, 8, 6, generator=g) > 0.4).float() * (0.5 + torch.rand(1, 2, 8, 6, generator=g))
+    m.view(-1)[5] = 5e-6                                   # below the pseudo-inverse's threshold
+    gamma = 0.37
+    out = torch.empty_like(x)
+    E.check(l.dinv_mask_solve(0, ctypes.c_int64(x.numel()), ctypes.c_int64(m.numel()), E.p(x), E.p(m), ctypes.c_float(1 / gamma), E.p(out), None))
+    assert torch.equal(out, x / (torch.conj(m) * m + 1 / gamma))
+    E.check(l.dinv_mask_solve(1, ctypes.c_int64(x.numel()), ctypes.c_int64(m.numel()), E.p(x), E.p(m), ctypes.c_float(0.0), E.p(out), None))
+    assert torch.equal(out, x * torch.where(m > 1e-5, m.reciprocal(), 0.0))
+    assert l.dinv_mask_solve(2, ctypes.c_int64(4), ctypes.c_int64(4), E.p(x), E.p(m), ctypes.c_float(0.0), E.p(out), None) != 0
+
+
 @pytest.mark.parametrize("check_every", [1, 4, 1000])
 def test_cg_with_device_side_convergence_matches_reference_cg(check_every, monkeypatch):
     """however rarely the host looks at the flag (every iteration, every 4th, never before max_iter), the iterate is
