@@ -25,7 +25,15 @@ struct ConvGeom {
     int32_t mode, stride;
     int32_t pt, pl, pb, pr;  // pads (top,left,bottom,right); 0 for valid
     int32_t Ho, Wo;          // output of A
+    uint32_t smagic;         // ceil(2^32 / stride) when every padded coordinate is below 2^16 (q / stride = mulhi(q, smagic)), else 0
 };
+
+// q / stride and q % stride for a padded coordinate q >= 0 (a hardware-less integer division costs ~30 instructions: the transposed
+// strided convolution needs one pair per candidate row / column)
+__device__ __forceinline__ void divmod_stride(const ConvGeom& g, int q, int& quo, int& rem) {
+    quo = g.smagic ? (int)__umulhi((unsigned)q, g.smagic) : q / g.stride;
+    rem = q - quo * g.stride;
+}
 
 // source index of padded coordinate q (relative to the unpadded axis), or -1 for a zero tap
 __device__ __forceinline__ int pad_map(int q, int n, int mode) {
@@ -105,22 +113,23 @@ __global__ __launch_bounds__(256) void conv2d_pad_transpose_kernel(ConvGeom g, c
     const Pre pcol = preimages(cc, g.W, g.pl, g.pr, g.mode);
     float acc = 0.f;
     for (int ir = 0; ir < prow.n; ++ir)
-        for (int pr = prow.lo[ir]; pr <= prow.hi[ir]; ++pr)
-            for (int u = pr % s; u < g.h; u += s) {   // (pr - u) divisible by s
-                const int a = pr - u;
-                if (a < 0) break;
-                const int io = a / s;
+        for (int pr = prow.lo[ir]; pr <= prow.hi[ir]; ++pr) {
+            int io0, u0;
+            divmod_stride(g, pr, io0, u0);
+            // taps u = u0 + t s (pr - u divisible by s), measurement row io = (pr - u) / s = io0 - t: no division inside
+            for (int u = u0, io = io0; u < g.h && io >= 0; u += s, --io) {
                 if (io >= g.Ho) continue;
                 const float* mrow = meas + (int64_t)io * g.Wo;
+                const float* krow = ks + u * g.w;
                 for (int ic = 0; ic < pcol.n; ++ic)
-                    for (int pc = pcol.lo[ic]; pc <= pcol.hi[ic]; ++pc)
-                        for (int v = pc % s; v < g.w; v += s) {
-                            const int bcol = pc - v;
-                            if (bcol < 0) break;
-                            const int jo = bcol / s;
-                            if (jo < g.Wo) acc = fmaf(ks[u * g.w + v], mrow[jo], acc);
-                        }
+                    for (int pc = pcol.lo[ic]; pc <= pcol.hi[ic]; ++pc) {
+                        int jo0, v0;
+                        divmod_stride(g, pc, jo0, v0);
+                        for (int v = v0, jo = jo0; v < g.w && jo >= 0; v += s, --jo)
+                            if (jo < g.Wo) acc = fmaf(krow[v], mrow[jo], acc);
+                    }
             }
+        }
     x[((int64_t)bc * g.H + r) * g.W + cc] = acc;
 }
 
@@ -162,6 +171,8 @@ int make_geom(const dinv_conv_desc* d, ConvGeom* g) {
     g->B = d->batch; g->C = d->channels; g->H = d->height; g->W = d->width;
     g->fb = d->fbatch; g->fc = d->fchannels; g->h = d->fh; g->w = d->fw;
     g->mode = d->mode; g->stride = d->stride;
+    g->smagic = (d->height + d->fh < 65536 && d->width + d->fw < 65536 && d->stride < 65536)
+                    ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)d->stride - 1) / (uint64_t)d->stride) : 0u;
     int fullH, fullW;
     if (d->mode == PAD_VALID) {
         g->pt = g->pl = g->pb = g->pr = 0;
