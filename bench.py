@@ -111,8 +111,30 @@ def main():
     graph_state = {"on": bool(args.loop_graph or world > 1), "error": None}
     model.fixed_point.use_graph = graph_state["on"]
 
+    def reconstruct():
+        """the loop on this rank's slab; a graph-capture failure switches this rank to the eager loop (no collective in here)"""
+        if graph_state["on"] and not graph_state.get("proven"):
+            try:
+                rec = model(y, physics)
+                graph_state["proven"] = True
+                return rec
+            except Exception as e:      # noqa: BLE001 - any capture problem: the eager loop instead of no result
+                graph_state.update(on=False, error=f"{type(e).__name__}: {e}"[:300])
+                model.fixed_point.use_graph = False
+                torch.cuda.synchronize()
+        return model(y, physics)
+
     def step():
-        return ctx.all_gather_batch(model(y, physics), args.batch)     # one RCCL all-gather per step (identity at N = 1)
+        return ctx.all_gather_batch(reconstruct(), args.batch)     # one RCCL all-gather per step (identity at N = 1)
+
+    def agree_on_graph():
+        """every rank must run the same number of collectives: if the capture failed anywhere, all ranks run the eager loop"""
+        if world > 1:
+            ok = torch.tensor([1 if graph_state["on"] else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if graph_state["on"] and int(ok.item()) == 0:
+                graph_state.update(on=False, error=graph_state["error"] or "capture failed on another rank")
+                model.fixed_point.use_graph = False
 
     def fence():
         if world > 1:
@@ -122,17 +144,10 @@ def main():
     power_samples, prof_steps = [], []
 
     def timed(nwarm, nsteps):
-        for i in range(nwarm):
-            if graph_state["on"] and i == 0:
-                try:
-                    step()
-                except Exception as e:      # noqa: BLE001 - any capture problem: run the eager loop instead of no result
-                    graph_state.update(on=False, error=f"{type(e).__name__}: {e}"[:300])
-                    model.fixed_point.use_graph = False
-                    torch.cuda.synchronize()
-                    step()
-            else:
-                step()
+        for i in range(max(nwarm, 1 if graph_state["on"] and not graph_state.get("proven") else 0)):
+            step()
+            if i == 0:
+                agree_on_graph()
         fence()
         # host thread: rocm-smi twice a second, no GPU work
         sampler = PowerSampler((device.index if device.index is not None else torch.cuda.current_device()) if rank == 0 else None)
