@@ -71,6 +71,10 @@ def main():
                     help="skip the companion timing of the bf16-split throughput setting")
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the operator rows of configs 3-5")
+    ap.add_argument("--as-multi", action="store_true",
+                    help="pre-flight of the multi-GPU code path on ONE rank: create the RCCL process group, replay the iteration as a HIP "
+                         "graph, run agree_on_graph / barrier / all-gather / max-over-ranks exactly as an N > 1 run does (world size 1 "
+                         "communicator), print the multi-GPU form of the JSON line (tests/test_loops_gpu.py)")
     ap.add_argument("--loop-graph", action="store_true",
                     help="replay the PGD iteration as a HIP graph also on one GPU (optim/fixed_point.py: use_graph; always on for "
                          "--gpus > 1); the per-launch HIP events of `roofline` then come from one eager step after the timed region")
@@ -84,8 +88,9 @@ def main():
 
     # rank / device / rendez-vous conventions, slab partition and the gather are those of deepinv_amd.distributed
     # (the same code the world-size-2 gloo tests run on CPU tensors, tests/test_distributed_cpu.py)
-    ctx = BatchParallelContext(backend="nccl")   # "nccl" is RCCL on ROCm
+    ctx = BatchParallelContext(backend="nccl", init_always=args.as_multi)   # "nccl" is RCCL on ROCm
     world, rank = ctx.world_size, ctx.rank
+    multi = world > 1 or args.as_multi      # the code path of an N > 1 run (every `multi` below was `world > 1`)
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     ctx.__enter__()
@@ -108,7 +113,7 @@ def main():
     # +0.4 % at 32 slices per GPU, +6 % at 4, where the host-side launch gaps are a visible share of the iteration.  On for the
     # multi-GPU runs (small per-GPU batches) and on request; the one-GPU line keeps the eager loop, whose per-launch HIP events over
     # the timed region are what `roofline` is computed from.  A capture failure falls back to the eager loop and says so.
-    graph_state = {"on": bool(args.loop_graph or world > 1), "error": None}
+    graph_state = {"on": bool(args.loop_graph or multi), "error": None}
     model.fixed_point.use_graph = graph_state["on"]
 
     def reconstruct():
@@ -129,7 +134,7 @@ def main():
 
     def agree_on_graph():
         """every rank must run the same number of collectives: if the capture failed anywhere, all ranks run the eager loop"""
-        if world > 1:
+        if multi:
             ok = torch.tensor([1 if graph_state["on"] else 0], device=device, dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if graph_state["on"] and int(ok.item()) == 0:
@@ -137,7 +142,7 @@ def main():
                 model.fixed_point.use_graph = False
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +174,7 @@ def main():
             prof = K.profile_end()
             prof_steps[-1] = 1
             model.fixed_point.use_graph = True
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -247,7 +252,9 @@ def main():
     op_row("MultiCoilMRI.A_adjoint", "cfg2", B_local, lambda: physics.A_adjoint(y), alg)
     op_row("MultiCoilMRI.A_adjoint_A", "cfg2", B_local, lambda: physics.A_adjoint_A(x_true), 2 * B_local * 2 * H * W * 4
            + args.coils * H * W * 8 + 2 * H * W * 4)
-    if world == 1 and not args.no_other_configs:
+    if not multi:
+        blur_and_single_coil_rows(dinv, device, op_row)
+    if not multi and not args.no_other_configs:
         other_config_ops(dinv, device, op_row, lambda: ops[-1], loop_row, ops.append)
 
     if rank == 0:
@@ -311,8 +318,10 @@ def main():
             "config": {"workload": "configs[1]: 2D MRI 8-coil 320x320, 4x radial mask (80 spokes), PnP-PGD 50 it + "
                                    "DRUNet(2->2, random init), global batch %d" % args.batch,
                        "global_batch": args.batch, "per_gpu_batch": B_local, "iters": args.iters,
-                       "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if world > 1 else "none",
-                       "conv_precision": "fp32", "loop_graph": graph_state["on"], "loop_graph_error": graph_state["error"]},
+                       "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if multi else "none",
+                       "conv_precision": "fp32", "loop_graph": graph_state["on"], "loop_graph_error": graph_state["error"],
+                       **({"as_multi_preflight": True, "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}}
+                          if args.as_multi else {})},
             "roofline": {"bound": "mfma", "kernel": f"{kname} ({kdesc})",
                          "achieved": round(executed / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": round(executed / peak, 4), "traffic": traffic, "mfma_busy": mfma_busy,
@@ -335,9 +344,9 @@ def main():
         }
         if split_leg:
             res.update(split_leg)
-        if world == 1:
+        if not multi:
             res["layer_rel_err_vs_fp64"] = layer_errors(device)
-        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
+        if not args.no_cpu_baseline and not multi:   # CPU baseline: rank 0 at N=1 only
             res["cpu_baseline"] = cpu_baseline(denoiser, maps, mask, H, W, args.coils, args.iters, y_cpu=y.cpu(), x_gpu=out.cpu())
             res["parity_rel_err_50it"] = res["cpu_baseline"].pop("parity_rel_err_max")
             res["parity_slices"] = res["cpu_baseline"].pop("parity_slices")
@@ -512,6 +521,37 @@ def drunet3d_forward_flops(den, vol):
     total += nb * 2 * (2 * 27 * nc[3] * nc[3] * lvl_vox[3])                 # body
     total += 2 * 27 * nc[0] * den.out_channels * lvl_vox[0]                 # tail
     return total
+
+
+def blur_and_single_coil_rows(dinv, device, op_row):
+    """the remaining operators north_star names, at a batch of 32: BlurFFT and Blur (9x9 Gaussian, sigma 2: BASELINE configs[0]'s
+    filter) on [32,3,256,256], single-coil MRI on [32,2,320,320].  Algorithmic bytes: image in + image out (+ the symbol
+    buffers mask [1,3,256,129,2] / angle [1,3,256,129] c64 once per call for BlurFFT; the k-space mask once per call for MRI)."""
+    g = torch.Generator().manual_seed(5)
+    B, img = 32, (3, 256, 256)
+    x = torch.rand(B, *img, generator=g).to(device)
+    k = dinv.physics.functional.gaussian_blur(psf_size=(9, 9), sigma=(2.0, 2.0)).to(device)
+    pf = dinv.physics.BlurFFT(img_size=img, filter=k, device=device)
+    y = pf.A(x)
+    alg = 2 * x.numel() * 4 + pf.mask.numel() * 4 + pf.angle.numel() * 8
+    op_row("BlurFFT.A", "cfg1-shape x32", B, lambda: pf.A(x), alg)
+    op_row("BlurFFT.A_adjoint", "cfg1-shape x32", B, lambda: pf.A_adjoint(y), alg)
+    op_row("BlurFFT.prox_l2", "cfg1-shape x32", B, lambda: pf.prox_l2(x, y, 1.3), 4 * x.numel() * 4 + pf.mask.numel() * 4 + pf.angle.numel() * 8)
+    for pad in ("circular", "valid"):
+        pb = dinv.physics.Blur(filter=k, padding=pad, device=device)
+        yb = pb.A(x)
+        algb = (x.numel() + yb.numel()) * 4
+        op_row(f"Blur({pad}).A", "cfg1-shape x32", B, lambda: pb.A(x), algb, VALU_TFLOP_per_s=2.0 * 81 * yb.numel() / 1e12)
+        op_row(f"Blur({pad}).A_adjoint", "cfg1-shape x32", B, lambda: pb.A_adjoint(yb), algb, VALU_TFLOP_per_s=2.0 * 81 * x.numel() / 1e12)
+    del x, y, pf
+    H = W = 320
+    xm = torch.rand(B, 2, H, W, generator=g).to(device)
+    mask = dinv.utils.radial_mask(H, W, 80).to(device)
+    pm = dinv.physics.MRI(mask=mask, img_size=(2, H, W), device=device)
+    ym = pm.A(xm)
+    algm = 2 * xm.numel() * 4 + 2 * H * W * 4
+    op_row("MRI.A", "single coil 320x320 x32", B, lambda: pm.A(xm), algm)
+    op_row("MRI.A_adjoint", "single coil 320x320 x32", B, lambda: pm.A_adjoint(ym), algm)
 
 
 def other_config_ops(dinv, device, op_row, ops_last, loop_row, loop_rows_append):

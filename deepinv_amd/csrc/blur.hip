@@ -71,6 +71,93 @@ __global__ __launch_bounds__(256) void conv2d_pad_kernel(ConvGeom g, const float
     y[((int64_t)bc * g.Ho + io) * g.Wo + jo] = acc;
 }
 
+// ---- LDS-tiled form for stride 1 (Blur.A with every padding mode; Blur.A_adjoint for valid / circular / constant, whose transpose
+// is again a gather with an index map).  A workgroup owns 64 x 64 outputs of one plane: the (64 + h - 1) x (64 + w4) input patch
+// goes through pad_map ONCE per element into LDS, a thread owns 4 x 4 outputs and walks the patch rows; per row and chunk of four
+// filter columns it reads 8 consecutive patch values (two 16-byte LDS reads) and one 16-byte row of filter taps (the same address
+// in every lane), and the taps of the previous three filter rows slide along in registers - the filter table carries three zero
+// rows above and below and zero columns up to a multiple of 4, so the inner loop has no conditions: 64 multiply-adds per three
+// LDS reads, no integer division, no global access.
+struct TileConv {
+    int32_t C, fb, fc;
+    int32_t Hi, Wi, Ho, Wo;
+    int32_t h, w;
+    int32_t off_r, off_c;   // input coordinate of tap (u, v) for output (r, c): (r + u - off_r, c + v - off_c), then pad_map
+    int32_t mode, flip;     // flip: taps are k[h w - 1 - (u w + v)] (true convolution), else k[u w + v] (its transpose)
+    int32_t pw, pitch;      // patch columns, LDS row pitch (floats)
+};
+
+__global__ __launch_bounds__(256) void conv2d_tiled_kernel(TileConv g, const float* __restrict__ in, const float* __restrict__ k,
+                                                           float* __restrict__ out) {
+    DINV_DYN_LDS(float, smem);
+    const int w4 = (g.w + 3) & ~3, ph = 64 + g.h - 1;
+    float* kt = smem;                                   // [(h + 6)][w4]
+    float* patch = smem + (g.h + 6) * w4;               // [ph][pitch]
+    const int bc = blockIdx.z, b = bc / g.C, c = bc % g.C;
+    const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * g.h * g.w;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (g.h + 6) * w4; i += 256) {
+        const int u = i / w4 - 3, v = i - (u + 3) * w4;
+        float t = 0.f;
+        if (u >= 0 && u < g.h && v < g.w) t = g.flip ? kf[g.h * g.w - 1 - (u * g.w + v)] : kf[u * g.w + v];
+        kt[i] = t;
+    }
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const float* img = in + (int64_t)bc * g.Hi * g.Wi;
+    for (int pr = tid / 64; pr < ph; pr += 4) {
+        const int rr = pad_map(r0 + pr - g.off_r, g.Hi, g.mode);
+        const bool rok = rr >= 0 && rr < g.Hi;
+        for (int pc = tid & 63; pc < g.pw; pc += 64) {
+            const int cc = pad_map(c0 + pc - g.off_c, g.Wi, g.mode);
+            patch[pr * g.pitch + pc] = (rok && cc >= 0 && cc < g.Wi) ? img[(int64_t)rr * g.Wi + cc] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int steps = g.h + 3;
+    for (int cv = 0; cv < w4; cv += 4) {
+        float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1, t3 = t1;
+        const float* prow = patch + (ty * 4) * g.pitch + tx * 4 + cv;
+        const float* krow = kt + 3 * w4 + cv;
+        for (int r = 0; r < steps; ++r) {
+            const float4 a = *reinterpret_cast<const float4*>(prow), bq = *reinterpret_cast<const float4*>(prow + 4);
+            const float4 t0 = *reinterpret_cast<const float4*>(krow);
+            const float sg[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+            const float tp[4][4] = {{t0.x, t0.y, t0.z, t0.w}, {t1.x, t1.y, t1.z, t1.w}, {t2.x, t2.y, t2.z, t2.w}, {t3.x, t3.y, t3.z, t3.w}};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)          // output row i sees patch row r with filter row u = r - i
+#pragma unroll
+                for (int vv = 0; vv < 4; ++vv)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(tp[i][vv], sg[vv + j], acc[i][j]);
+            t3 = t2; t2 = t1; t1 = t0;
+            prow += g.pitch;
+            krow += w4;
+        }
+    }
+    float* o = out + (int64_t)bc * g.Ho * g.Wo;
+    const int oc = c0 + tx * 4;
+    const bool vec = (g.Wo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && (((int64_t)g.Ho * g.Wo) % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int orow = r0 + ty * 4 + i;
+        if (orow >= g.Ho) continue;
+        float* dst = o + (int64_t)orow * g.Wo + oc;
+        if (vec && oc + 3 < g.Wo) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (oc + j < g.Wo) dst[j] = acc[i][j];
+        }
+    }
+}
+
 // pre-images of unpadded index t under pad_map, in padded coordinates [0, n+pt+pb): up to 3 ranges [lo,hi]
 struct Pre { int lo[3], hi[3], n; };
 __device__ __forceinline__ Pre preimages(int t, int n, int p0, int p1, int mode) {
@@ -189,6 +276,32 @@ int make_geom(const dinv_conv_desc* d, ConvGeom* g) {
     g->Wo = (fullW + d->stride - 1) / d->stride;
     DINV_REQUIRE((int64_t)g->B * g->C <= 65535, "too many (batch*channel) planes per call");
     DINV_REQUIRE((size_t)g->h * g->w * sizeof(float) <= 64 * 1024, "filter too large for LDS");
+    return 0;
+}
+
+// the LDS-tiled kernel for a stride-1 geometry; returns 1 when it took the call, 0 when the caller's general kernel must
+inline int launch_tiled(const ConvGeom& g, bool transpose, const float* in, const float* k, float* out, hipStream_t s, int* took) {
+    *took = 0;
+    if (g.stride != 1) return 0;
+    if (transpose && !(g.mode == PAD_VALID || g.mode == PAD_CIRCULAR || g.mode == PAD_CONSTANT)) return 0;
+    TileConv t;
+    t.C = g.C; t.fb = g.fb; t.fc = g.fc; t.h = g.h; t.w = g.w;
+    if (!transpose) {
+        t.Hi = g.H; t.Wi = g.W; t.Ho = g.Ho; t.Wo = g.Wo; t.off_r = g.pt; t.off_c = g.pl; t.mode = g.mode; t.flip = 1;
+    } else {
+        // x[r, c] = sum_{u, v} kf[u, v] y[r + pt - u, c + pl - v]: with u' = h - 1 - u a gather with the UNFLIPPED filter
+        // (zero outside y for valid / constant, periodic for circular)
+        t.Hi = g.Ho; t.Wi = g.Wo; t.Ho = g.H; t.Wo = g.W; t.off_r = g.h - 1 - g.pt; t.off_c = g.w - 1 - g.pl;
+        t.mode = g.mode == PAD_CIRCULAR ? PAD_CIRCULAR : PAD_CONSTANT; t.flip = 0;
+    }
+    const int w4 = (g.w + 3) & ~3;
+    t.pw = 64 + w4;
+    t.pitch = t.pw;
+    const size_t lds = ((size_t)(g.h + 6) * w4 + (size_t)(64 + g.h - 1) * t.pitch) * sizeof(float);
+    if (lds > 64 * 1024) return 0;
+    hipLaunchKernelGGL(conv2d_tiled_kernel, dim3((t.Wo + 63) / 64, (t.Ho + 63) / 64, g.B * g.C), dim3(256), lds, s, t, in, k, out);
+    DINV_CHECK_LAUNCH();
+    *took = 1;
     return 0;
 }
 
@@ -368,7 +481,259 @@ struct HalfRowsStoreRealIo {  // half spectrum [L, W/2+1] -> real [L, W]  (pocke
     __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
 };
 
+
+// ------------------------------------------------------------------ BlurFFT: the spectral symbol and the fused operator
+// DecomposablePhysics of BlurFFT (deepinv/physics/blur.py:639-657, forward.py:1080-1117, 1212-1252): every operator of the class is
+//     out = irfft2( SYMBOL( rfft2(x) ) ),     SYMBOL(v) = post( scale( pre(v) ) )   per frequency bin,
+//   pre   = v * conj(angle)   (U_adjoint, blur.py:650-653)                     - A_adjoint, A_A_adjoint, A_dagger
+//   scale = m (.) v per real / imaginary component (`mask * view_as_real(.)`)  - A, A_adjoint          (mode 1)
+//           (m m) (.) v        (`mask.conj() * mask * .`)                      - A_adjoint_A, A_A_adjoint   (mode 2)
+//           v / (m m + add)    (forward.py:1223-1234)                          - prox_l2, add = 1 / gamma   (mode 3)
+//           v * (m > 1e-5 ? 1 / m : 0)   (forward.py:1247-1252)                - A_dagger                   (mode 4)
+//   post  = v * angle         (U, blur.py:645-648)                             - A, A_A_adjoint
+// `mask` is the reference's buffer [Ps, H, Wh, 2] (two real values per bin), `angle` complex64 [Ps, H, Wh]; spectrum plane p uses
+// symbol plane p % Ps (Ps = C for a filter shared by the batch, B C for per-sample filters).
+struct Symbol {
+    const float2* mask;
+    const float2* angle;
+    int64_t planes, plane_bins;     // Ps, H * Wh
+    int32_t wh;
+    int32_t pre_conj, scale_mode, post;
+    float add;
+    __device__ __forceinline__ float2 apply(float2 v, int64_t p, int k, int q) const {
+        const int64_t i = (p % planes) * plane_bins + (int64_t)k * wh + q;
+        float2 a = make_float2(1.f, 0.f);
+        if (pre_conj | post) a = angle[i];
+        if (pre_conj) v = cmulc(v, a);
+        if (scale_mode) {
+            const float2 m = mask[i];
+            switch (scale_mode) {
+                case 1: v.x *= m.x; v.y *= m.y; break;
+                case 2: v.x *= m.x * m.x; v.y *= m.y * m.y; break;
+                case 3: {
+                    float sx = m.x * m.x, sy = m.y * m.y;     // m m, then + add: two roundings, as the reference's tensor expression
+#ifndef DINV_EMU
+                    asm volatile("" : "+v"(sx), "+v"(sy));
+#endif
+                    v.x = v.x / (sx + add); v.y = v.y / (sy + add);
+                    break;
+                }
+                default:
+                    v.x *= m.x > 1e-5f ? 1.0f / m.x : 0.0f;
+                    v.y *= m.y > 1e-5f ? 1.0f / m.y : 0.0f;
+            }
+        }
+        if (post) v = cmul(v, a);
+        return v;
+    }
+};
+
+// in-place symbol multiply of a contiguous half spectrum [P, H, Wh] (general sizes; U / U_adjoint alone)
+__global__ __launch_bounds__(256) void spectrum_symbol_kernel(Symbol sym, const float2* __restrict__ in, float2* __restrict__ out,
+                                                              int64_t n, int64_t pitch) {
+    const int64_t per_plane = sym.plane_bins / sym.wh * pitch;      // H * pitch
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / per_plane, r = i - p * per_plane;
+        const int k = (int)(r / pitch), q = (int)(r - (int64_t)k * pitch);
+        if (q < sym.wh) out[i] = sym.apply(in[i], p, k, q);
+    }
+}
+
+// rows passes on the PITCHED intermediate t [P, H, pitch] (pitch = Wh rounded up to 16 complex: every 16-column strip of the
+// column pass is one aligned 128-byte segment per row; the pad columns are never read as data)
+template <bool V4>
+struct RealRowsPitchedIo {   // real [L, W] -> t rows
+    const float* x;
+    float2* out;
+    int32_t wh, pitch;
+    int64_t n_, q_;
+    struct RowCtx { int64_t i, o; };
+    struct ColCtx {};
+    __device__ __forceinline__ RowCtx row_ctx(int64_t line) const { return RowCtx{line * n_, line * pitch}; }
+    __device__ __forceinline__ float2 load(const RowCtx& c, int n) const { return make_float2(x[c.i + n], 0.f); }
+    __device__ __forceinline__ void store(const RowCtx& c, int k, float2 v) const { if (k < wh) out[c.o + k] = v; }
+    static constexpr bool has_vec4 = V4;
+    __device__ __forceinline__ void load4(const RowCtx& c, int n0, float2 (&v)[4]) const {
+        const float4 a = ld_f4(x + c.i + n0);
+        v[0] = make_float2(a.x, 0.f); v[1] = make_float2(a.y, 0.f); v[2] = make_float2(a.z, 0.f); v[3] = make_float2(a.w, 0.f);
+    }
+    __device__ __forceinline__ void store4(const RowCtx& c, int k0, const float2 (&v)[4]) const {
+        if (k0 < wh) st_c4(out + c.o + k0, v);      // a group that straddles Wh spills into the pad columns (pitch >= Wh + 3)
+    }
+    __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
+};
+
+template <bool V4>
+struct HalfRowsPitchedIo {  // t rows -> real [L, W]  (pocketfft c2r conventions: imaginary parts of DC / Nyquist ignored)
+    const float2* in;
+    float* out;
+    int32_t wh, pitch;
+    int64_t n_, q_;
+    struct RowCtx { int64_t i, o; };
+    struct ColCtx {};
+    __device__ __forceinline__ RowCtx row_ctx(int64_t line) const { return RowCtx{line * pitch, line * n_}; }
+    __device__ __forceinline__ float2 load(const RowCtx& c, int n) const {
+        const int N = (int)n_;
+        float2 v;
+        if (n < wh) {
+            v = in[c.i + n];
+            if (n == 0 || (2 * n == N)) v.y = 0.f;
+        } else {
+            v = in[c.i + (N - n)];
+            v.y = -v.y;
+        }
+        return v;
+    }
+    __device__ __forceinline__ void store(const RowCtx& c, int k, float2 v) const { out[c.o + k] = v.x; }
+    static constexpr bool has_vec4 = V4;
+    __device__ __forceinline__ void load4(const RowCtx& c, int n0, float2 (&v)[4]) const {
+        if (n0 > 0 && n0 + 3 < wh && 2 * (n0 + 3) < (int)n_) {
+            ld_c4(in + c.i + n0, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = load(c, n0 + e);
+        }
+    }
+    __device__ __forceinline__ void store4(const RowCtx& c, int k0, const float2 (&v)[4]) const {
+        st_f4(out + c.o + k0, make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
+    }
+    __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
+};
+
+struct PitchedColsIo {      // column pass over the first Q columns of t [P, N, pitch]
+    const float2* in;
+    float2* out;
+    int64_t pitch;
+    int64_t n_, q_;
+    struct RowCtx {};
+    struct ColCtx { int64_t base; };
+    __device__ __forceinline__ ColCtx col_ctx(int64_t p, int64_t q) const { return ColCtx{p * n_ * pitch + q}; }
+    __device__ __forceinline__ float2 load(const ColCtx& c, int k) const { return in[c.base + (int64_t)k * pitch]; }
+    __device__ __forceinline__ void store(const ColCtx& c, int k, float2 v) const { out[c.base + (int64_t)k * pitch] = v; }
+    __host__ void set_geometry(int64_t n, int64_t q) { n_ = n; q_ = q; }
+};
+
+// The middle pass of the fused operator: t <- F_H^-1( SYMBOL( F_H t ) ) on strips of L columns - the forward column transform
+// leaves its outputs, symbol applied, in a second LDS tile in natural order; the inverse transform reads them from there.  The
+// spectrum crosses HBM once in each direction instead of three times (forward columns, symbol, inverse columns).
+template <class P, int L>
+__global__ __launch_bounds__(256) void blurfft_cols_kernel(float2* __restrict__ t, int64_t pitch, int64_t Q, int64_t qtiles,
+                                                           int64_t ntiles, const void* table, Symbol sym) {
+    using TF = TileFft<P, false, false, L>;
+    using TI = TileFft<P, true, false, L>;
+    constexpr int N = P::N;
+    __shared__ __attribute__((aligned(16))) float2 buf[TF::lds_floats2];
+    __shared__ __attribute__((aligned(16))) float2 ksp[(size_t)L * N];
+    const float2* tw = reinterpret_cast<const float2*>(table);
+    const int tid = threadIdx.x;
+    const int line = tid % L;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p = tile / qtiles;
+        const int64_t q0 = (tile - p * qtiles) * L;
+        const int cols = (int)min((int64_t)L, Q - q0);
+        const int q = (int)q0 + (line < cols ? line : 0);
+        float2* col = t + p * (int64_t)N * pitch + q;
+        __syncthreads();   // the previous tile's inverse transform has left `buf` and `ksp`
+        TF::run(buf, tw, cols, 0, 1.0f, tid,
+                [&](int, int, int, int n) { return col[(int64_t)n * pitch]; },
+                [&](int, int ln, int k, int, float2 v) { ksp[k * L + ln] = sym.apply(v, p, k, q); });
+        __syncthreads();
+        TI::run(buf, tw, cols, 0, 1.0f, tid,
+                [&](int, int, int ln, int n) { return ksp[n * L + ln]; },
+                [&](int, int, int k, int, float2 v) { col[(int64_t)k * pitch] = v; });
+    }
+}
+
+template <int N> struct BlurColsL { static constexpr int value = N >= 512 ? 8 : 16; };
+
+template <int N>
+int launch_blurfft_cols(float2* t, int64_t pitch, int64_t P_, int64_t Q, const void* table, const Symbol& sym, hipStream_t s) {
+    using P = typename PlanFor<N>::P;
+    constexpr int L = BlurColsL<N>::value;
+    const int64_t qtiles = ceil_div(Q, L), ntiles = P_ * qtiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 4 * kMaxGrid);
+    hipLaunchKernelGGL((blurfft_cols_kernel<P, L>), dim3(grid), dim3(256), 0, s, t, pitch, Q, qtiles, ntiles, table, sym);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+int make_symbol(Symbol* sym, const float* mask, const float* angle, int64_t symbol_planes, int H, int Wh, int32_t flags, float add) {
+    const int scale_mode = (flags >> 4) & 7;
+    DINV_REQUIRE(symbol_planes >= 1, "symbol_planes must be >= 1");
+    DINV_REQUIRE(scale_mode <= 4, "unknown scale mode %d", scale_mode);
+    DINV_REQUIRE(scale_mode == 0 || mask, "this symbol needs the singular values (mask)");
+    DINV_REQUIRE(!(flags & 3) || angle, "this symbol needs the phases (angle)");
+    *sym = Symbol{reinterpret_cast<const float2*>(mask), reinterpret_cast<const float2*>(angle), symbol_planes, (int64_t)H * Wh, Wh,
+                  (flags & 1) ? 1 : 0, scale_mode, (flags & 2) ? 1 : 0, add};
+    return 0;
+}
+
 }  // namespace
+
+extern "C" size_t dinv_blurfft_workspace_bytes(int64_t P, int32_t H, int32_t W) {
+    const int64_t pitch = ceil_div(W / 2 + 1, 16) * 16;
+    return (size_t)(P * H * pitch) * sizeof(float2);
+}
+
+extern "C" int dinv_spectrum_symbol(const float* spec_in, float* spec_out, int64_t P, int32_t H, int32_t Wh, const float* mask,
+                                    const float* angle, int64_t symbol_planes, int32_t flags, float add, dinv_stream_t stream) {
+    DINV_REQUIRE(spec_in && spec_out && P >= 0 && H >= 1 && Wh >= 1, "bad arguments");
+    Symbol sym;
+    if (int e = make_symbol(&sym, mask, angle, symbol_planes, H, Wh, flags, add)) return e;
+    const int64_t n = P * H * (int64_t)Wh;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(spectrum_symbol_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), sym, reinterpret_cast<const float2*>(spec_in),
+                       reinterpret_cast<float2*>(spec_out), n, (int64_t)Wh);
+    DINV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dinv_blurfft_apply(const float* x, float* out, int64_t P, const dinv_fft_plan* plan_h, const void* table_h,
+                                  const dinv_fft_plan* plan_w, const void* table_w, const float* mask, const float* angle,
+                                  int64_t symbol_planes, int32_t flags, float add, float scale, void* ws, size_t ws_bytes,
+                                  dinv_stream_t stream) {
+    DINV_REQUIRE(x && out && plan_h && plan_w && table_h && table_w && ws, "null pointer");
+    if (P == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int H = plan_h->n, W = plan_w->n, Wh = W / 2 + 1;
+    const int64_t pitch = ceil_div(Wh, 16) * 16;
+    DINV_REQUIRE(ws_bytes >= dinv_blurfft_workspace_bytes(P, H, W), "workspace too small");
+    DINV_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)ws) % 16 == 0, "tensors must be 16-byte aligned");
+    Symbol sym;
+    if (int e = make_symbol(&sym, mask, angle, symbol_planes, H, Wh, flags, add)) return e;
+    float2* t = reinterpret_cast<float2*>(ws);
+    // scale of the transform pair (ortho: 1 / (H W)) applied once, in the first pass
+    if (W % 4 == 0) {
+        RealRowsPitchedIo<true> rio{x, t, Wh, (int32_t)pitch, 0, 0};
+        if (int e = launch_rows(rio, P * H, *plan_w, table_w, 0, 0, scale, s)) return e;
+    } else {       // 4-element groups need W % 4 == 0: scalar accesses otherwise
+        RealRowsPitchedIo<false> rio{x, t, Wh, (int32_t)pitch, 0, 0};
+        if (int e = launch_rows(rio, P * H, *plan_w, table_w, 0, 0, scale, s)) return e;
+    }
+    bool fused = false;
+    switch (H) {
+#define DINV_CASE(NN) case NN: fused = true; if (int e = launch_blurfft_cols<NN>(t, pitch, P, Wh, table_h, sym, s)) return e; break;
+        DINV_CASE(64) DINV_CASE(128) DINV_CASE(256) DINV_CASE(320) DINV_CASE(512)
+#undef DINV_CASE
+        default: break;
+    }
+    if (!fused) {      // other heights: forward columns, symbol, inverse columns as three passes of the generic engine
+        PitchedColsIo cio{t, t, pitch, 0, 0};
+        if (int e = launch_cols(cio, P, Wh, *plan_h, table_h, 0, 0, 1.0f, s)) return e;
+        const int64_t n = P * H * pitch;
+        hipLaunchKernelGGL(spectrum_symbol_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, s, sym, t,
+                           t, n, pitch);
+        DINV_CHECK_LAUNCH();
+        if (int e = launch_cols(cio, P, Wh, *plan_h, table_h, 1, 0, 1.0f, s)) return e;
+    }
+    if (W % 4 == 0) {
+        HalfRowsPitchedIo<true> oio{t, out, Wh, (int32_t)pitch, 0, 0};
+        return launch_rows(oio, P * H, *plan_w, table_w, 1, 0, 1.0f, s);
+    }
+    HalfRowsPitchedIo<false> oio{t, out, Wh, (int32_t)pitch, 0, 0};
+    return launch_rows(oio, P * H, *plan_w, table_w, 1, 0, 1.0f, s);
+}
 
 extern "C" int dinv_conv2d_out_size(const dinv_conv_desc* d, int32_t* ho, int32_t* wo) {
     ConvGeom g;
@@ -382,6 +747,9 @@ extern "C" int dinv_conv2d(const dinv_conv_desc* d, const float* x, const float*
     if (int e = make_geom(d, &g)) return e;
     if (g.B == 0) return 0;
     DINV_REQUIRE(x && filter && y, "null pointer");
+    int took = 0;
+    if (int e = launch_tiled(g, false, x, filter, y, reinterpret_cast<hipStream_t>(stream), &took)) return e;
+    if (took) return 0;
     hipLaunchKernelGGL(conv2d_pad_kernel, dim3((g.Wo + 63) / 64, (g.Ho + 3) / 4, g.B * g.C), dim3(256),
                        g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, x, filter, y);
     DINV_CHECK_LAUNCH();
@@ -394,6 +762,9 @@ extern "C" int dinv_conv2d_transpose(const dinv_conv_desc* d, const float* y, co
     if (int e = make_geom(d, &g)) return e;
     if (g.B == 0) return 0;
     DINV_REQUIRE(x && filter && y, "null pointer");
+    int took = 0;
+    if (int e = launch_tiled(g, true, y, filter, x, reinterpret_cast<hipStream_t>(stream), &took)) return e;
+    if (took) return 0;
     hipLaunchKernelGGL(conv2d_pad_transpose_kernel, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.B * g.C), dim3(256),
                        g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y, filter, x);
     DINV_CHECK_LAUNCH();

@@ -40,6 +40,10 @@ def _l():
             getattr(l, name).argtypes = [D3, vp, vp, vp, vp]
         l.dinv_rfft2.argtypes = [vp, vp, i64, P, vp, P, vp, f32, vp]
         l.dinv_irfft2.argtypes = [vp, vp, i64, P, vp, P, vp, f32, vp, sz, vp]
+        l.dinv_blurfft_workspace_bytes.restype = sz
+        l.dinv_blurfft_workspace_bytes.argtypes = [i64, i32, i32]
+        l.dinv_blurfft_apply.argtypes = [vp, vp, i64, P, vp, P, vp, vp, vp, i64, i32, f32, f32, vp, sz, vp]
+        l.dinv_spectrum_symbol.argtypes = [vp, vp, i64, i32, i32, vp, vp, i64, i32, f32, vp]
         _declared = True
     return l
 
@@ -290,3 +294,80 @@ def rfft2(x, norm="backward"):
 
 def irfft2(xc, s, norm="backward"):
     return _Irfft2.apply(xc, tuple(s), norm)
+
+
+# --------------------------------------------------------------------------- BlurFFT: symbol of the spectrum, fused operator
+SYM_PRE_CONJ_ANGLE, SYM_POST_ANGLE = 1, 2
+SYM_NONE, SYM_MASK, SYM_MASK2, SYM_PROX, SYM_DAGGER = (m << 4 for m in range(5))
+
+
+def _symbol_planes(x_planes_shape, mask, angle, H, Wh):
+    """number of symbol planes Ps (spectrum plane p uses symbol plane p % Ps), or None when the buffers do not have the shape the
+    kernels index: mask [1|B, C, H, Wh, 2] fp32 and angle [1|B, C, H, Wh] complex64 of one common leading shape, contiguous"""
+    lead = None
+    for t, tail, dt in ((mask, (H, Wh, 2), torch.float32), (angle, (H, Wh), torch.complex64)):
+        if t is None:
+            continue
+        if not (isinstance(t, torch.Tensor) and t.dtype == dt and t.is_contiguous() and tuple(t.shape[t.dim() - len(tail):]) == tail):
+            return None
+        l = tuple(t.shape[: t.dim() - len(tail)])
+        while len(l) > 1 and l[0] == 1:
+            l = l[1:]
+        if lead is not None and l != lead:
+            return None
+        lead = l
+    lead = tuple(lead or ())
+    xs = tuple(x_planes_shape)
+    if lead and lead != (1,) and xs[len(xs) - len(lead):] != lead:
+        return None
+    return max(int(math.prod(lead)), 1)
+
+
+def blurfft_supported(x, mask, angle):
+    """the fused BlurFFT operator takes this image / symbol pair (plain fp32 device tensors outside autograd recording)"""
+    from . import elementwise as EW
+
+    if not (EW.eligible(x) and x.dim() >= 2 and x.shape[-1] >= 2):
+        return False
+    H, W = x.shape[-2:]
+    for t in (mask, angle):
+        if t is not None and ((torch.is_grad_enabled() and t.requires_grad) or t.device != x.device):
+            return False
+    return _symbol_planes(x.shape[:-2], mask, angle, H, W // 2 + 1) is not None
+
+
+def blurfft_apply(x, mask, angle, flags: int, add: float = 0.0, norm: str = "ortho"):
+    """irfft2(SYMBOL(rfft2(x))) in one call of dinv_blurfft_apply (csrc/blur.hip): flags = SYM_* scale mode | SYM_PRE_CONJ_ANGLE |
+    SYM_POST_ANGLE; `mask` / `angle` are BlurFFT's buffers (blur.py:677-686)"""
+    dev = require_hip(x)
+    H, W = x.shape[-2:]
+    Ps = _symbol_planes(x.shape[:-2], mask, angle, H, W // 2 + 1)
+    if Ps is None:
+        raise ValueError(f"blurfft_apply: symbol buffers {None if mask is None else tuple(mask.shape)} / "
+                         f"{None if angle is None else tuple(angle.shape)} do not fit an image of shape {tuple(x.shape)}")
+    P = x.numel() // (H * W) if x.numel() else 0
+    out = torch.empty_like(x)
+    nb = int(_l().dinv_blurfft_workspace_bytes(P, H, W))
+    ws = torch.empty(max(nb, 16), device=dev, dtype=torch.uint8)
+    ph, th = fft_plan(H, dev)
+    pw, tw = fft_plan(W, dev)
+    scale = _scale(norm, H * W, False) * _scale(norm, H * W, True)
+    check(_l().dinv_blurfft_apply(ptr(x), ptr(out), P, ctypes.byref(ph), ptr(th), ctypes.byref(pw), ptr(tw), ptr(mask),
+                                  ptr(None if angle is None else torch.view_as_real(angle)), Ps, int(flags), float(add), scale,
+                                  ptr(ws), ws.numel(), stream_ptr(dev)))
+    return out
+
+
+def spectrum_symbol(spec, mask, angle, flags: int, add: float = 0.0):
+    """SYMBOL(spec) for a contiguous complex64 half spectrum [..., H, Wh] (the multiplications of BlurFFT.U / U_adjoint)"""
+    dev = require_hip(spec)
+    H, Wh = spec.shape[-2:]
+    Ps = _symbol_planes(spec.shape[:-2], mask, angle, H, Wh)
+    if Ps is None or spec.dtype != torch.complex64 or not spec.is_contiguous():
+        raise ValueError(f"spectrum_symbol: symbol buffers do not fit a spectrum of shape {tuple(spec.shape)} / {spec.dtype}")
+    out = torch.empty_like(spec)
+    P = spec.numel() // (H * Wh) if spec.numel() else 0
+    check(_l().dinv_spectrum_symbol(ptr(torch.view_as_real(spec)), ptr(torch.view_as_real(out)), P, H, Wh, ptr(mask),
+                                    ptr(None if angle is None else torch.view_as_real(angle)), Ps, int(flags), float(add),
+                                    stream_ptr(dev)))
+    return out

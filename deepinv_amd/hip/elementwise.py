@@ -64,10 +64,15 @@ def affine(a: float, x, b: float = 0.0, y=None, c: float = 0.0, z=None, d: float
 
 
 def cdiv_real(s, d, add: float = 0.0):
-    """s / (d + add) for a complex64 tensor s whose trailing dimensions are those of the real fp32 tensor d (d is shared by the
-    leading batch / channel dimensions of s): one launch of dinv_cdiv_real, in place of a broadcast add and a complex division"""
+    """s / (d + add) for a complex64 tensor s whose trailing dimensions are those of the real fp32 tensor d up to d's LEADING singleton
+    dimensions (d is shared by the leading batch / channel dimensions of s): one launch of dinv_cdiv_real, in place of a broadcast
+    add and a complex division.  Only leading singletons are stripped (like mask_solve): a symbol [B, 1, h, w] against a spectrum
+    [B, C, h, w] is NOT a trailing part and is rejected - the caller expands it."""
+    tail = list(d.shape)
+    while len(tail) > 1 and tail[0] == 1:
+        tail = tail[1:]
     if not (s.dtype == torch.complex64 and s.is_contiguous() and d.dtype == torch.float32 and d.is_contiguous()
-            and d.numel() > 0 and s.numel() % d.numel() == 0 and tuple(s.shape[s.dim() - d.squeeze().dim():]) == tuple(d.squeeze().shape)):
+            and d.numel() > 0 and len(tail) <= s.dim() and list(s.shape[s.dim() - len(tail):]) == tail):
         raise ValueError(f"cdiv_real: spectrum {tuple(s.shape)} / {s.dtype} does not end in the symbol's shape {tuple(d.shape)} / {d.dtype}")
     out = torch.empty_like(s)
     check(_l().dinv_cdiv_real(s.numel(), d.numel(), ptr(torch.view_as_real(s)), ptr(d), float(add), ptr(torch.view_as_real(out)),

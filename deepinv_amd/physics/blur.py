@@ -59,20 +59,72 @@ class BlurFFT(DecomposablePhysics):
         self.register_buffer("mask", p["mask"])
         self.to(device)
 
+    # ---- the operators of DecomposablePhysics (forward.py:1080-1117, 1212-1252) as ONE library call each: rfft2 rows, the column
+    # transform pair with the symbol applied in LDS between them, irfft2 rows (hip/conv.py: blurfft_apply).  Tensors that record a
+    # gradient, non-fp32 inputs and symbol buffers of another layout take the composed U / V / mask expressions of the base class.
+    def _fused(self, x, flags, add=0.0):
+        if isinstance(self.mask, Tensor) and isinstance(self.angle, Tensor) and tuple(x.shape[-2:]) == tuple(self.img_size[-2:]) \
+                and hc.blurfft_supported(x, self.mask, self.angle):
+            return hc.blurfft_apply(x, self.mask, self.angle, flags, add, norm="ortho")
+        return None
+
     def A(self, x, filter=None, **kwargs):
-        return super().A(x, filter=filter)
+        self.update_parameters(filter=filter)
+        out = self._fused(x, hc.SYM_MASK | hc.SYM_POST_ANGLE)
+        return out if out is not None else DecomposablePhysics.A(self, x)
 
     def A_adjoint(self, x, filter=None, **kwargs):
-        return super().A_adjoint(x, filter=filter)
+        self.update_parameters(filter=filter)
+        out = self._fused(x, hc.SYM_PRE_CONJ_ANGLE | hc.SYM_MASK)
+        return out if out is not None else DecomposablePhysics.A_adjoint(self, x)
+
+    def A_adjoint_A(self, x, filter=None, **kwargs):
+        self.update_parameters(filter=filter)
+        out = self._fused(x, hc.SYM_MASK2)
+        return out if out is not None else DecomposablePhysics.A_adjoint_A(self, x)
+
+    def A_A_adjoint(self, y, filter=None, **kwargs):
+        self.update_parameters(filter=filter)
+        out = self._fused(y, hc.SYM_PRE_CONJ_ANGLE | hc.SYM_MASK2 | hc.SYM_POST_ANGLE)
+        return out if out is not None else DecomposablePhysics.A_A_adjoint(self, y)
+
+    def prox_l2(self, z, y, gamma, **kwargs):
+        from ..hip import elementwise as EW
+
+        if not isinstance(gamma, Tensor) and EW.eligible(z, y):
+            aty = self._fused(y, hc.SYM_PRE_CONJ_ANGLE | hc.SYM_MASK)
+            if aty is not None:     # b = A^T y + z / gamma, then V(V^T b / (m m + 1 / gamma))
+                return self._fused(EW.lincomb(1.0, aty, 1.0 / float(gamma), z), hc.SYM_PROX, 1.0 / float(gamma))
+        return DecomposablePhysics.prox_l2(self, z, y, gamma, **kwargs)
+
+    def A_dagger(self, y, filter=None, **kwargs):
+        self.update_parameters(filter=filter)
+        out = self._fused(y, hc.SYM_PRE_CONJ_ANGLE | hc.SYM_DAGGER)
+        return out if out is not None else DecomposablePhysics.A_dagger(self, y)
+
+    def _symbol_ok(self, spec):
+        from ..hip import elementwise as EW
+
+        return (isinstance(self.angle, Tensor) and spec.dtype == torch.complex64 and EW.eligible(torch.view_as_real(spec))
+                and not (torch.is_grad_enabled() and self.angle.requires_grad)
+                and hc._symbol_planes(spec.shape[:-2], None, self.angle, *spec.shape[-2:]) is not None)
 
     def V_adjoint(self, x):
         return torch.view_as_real(hc.rfft2(x, norm="ortho"))
 
     def U(self, x):
-        return hc.irfft2(torch.view_as_complex(x.contiguous()) * self.angle, self.img_size[-2:], norm="ortho")
+        spec = torch.view_as_complex(x.contiguous())
+        if self._symbol_ok(spec):
+            spec = hc.spectrum_symbol(spec, None, self.angle, hc.SYM_POST_ANGLE)
+        else:
+            spec = spec * self.angle
+        return hc.irfft2(spec, self.img_size[-2:], norm="ortho")
 
     def U_adjoint(self, x):
-        return torch.view_as_real(hc.rfft2(x, norm="ortho") * torch.conj(self.angle))
+        spec = hc.rfft2(x, norm="ortho")
+        if self._symbol_ok(spec):
+            return torch.view_as_real(hc.spectrum_symbol(spec, None, self.angle, hc.SYM_PRE_CONJ_ANGLE))
+        return torch.view_as_real(spec * torch.conj(self.angle))
 
     def V(self, x):
         return hc.irfft2(torch.view_as_complex(x.contiguous()), self.img_size[-2:], norm="ortho")
@@ -265,9 +317,15 @@ class Downsampling(LinearPhysics):
         if EW.eligible(z, y, Az) and not isinstance(gamma, Tensor) and y.shape[-1] % 2 == 0:
             # all on the HIP kernels: the residual, a REAL-input transform pair of the low-resolution grid (half the spectrum:
             # the aliased symbol of a real filter is even), the division by the symbol, the update
-            if getattr(self, "_alias_half_key", None) != key:
-                self._alias_half = self._alias_mean[..., : y.shape[-1] // 2 + 1].contiguous()
-                self._alias_half_key = key
+            hkey = key + (tuple(y.shape[:2]),)
+            if getattr(self, "_alias_half_key", None) != hkey:
+                half = self._alias_mean[..., : y.shape[-1] // 2 + 1]
+                # the kernel indexes the symbol as the TRAILING part of the spectrum [B, C, h, w/2+1]: a per-sample symbol
+                # [B, 1, h, .] (filters from a physics generator) is expanded over the channels first (low-resolution grid: small)
+                if half.dim() == 4 and half.shape[0] > 1 and half.shape[1] != y.shape[1]:
+                    half = half.expand(half.shape[0], y.shape[1], *half.shape[2:])
+                self._alias_half = half.contiguous()
+                self._alias_half_key = hkey
             r = EW.lincomb(1.0, y, -1.0, Az)
             S = EW.cdiv_real(hc.rfft2(r, norm="backward"), self._alias_half, 1.0 / float(gamma))
             s = hc.irfft2(S, y.shape[-2:], norm="backward")

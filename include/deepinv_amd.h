@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 7 = this header (adds dinv_conv3x3_winograd4_last_split, dinv_conv3x3_winograd4_bf16x3, dinv_conv2d/3d_filter_grad, dinv_conv3d*, dinv_cdiv_real, dinv_mask_solve and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 8 = this header (adds dinv_blurfft_apply, dinv_blurfft_workspace_bytes, dinv_spectrum_symbol); 7: (adds dinv_conv3x3_winograd4_last_split, dinv_conv3x3_winograd4_bf16x3, dinv_conv2d/3d_filter_grad, dinv_conv3d*, dinv_cdiv_real, dinv_mask_solve and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -441,6 +441,33 @@ int dinv_rfft2(const float* x, float* out, int64_t P, const dinv_fft_plan* plan_
 int dinv_irfft2(const float* in, float* out, int64_t P, const dinv_fft_plan* plan_h, const void* table_h,
                 const dinv_fft_plan* plan_w, const void* table_w, float scale, void* ws, size_t ws_bytes,
                 dinv_stream_t stream);
+
+/* BlurFFT as ONE call: out = irfft2( SYMBOL( rfft2(x) ) ) over the last two dims of a real [P,H,W] tensor - every operator of
+ * deepinv's BlurFFT / DecomposablePhysics (deepinv/physics/blur.py:639-657 V_adjoint / U / U_adjoint / V;
+ * deepinv/physics/forward.py:1080-1117 A / A_adjoint / A_adjoint_A / A_A_adjoint; :1212-1252 prox_l2 / A_dagger) with no
+ * arithmetic between the transforms left to the caller.  SYMBOL(v) = post(scale(pre(v))) per frequency bin:
+ *   flags bit 0 (DINV_SYM_PRE_CONJ_ANGLE)  v <- v * conj(angle)                 (U_adjoint)
+ *   flags bits 4-6 scale mode: 0 none; 1  v <- m (.) v  (per real / imaginary component, `mask * view_as_real(v)`);
+ *                              2  v <- (m m) (.) v;  3  v <- v / (m m + add)  (prox_l2: add = 1 / gamma);
+ *                              4  v <- v * (m > 1e-5 ? 1 / m : 0)  (A_dagger)
+ *   flags bit 1 (DINV_SYM_POST_ANGLE)      v <- v * angle                       (U)
+ * mask: the reference's `mask` buffer [Ps,H,W/2+1,2] (float pairs), angle: its `angle` buffer [Ps,H,W/2+1] complex64 (either may
+ * be null when the flags do not use it); spectrum plane p uses symbol plane p % Ps.  `scale` multiplies the result (ortho pair:
+ * 1 / (H W)).  For H in {64,128,256,320,512} the forward column transform, the symbol and the inverse column transform are ONE
+ * pass over an LDS tile (the half spectrum crosses HBM once each way); other heights run them as three passes.  `ws`: caller
+ * scratch of dinv_blurfft_workspace_bytes(P,H,W) bytes. */
+#define DINV_SYM_PRE_CONJ_ANGLE 1
+#define DINV_SYM_POST_ANGLE 2
+#define DINV_SYM_SCALE(mode) ((mode) << 4)
+size_t dinv_blurfft_workspace_bytes(int64_t P, int32_t H, int32_t W);
+int dinv_blurfft_apply(const float* x, float* out, int64_t P, const dinv_fft_plan* plan_h, const void* table_h,
+                       const dinv_fft_plan* plan_w, const void* table_w, const float* mask, const float* angle,
+                       int64_t symbol_planes, int32_t flags, float add, float scale, void* ws, size_t ws_bytes,
+                       dinv_stream_t stream);
+/* the symbol alone on a contiguous half spectrum [P,H,Wh] (interleaved complex; in place when spec_out == spec_in): the
+ * multiplications of BlurFFT.U / U_adjoint and of the three-call form rfft2 -> symbol -> irfft2 */
+int dinv_spectrum_symbol(const float* spec_in, float* spec_out, int64_t P, int32_t H, int32_t Wh, const float* mask,
+                         const float* angle, int64_t symbol_planes, int32_t flags, float add, dinv_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Loop algebra of the iteration drivers                                       */

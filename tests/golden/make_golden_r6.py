@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Round-6 golden vectors from the REAL reference (deepinv v0.4.1 at /root/reference through oracle/ref_shim.py).
+
+* `cfg3_full_b.npz`  a SECOND full-length draw of BASELINE configs[2] (VERDICT r5 "next" #5a): another 512x512 image (seed 60) and
+                     another DRUNet(1->1) initialisation (seed 62) through FBP + 30-iteration `deepinv.optim.HQS` with the reference's
+                     default CG prox - same contents as cfg3_full.npz (make_golden_r5.py), so the 1e-4 end point is not a single draw.
+* `cfg3_pair.npz`    TWO DISTINCT images in one batch at a reduced size (256x256, 360 angles) through the same loop: the reference
+                     stops its CG on `torch.all(residual < tol)` over the BATCH (deepinv/optim/linear/conjugate_gradient.py:61), so a
+                     non-degenerate batch is the case where one unit's residual decides for the other.
+* `mask_generators.npz`  sampling statistics of the reference's Cartesian mask generators (deepinv/physics/generator/mri.py:134-384):
+                     per-column inclusion counts over 4096 masks of `RandomMaskGenerator` and `GaussianMaskGenerator` (W = 320 and
+                     W = 128, acceleration 4 and 8), the offset histogram of `EquispacedMaskGenerator` with the column sets of every
+                     offset, `PolyOrderMaskGenerator`'s pdf (the binary-searched Bernoulli probabilities) and its inclusion counts.
+
+    python tests/golden/make_golden_r6.py [masks] [cfg3_pair] [cfg3_b]      # masks: ~1 min, cfg3_pair: ~15 min, cfg3_b: ~1.5 h
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.ref_shim import import_reference  # noqa: E402
+from oracle import drunet_cpu as OD  # noqa: E402
+
+dinv = import_reference()
+OUT = os.path.dirname(os.path.abspath(__file__))
+STRIDE = 7
+STRIDE_TRACE = 1009
+
+
+def sub(t, stride=STRIDE):
+    return t.detach().reshape(-1)[::stride].clone()
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()}, flush=True)
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def hqs_schedule(n=30):
+    s = np.logspace(np.log10(49 / 255.0), np.log10(0.02), n).astype("float32")
+    st = ((s / 0.02) ** 2 / 0.23).astype("float32")
+    return s, st
+
+
+def hqs_run(name, W, nang, xs, drunet_seed, iters=30, per_unit=False):
+    """FBP + `iters`-iteration deepinv.optim.HQS over the batch `xs`; per-prox A^T A counts, per-iteration denoiser traces"""
+    t0 = time.time()
+    p = dinv.physics.Tomography(angles=nang, img_width=W, circle=False, normalize=True, device="cpu")
+    print(name, "init", time.time() - t0, "max_iter", p.max_iter, "tol", p.tol, flush=True)
+    y = p.A(xs)
+    den = dinv.models.DRUNet(in_channels=1, out_channels=1, pretrained=None)
+    den.load_state_dict(OD.init_state_dict(1, 1, seed=drunet_seed))
+    den.eval()
+    outs = []
+
+    class Trace(torch.nn.Module):
+        def forward(self, x, sigma, *a, **k):
+            o = den(x, sigma, *a, **k)
+            outs.append(torch.stack([sub(u, STRIDE_TRACE) for u in o]) if per_unit else sub(o, STRIDE_TRACE))
+            print("  denoiser call", len(outs), time.strftime("%H:%M:%S"), flush=True)
+            return o
+
+    sigs, steps = hqs_schedule(iters)
+    n_ata, cnt = [], [0]
+    ata, prox = p.A_adjoint_A, p.prox_l2
+
+    def counting_ata(v, **kw):
+        cnt[0] += 1
+        return ata(v, **kw)
+
+    def counting_prox(*a, **kw):
+        cnt[0] = 0
+        o = prox(*a, **kw)
+        n_ata.append(cnt[0])
+        print("  prox: A_adjoint_A applications", cnt[0], time.strftime("%H:%M:%S"), flush=True)
+        return o
+
+    p.A_adjoint_A, p.prox_l2 = counting_ata, counting_prox
+    model = dinv.optim.HQS(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(Trace()), stepsize=list(map(float, steps)),
+                           g_param=list(map(float, sigs)), max_iter=iters, early_stop=False,
+                           custom_init=lambda yy, pp: pp.A_dagger(yy, fbp=True))
+    t0 = time.time()
+    with torch.no_grad():
+        rec = model(y, p)
+    print(name, "loop", time.time() - t0, flush=True)
+    save(name, operator_norm=p.operator_norm, rec=torch.stack([sub(r) for r in rec]) if per_unit else sub(rec),
+         den_outs=torch.stack(outs), n_ata=np.int32(n_ata), steps=steps, sigs=sigs, stride=STRIDE, stride_trace=STRIDE_TRACE,
+         drunet_seed=drunet_seed, iters=iters, cg_max_iter=p.max_iter, cg_tol=p.tol, width=W, angles=nang)
+
+
+def cfg3_b():
+    hqs_run("cfg3_full_b", 512, 720, torch.rand(1, 1, 512, 512, generator=g(60)), 62)
+
+
+def cfg3_pair():
+    W = 256
+    xs = torch.cat((torch.rand(1, 1, W, W, generator=g(64)), 0.5 * torch.rand(1, 1, W, W, generator=g(65)) ** 2))
+    hqs_run("cfg3_pair", W, 360, xs, 66, per_unit=True)
+
+
+def masks():
+    from deepinv.physics.generator import (EquispacedMaskGenerator, GaussianMaskGenerator, RandomMaskGenerator)
+    from deepinv.physics.generator.mri import PolyOrderMaskGenerator
+    NM = 4096
+    out = {"n_masks": NM}
+    for W, acc in ((320, 4), (128, 8)):
+        for nm, cls in (("random", RandomMaskGenerator), ("gaussian", GaussianMaskGenerator)):
+            gen = cls((2, 8, W), acceleration=acc, rng=g(90))
+            m = gen.step(batch_size=NM)["mask"]                 # [NM, 2, 8, W]
+            assert bool((m[:, :1, :1] == m).all())              # every channel / row carries the same columns
+            cols = m[:, 0, 0]                                   # [NM, W]
+            out[f"{nm}_{W}_{acc}_counts"] = cols.sum(0).to(torch.int32)
+            out[f"{nm}_{W}_{acc}_lines"] = np.int32([gen.n_lines, gen.n_center])
+            assert bool((cols.sum(1) == gen.n_lines + gen.n_center).all())
+        gen = EquispacedMaskGenerator((2, 8, W), acceleration=acc, rng=g(91))
+        cols = gen.step(batch_size=NM)["mask"][:, 0, 0]
+        pats, inv = torch.unique(cols, dim=0, return_inverse=True)
+        out[f"equispaced_{W}_{acc}_patterns"] = pats.to(torch.uint8)
+        out[f"equispaced_{W}_{acc}_pattern_counts"] = torch.bincount(inv, minlength=pats.shape[0]).to(torch.int32)
+        for order in (4, 8):
+            gen = PolyOrderMaskGenerator((2, 8, W), acceleration=acc, poly_order=order, rng=g(92))
+            cols = gen.step(batch_size=NM)["mask"][:, 0, 0]
+            out[f"poly{order}_{W}_{acc}_pdf"] = gen.pdf.float()
+            out[f"poly{order}_{W}_{acc}_counts"] = cols.sum(0).to(torch.int32)
+    # k-t sampling: the time steps of a sample are drawn independently (random / gaussian), sheared (equispaced)
+    gen = EquispacedMaskGenerator((2, 4, 8, 64), acceleration=4, rng=g(93))
+    m = gen.step(batch_size=64)["mask"]                         # [64, 2, 4, 8, 64]
+    out["equispaced_kt_cols"] = m[:, 0, :, 0].to(torch.uint8)     # [64, 4, 64]
+    save("mask_generators", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count() or 8)))
+    for name in sys.argv[1:] or ["masks", "cfg3_pair", "cfg3_b"]:
+        {"masks": masks, "cfg3_pair": cfg3_pair, "cfg3_b": cfg3_b}[name]()
+    print("done")

@@ -133,3 +133,118 @@ def test_conv3d_transpose_and_filter_grad_emulated(mode, shape):
     dk = torch.full((B, C, fd, fh, fw), float("nan"))
     E.check(l.dinv_conv3d_filter_grad(ctypes.byref(d), E.p(x), E.p(v), E.p(dk), None))
     assert float((dk.double() - kp.grad).norm() / kp.grad.norm()) < 2e-6
+
+
+def _symbol_ref(X, m, a, flags, add):
+    """SYMBOL of include/deepinv_amd.h (dinv_blurfft_apply) in fp64 with the reference's expressions (blur.py:639-657,
+    forward.py:1080-1117, 1212-1252): X complex [P,H,Wh], m real pairs [Ps,H,Wh,2], a complex [Ps,H,Wh]"""
+    P, Ps = X.shape[0], m.shape[0]
+    m = m.double().repeat(P // Ps, 1, 1, 1)
+    a = a.to(torch.complex128).repeat(P // Ps, 1, 1)
+    v = X.to(torch.complex128)
+    if flags & 1:
+        v = v * torch.conj(a)
+    v = torch.view_as_real(v)
+    mode = (flags >> 4) & 7
+    if mode == 1:
+        v = m * v
+    elif mode == 2:
+        v = m * m * v
+    elif mode == 3:
+        v = v / (m * m + add)
+    elif mode == 4:
+        v = v * torch.where(m > 1e-5, 1 / m, torch.zeros_like(m))
+    v = torch.view_as_complex(v.contiguous())
+    if flags & 2:
+        v = v * a
+    return v
+
+
+BLURFFT_FLAGS = [0x10 | 2, 1 | 0x10, 0x20, 1 | 0x20 | 2, 0x30, 1 | 0x40, 0]
+
+
+@pytest.mark.parametrize("H,W,Ps", [(64, 32, 3), (64, 64, 1), (16, 24, 3), (12, 10, 6), (128, 20, 2)])
+def test_blurfft_apply_emulated(H, W, Ps):
+    """dinv_blurfft_apply (csrc/blur.hip): out = irfft2(SYMBOL(rfft2 x)) for every operator of BlurFFT / DecomposablePhysics, against
+    an fp64 evaluation of the reference's expressions - the fused LDS column pass (H = 64, 128), the three-pass form of other
+    heights, widths that are / are not multiples of 4, symbols shared by the batch (Ps = C) and per sample (Ps = B C); and
+    dinv_spectrum_symbol alone"""
+    P, Wh = 6, W // 2 + 1
+    gen = torch.Generator().manual_seed(H * W + Ps)
+    x = torch.randn(P, H, W, generator=gen)
+    m = torch.rand(Ps, H, Wh, 2, generator=gen) + 0.05
+    m[:, 0, 0] = 1e-7                                   # a singular value below the pseudo-inverse's threshold
+    ph_ = torch.rand(Ps, H, Wh, generator=gen) * 6.28
+    a = torch.polar(torch.ones_like(ph_), ph_).contiguous()
+    l = E.lib()
+    l.dinv_blurfft_workspace_bytes.restype = ctypes.c_size_t
+    ph, th = E.fft_plan(H)
+    pw, tw = E.fft_plan(W)
+    nb = l.dinv_blurfft_workspace_bytes(ctypes.c_int64(P), ctypes.c_int32(H), ctypes.c_int32(W))
+    X = torch.fft.rfft2(x.double(), norm="ortho")
+    for flags in BLURFFT_FLAGS:
+        add = 1.0 / 1.3
+        ws = torch.zeros(nb // 4 + 4)
+        out = torch.full((P, H, W), float("nan"))
+        E.check(l.dinv_blurfft_apply(E.p(x), E.p(out), ctypes.c_int64(P), ctypes.byref(ph), E.p(th), ctypes.byref(pw), E.p(tw), E.p(m),
+                                     E.p(torch.view_as_real(a)), ctypes.c_int64(Ps), ctypes.c_int32(flags), ctypes.c_float(add),
+                                     ctypes.c_float(1.0 / (H * W)), E.p(ws), ctypes.c_size_t(ws.numel() * 4), None))
+        S = _symbol_ref(X, m, a, flags, add)
+        ref = torch.fft.irfft2(S, s=(H, W), norm="ortho")
+        err = float((out.double() - ref).norm() / ref.norm())
+        assert err < 3e-6, (flags, err)
+        spec = X.to(torch.complex64).contiguous()
+        so = torch.full((P, H, Wh, 2), float("nan"))
+        E.check(l.dinv_spectrum_symbol(E.p(torch.view_as_real(spec)), E.p(so), ctypes.c_int64(P), ctypes.c_int32(H), ctypes.c_int32(Wh),
+                                       E.p(m), E.p(torch.view_as_real(a)), ctypes.c_int64(Ps), ctypes.c_int32(flags),
+                                       ctypes.c_float(add), None))
+        assert float((torch.view_as_complex(so).to(torch.complex128) - S).norm() / S.norm()) < 1e-6, flags
+    # a symbol that needs buffers it was not given is an error, not a crash
+    assert l.dinv_blurfft_apply(E.p(x), E.p(out), ctypes.c_int64(P), ctypes.byref(ph), E.p(th), ctypes.byref(pw), E.p(tw), None, None,
+                                ctypes.c_int64(Ps), ctypes.c_int32(0x10), ctypes.c_float(0), ctypes.c_float(1), E.p(ws),
+                                ctypes.c_size_t(ws.numel() * 4), None) != 0
+
+
+def test_blurfft_class_on_the_fused_operator_emulated():
+    """the product's BlurFFT class over the emulated kernels: A / A_adjoint / A_adjoint_A / A_A_adjoint / prox_l2 / A_dagger take the
+    fused call and equal the oracle's restatement of the reference (oracle/physics_cpu.py); U / U_adjoint multiply through
+    dinv_spectrum_symbol"""
+    import deepinv_amd as dinv
+    from emu_backend import emu_backend
+    from oracle import physics_cpu as O
+
+    img = (3, 64, 32)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, *img, generator=g)
+    k = torch.rand(1, 1, 5, 5, generator=g)
+    k = k / k.sum()
+    mask, angle = O.blurfft_params(img, k)
+    with emu_backend():
+        from deepinv_amd.hip import conv as hc
+        calls = []
+        orig = hc.blurfft_apply
+        hc.blurfft_apply = lambda *a, **kw: (calls.append(a[3]), orig(*a, **kw))[1]
+        try:
+            p = dinv.physics.BlurFFT(img_size=img, filter=k, device="cpu")
+            y = p.A(x)
+            yr = O.blurfft_A(x, mask, angle, img)
+            assert float((y - yr).norm() / yr.norm()) < 1e-5
+            assert float((p.A_adjoint(y) - O.blurfft_AT(yr, mask, angle, img)).norm() / yr.norm()) < 1e-5
+            z = torch.rand(2, *img, generator=g)
+            pr = O.blurfft_prox_l2(z, yr, 1.3, mask, angle, img)
+            assert float((p.prox_l2(z, y, 1.3) - pr).norm() / pr.norm()) < 1e-5
+            ata = O.blurfft_AT(O.blurfft_A(x, mask, angle, img), mask, angle, img)
+            assert float((p.A_adjoint_A(x) - ata).norm() / ata.norm()) < 1e-5
+            aat = O.blurfft_A(O.blurfft_AT(yr, mask, angle, img), mask, angle, img)
+            assert float((p.A_A_adjoint(y) - aat).norm() / aat.norm()) < 1e-5
+            dag = p.A_dagger(y)
+            assert float((p.A(dag) - y).norm() / y.norm()) < 1e-3          # A A^+ y = y on the range
+            assert len(calls) >= 8 and {0x12, 0x11, 0x20, 0x23, 0x30, 0x41} <= set(calls), calls
+            u = p.U(p.V_adjoint(x))
+            ur = torch.fft.irfft2(torch.fft.rfft2(x, norm="ortho") * angle, s=img[-2:], norm="ortho")
+            assert float((u - ur).norm() / ur.norm()) < 1e-5
+            ua = torch.view_as_complex(p.U_adjoint(x).contiguous())
+            uar = torch.fft.rfft2(x, norm="ortho") * torch.conj(angle)
+            assert float((ua - uar).norm() / uar.norm()) < 1e-5
+        finally:
+            hc.blurfft_apply = orig

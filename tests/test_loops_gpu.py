@@ -413,3 +413,36 @@ def test_multi_gpu_batch_parallel_over_rccl(dev):
         assert np.linalg.norm(rec - ref) / np.linalg.norm(ref) < 1e-5
         covered[start:stop] += 1
     assert (covered == 1).all()                      # the slabs tile the batch exactly once
+
+
+def test_bench_multi_gpu_code_path_preflight_on_one_rank():
+    """Everything `bench.py --gpus N` (N > 1) does that one GPU allows, launched the way the driver launches it
+    (`python -m torch.distributed.run --nproc-per-node 1 ...`): RCCL process group from the torchrun environment, the PGD iteration
+    replayed as a HIP graph, agree_on_graph's all-reduce, the barrier + all-gather + max-over-ranks all-reduce of the timed region,
+    the eager profiling step after it, and ONE JSON line from rank 0 - so that the first real 8-rank run cannot die on plumbing
+    (reference conventions: deepinv/distributed/distrib_framework.py:73-173)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--as-multi", "--batch", "4", "--iters", "6", "--steps", "2", "--warmup", "1", "--no-split-leg"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints exactly one JSON line
+    res = json.loads(lines[0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 1 and res["steps"] == 2 and res["value"] > 0
+    assert cfg["as_multi_preflight"] and cfg["process_group"] == {"backend": "nccl", "world_size": 1}
+    assert cfg["loop_graph"] is True and cfg["loop_graph_error"] is None, cfg
+    assert cfg["collective"] == "all_gather(reconstruction)"
+    assert "eager step after the timed region" in res["roofline"]["events_from"]
+    assert res["roofline"]["launches"] > 0 and "cpu_baseline" not in res
