@@ -6,6 +6,8 @@
 //       per (batch, time) row: n_lines columns drawn WITHOUT replacement with probabilities pdf (zero on the centre
 //       band), the centre band always sampled, every image row gets the same columns
 //   EquispacedMaskGenerator         mri.py:304-384   columns round(arange((t + offset_b) % a, W - 1, a)), random offset_b
+//   PolyOrderMaskGenerator          mri.py:199-281   every column an independent Bernoulli draw with probability pdf[w]
+//       (the polynomial variable density shifted by bisection to the target rate; centre band probability 1)
 //
 // The reference draws from torch's generators with a Python loop per sample; here one launch serves the whole batch.
 // Random numbers come from Philox4x32-10 (counter based: element i of a call uses counter (offset + i / 4), key = seed),
@@ -77,7 +79,7 @@ struct MaskArgs {
     int32_t rows;        // batch * T
     int32_t T, C, H, W;
     int32_t n_lines, c_lo, c_hi;   // columns [c_lo, c_hi) = always-sampled centre band
-    int32_t mode;        // 0: random lines with probabilities pdf ; 1: equispaced with random offset
+    int32_t mode;        // 0: random lines with probabilities pdf ; 1: equispaced with random offset ; 2: Bernoulli(pdf[w]) per column
     double accel;        // equispaced: adjusted acceleration (mri.py:357-359)
     int32_t n_offsets;   // equispaced: offset_b uniform in [0, n_offsets)
     uint64_t seed, offset;
@@ -107,6 +109,14 @@ __global__ __launch_bounds__(256) void mask_lines_kernel(MaskArgs a, const float
                 for (int v = 0; v < a.W; ++v) rank += (key[v] > kw || (key[v] == kw && v < w)) ? 1 : 0;
                 if (rank < a.n_lines) line[w] = 1;
             }
+        }
+    } else if (a.mode == 2) {
+        // torch.bernoulli(pdf) (mri.py:273-281): column w is sampled iff u < pdf[w], u uniform; here u in (0, 1] and the test is
+        // u <= p, so p = 1 (the centre band) always fires and p = 0 never does
+        for (int w = tid; w < a.W; w += 256) {
+            Philox ph(a.seed, a.offset + (uint64_t)row * ((MAXW + 3) / 4) + (uint64_t)(w >> 2), 3u);
+            ph.run();
+            line[w] = u01(ph.c[w & 3]) <= pdf[w] ? 1 : 0;
         }
     } else {
         __syncthreads();
@@ -152,9 +162,9 @@ extern "C" int dinv_mri_mask_lines(int32_t batch, int32_t channels, int32_t time
                                    float* mask, dinv_stream_t stream) {
     DINV_REQUIRE(batch >= 0 && channels >= 1 && times >= 1 && height >= 1 && width >= 1 && mask, "bad mask geometry");
     DINV_REQUIRE(width <= MAXW, "mask width %d above the generator's limit %d", width, MAXW);
-    DINV_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (random lines) or 1 (equispaced)");
-    DINV_REQUIRE(mode == 1 || pdf_dev, "random-line masks need the column probabilities");
-    DINV_REQUIRE(mode == 0 || accel > 0.0, "equispaced masks need a positive acceleration");
+    DINV_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (random lines), 1 (equispaced) or 2 (Bernoulli columns)");
+    DINV_REQUIRE(mode == 1 || pdf_dev, "random-line and Bernoulli masks need the column probabilities");
+    DINV_REQUIRE(mode != 1 || accel > 0.0, "equispaced masks need a positive acceleration");
     DINV_REQUIRE(n_lines >= 0 && center_lo >= 0 && center_lo <= center_hi && center_hi <= width, "bad line counts");
     if (batch == 0) return 0;
     MaskArgs a{batch * times, times, channels, height, width, n_lines, center_lo, center_hi, mode, accel, n_offsets, seed, offset};

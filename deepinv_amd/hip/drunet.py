@@ -161,9 +161,24 @@ def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
     cout, cin = w.shape[:2]
     if cin % 16 or cin < 32 or cout % 64:
         raise ValueError(f"winograd packing needs cin % 16 == 0, cin >= 32 and cout % 64 == 0, got {cin},{cout}")
-    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
-    u = (G @ w.detach().double() @ G.t()).float().reshape(cout // 64, 64, cin // 8, 8, 16)
+    G = [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]]
+    u = filter_transform(G, w.detach().double()).float().reshape(cout // 64, 64, cin // 8, 8, 16)
     return u.permute(0, 2, 3, 1, 4).contiguous()
+
+
+def filter_transform(G, g: torch.Tensor) -> torch.Tensor:
+    """G g G^T over the last two dimensions of g [..., 3, 3] for an n x 3 matrix G given as nested Python floats, as
+    scalar-coefficient combinations of slices (fp64 elementwise arithmetic where the weights live): no matrix-multiply library is
+    called for an n x 3 . 3 x 3 . 3 x n product per filter (a batched fp64 GEMM through rocBLAS / Tensile otherwise)"""
+    def comb(coefs, parts):
+        acc = None
+        for c, p in zip(coefs, parts):
+            if c != 0.0:
+                acc = p * c if acc is None else acc + p * c
+        return acc if acc is not None else torch.zeros_like(parts[0])
+
+    rows = torch.stack([comb(Gi, [g[..., a, :] for a in range(3)]) for Gi in G], dim=-2)          # [..., n, 3] = G g
+    return torch.stack([comb(Gj, [rows[..., :, b] for b in range(3)]) for Gj in G], dim=-1)       # [..., n, n] = (G g) G^T
 
 
 def winograd4_matrices(dtype=torch.float64, device=None):
@@ -193,8 +208,8 @@ def pack_winograd4_weight(w: torch.Tensor) -> torch.Tensor:
     cout, cin = w.shape[:2]
     if cin % 16 or cout % 64:
         raise ValueError(f"winograd F(4,3) packing needs cin % 16 == 0 and cout % 64 == 0, got {cin},{cout}")
-    _, G, _ = winograd4_matrices(device=w.device)
-    u = (G @ w.detach().double() @ G.t()).float()                       # [co, ci, 6, 6]
+    _, G, _ = winograd4_matrices(device="cpu")
+    u = filter_transform(G.tolist(), w.detach().double()).float()       # [co, ci, 6, 6]
     u = u.reshape(cout, cin, 36)[:, :, list(WINOGRAD4_POINT_SLOTS)]     # slot order: see WINOGRAD4_POINT_SLOTS
     u = u.reshape(cout // 64, 2, 32, cin // 8, 2, 4, 4, 9)              # ct, c2, r, cb, h, m, q, k
     return u.permute(0, 3, 1, 6, 7, 4, 2, 5).contiguous()               # ct, cb, c2, q, k, h, r, m

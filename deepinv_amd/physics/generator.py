@@ -131,3 +131,43 @@ class EquispacedMaskGenerator(BaseMaskGenerator):
     def _sampling(self, W):
         adjusted = (self.acc * (self.n_center - W)) / (self.n_center * self.acc - W)
         return None, adjusted, round(adjusted)
+
+
+class PolyOrderMaskGenerator(BaseMaskGenerator):
+    """polynomial variable density (mri.py:199-281, Millard & Chiew): density (1 - r)^p over the normalised distance r from the
+    centre column, shifted by a constant found by bisection so that the mean sampling rate is 1 / acceleration, centre band
+    probability 1; every column of a mask row is then an independent Bernoulli draw (one launch for the whole batch, mode 2 of
+    dinv_mri_mask_lines).  The number of sampled lines is random (only its mean is 1 / acceleration), as in the reference."""
+
+    mode = 2
+
+    def __init__(self, *args, poly_order: int = 8, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.poly_order = poly_order
+        self.pdf = self.get_pdf()
+
+    def get_pdf(self, max_iter: int = 100, tol: float = 1e-3) -> torch.Tensor:
+        """the Bernoulli probabilities per column (fp32 arithmetic in the reference's order: its bisection stops at the first
+        midpoint whose rate is within `tol` of the target, so the same sequence of midpoints must be visited)"""
+        lo_c, hi_c = BaseMaskGenerator._center(self, self.W)
+        base = (1 - torch.linspace(-1, 1, self.W).abs()) ** self.poly_order
+        base[lo_c:hi_c] = 1
+        target = 1.0 / self.acc
+        lo, hi = -1.0, 1.0
+        for _ in range(max_iter):
+            shift = (lo + hi) / 2
+            cand = (base + shift).clamp_(0, 1)
+            cand[lo_c:hi_c] = 1
+            rate = cand.mean().item()
+            if rate < target - tol:
+                lo = shift
+            elif rate > target + tol:
+                hi = shift
+            else:
+                return cand.to(self.device)
+        raise ValueError(f"get_pdf did not converge after {max_iter} iterations")
+
+    def _sampling(self, W):
+        if W != self.W:
+            raise ValueError(f"PolyOrderMaskGenerator samples masks of the width it was built for ({self.W}), got {W}")
+        return self.pdf.float().contiguous(), 1.0, 0

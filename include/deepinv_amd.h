@@ -389,7 +389,9 @@ int dinv_gaussian_noise(int64_t n, int64_t per_sample, const float* x, const flo
 /* mask[batch, channels, times, height, width] of k-space columns.  mode 0: per (batch, time) row, n_lines columns
  * without replacement with probabilities pdf_dev[width] (zero on the centre band [center_lo, center_hi), which is
  * always sampled); mode 1: equispaced columns round(arange((t + offset_b) % accel, width - 1, accel)) with
- * offset_b uniform in [0, n_offsets). */
+ * offset_b uniform in [0, n_offsets); mode 2 (ABI 8): every column of a row an independent Bernoulli draw with probability
+ * pdf_dev[w] (PolyOrderMaskGenerator, mri.py:199-281; the centre band is whatever pdf_dev says, [center_lo, center_hi) is also
+ * forced on). */
 int dinv_mri_mask_lines(int32_t batch, int32_t channels, int32_t times, int32_t height, int32_t width, int32_t n_lines,
                         int32_t center_lo, int32_t center_hi, int32_t mode, const float* pdf_dev, double accel,
                         int32_t n_offsets, uint64_t seed, uint64_t offset, float* mask, dinv_stream_t stream);

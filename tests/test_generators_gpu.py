@@ -61,3 +61,68 @@ def test_mask_generators(dev, cls):
     phys = dinv.physics.MRI(img_size=(2, 320, 320), device=dev)
     y = phys.A(torch.rand(8, 2, 320, 320, device=dev), mask=m)
     assert torch.equal(y == 0, m == 0) or float(((y == 0) != (m == 0)).float().mean()) < 1e-6
+
+
+@pytest.mark.parametrize("cls,key", [("RandomMaskGenerator", "random"), ("GaussianMaskGenerator", "gaussian")])
+@pytest.mark.parametrize("W,acc", [(320, 4), (128, 8)])
+def test_mask_generators_have_the_reference_distribution(dev, cls, key, W, acc):
+    """4096 masks from the device generator against 4096 masks from the REFERENCE's generator (tests/golden/mask_generators.npz,
+    deepinv/physics/generator/mri.py:136-196, 284-325): per-column inclusion counts, two-sample chi-square (VERDICT r5 #5c)"""
+    import deepinv_amd as dinv
+    from test_emu_random import _golden_masks, chi_square_vs_reference
+
+    d = _golden_masks()
+    N = int(d["n_masks"])
+    gen = getattr(dinv.physics.generator, cls)((2, 8, W), acceleration=acc, device=dev, rng=torch.Generator(dev).manual_seed(1))
+    assert [gen.n_lines, gen.n_center] == [int(v) for v in d[f"{key}_{W}_{acc}_lines"]]
+    cols = gen.step(batch_size=N)["mask"][:, 0, 0]
+    assert torch.all(cols.sum(-1) == gen.n_lines + gen.n_center)
+    stat, df, bound = chi_square_vs_reference(cols.sum(0).cpu().numpy(), N, d[f"{key}_{W}_{acc}_counts"], N)
+    print(cls, W, acc, "chi-square", round(stat, 1), "df", df, "bound", round(bound, 1))
+    assert stat < bound
+
+
+@pytest.mark.parametrize("W,acc", [(320, 4), (128, 8)])
+@pytest.mark.parametrize("order", [4, 8])
+def test_poly_order_mask_generator(dev, W, acc, order):
+    """PolyOrderMaskGenerator (mri.py:199-281): the bisected Bernoulli probabilities equal the reference's, the masks have its
+    distribution, the centre band is always sampled, shapes / seeding follow the base class"""
+    import deepinv_amd as dinv
+    from test_emu_random import _golden_masks, chi_square_vs_reference
+
+    d = _golden_masks()
+    N = int(d["n_masks"])
+    gen = dinv.physics.generator.PolyOrderMaskGenerator((2, 8, W), acceleration=acc, poly_order=order, device=dev,
+                                                        rng=torch.Generator(dev).manual_seed(2))
+    ref_pdf = torch.from_numpy(d[f"poly{order}_{W}_{acc}_pdf"])
+    assert torch.allclose(gen.pdf.cpu(), ref_pdf, atol=1e-6)
+    m = gen.step(batch_size=N)["mask"]
+    assert m.shape == (N, 2, 8, W) and torch.equal(m, m[:, :1, :1].expand_as(m))
+    cols = m[:, 0, 0]
+    lo = W // 2 - gen.n_center // 2
+    assert torch.all(cols[:, lo:lo + gen.n_center] == 1)
+    stat, df, bound = chi_square_vs_reference(cols.sum(0).cpu().numpy(), N, d[f"poly{order}_{W}_{acc}_counts"], N)
+    assert stat < bound, (stat, df, bound)
+    assert abs(float(cols.mean()) - 1.0 / acc) < 2e-3 + 1e-3          # mean rate = 1 / acceleration within the bisection's tolerance
+    assert torch.equal(gen.step(batch_size=4, seed=9)["mask"], gen.step(batch_size=4, seed=9)["mask"])
+
+
+def test_equispaced_generator_patterns_are_the_reference_patterns(dev):
+    import deepinv_amd as dinv
+    from test_emu_random import _golden_masks
+
+    d = _golden_masks()
+    for W, acc in ((320, 4), (128, 8)):
+        pats = torch.from_numpy(d[f"equispaced_{W}_{acc}_patterns"]).float().to(dev)
+        gen = dinv.physics.generator.EquispacedMaskGenerator((2, 8, W), acceleration=acc, device=dev, rng=torch.Generator(dev).manual_seed(3))
+        cols = gen.step(batch_size=2048)["mask"][:, 0, 0]
+        which = (cols[:, None, :] == pats[None]).all(-1)
+        assert bool(which.any(1).all())
+        counts = which.float().sum(0)
+        assert float(counts.min()) > 0.5 * 2048 / pats.shape[0]         # every offset occurs, roughly uniformly
+    # k-t: sheared over time exactly like the reference's masks (same pattern family)
+    kt = torch.from_numpy(d["equispaced_kt_cols"]).float()            # [64, 4, 64] from the reference
+    gen = dinv.physics.generator.EquispacedMaskGenerator((2, 4, 8, 64), acceleration=4, device=dev, rng=torch.Generator(dev).manual_seed(4))
+    mine = gen.step(batch_size=256)["mask"][:, 0, :, 0].cpu()          # [256, 4, 64]
+    ref_set = {tuple(r.reshape(-1).tolist()) for r in kt}
+    assert len(ref_set) == 5 and {tuple(r.reshape(-1).tolist()) for r in mine} <= ref_set
