@@ -71,6 +71,9 @@ def main():
                     help="skip the companion timing of the bf16-split throughput setting")
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the operator rows of configs 3-5")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="DRUNet.batch_lanes: the per-GPU batch cut into this many parts, each run through the network on its own HIP "
+                         "stream (models/drunet.py); default: the model's default")
     ap.add_argument("--as-multi", action="store_true",
                     help="pre-flight of the multi-GPU code path on ONE rank: create the RCCL process group, replay the iteration as a HIP "
                          "graph, run agree_on_graph / barrier / all-gather / max-over-ranks exactly as an N > 1 run does (world size 1 "
@@ -107,6 +110,9 @@ def main():
 
     torch.manual_seed(0)
     denoiser = dinv.models.DRUNet(2, 2, pretrained=None).to(device).eval()
+    if args.lanes is not None:
+        denoiser.batch_lanes = args.lanes
+    lanes = max(1, min(int(denoiser.batch_lanes), B_local))
     model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(denoiser), stepsize=1.0, g_param=0.05,
                            max_iter=args.iters, early_stop=False)
     # The PGD iteration as a replayed HIP graph (optim/fixed_point.py: use_graph - one host call per iteration instead of ~80 launches):
@@ -267,8 +273,11 @@ def main():
         # the direct convolution it evaluates (36 instead of 144 per 4x4 output tile and channel pair for F(4x4,3x3)): the
         # ALGORITHMIC count of SURVEY 8d (2*9*Cin*Cout*B*H*W per launch) over the same time is reported beside it as
         # `direct_equiv` / `frac_direct_equiv` (that one can exceed 1 and is not a fraction of any roofline).
-        achieved = kp["direct_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
-        executed = kp["mfma_flops"] / (kp["ms"] * 1e-3) if kp else 0.0
+        # batch lanes > 1: the launches of the lanes run CONCURRENTLY (each on the compute units the other leaves idle), so the HIP-event
+        # durations of the launches overlap in time; the time the kernel family occupies the chip is their sum / lanes
+        kms = kp["ms"] / lanes if kp else 0.0
+        achieved = kp["direct_flops"] / (kms * 1e-3) if kp else 0.0
+        executed = kp["mfma_flops"] / (kms * 1e-3) if kp else 0.0
         all_ms = sum(v["ms"] for v in conv_prof.values())
         all_direct = sum(v["direct_flops"] for v in conv_prof.values())
         kdesc = {"conv3x3_wino4_kernel": "DRUNet 3x3 conv as Winograd F(4x4,3x3), v_mfma_f32_32x32x2_f32",
@@ -319,7 +328,7 @@ def main():
                                    "DRUNet(2->2, random init), global batch %d" % args.batch,
                        "global_batch": args.batch, "per_gpu_batch": B_local, "iters": args.iters,
                        "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if multi else "none",
-                       "conv_precision": "fp32", "loop_graph": graph_state["on"], "loop_graph_error": graph_state["error"],
+                       "conv_precision": "fp32", "batch_lanes": lanes, "loop_graph": graph_state["on"], "loop_graph_error": graph_state["error"],
                        **({"as_multi_preflight": True, "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}}
                           if args.as_multi else {})},
             "roofline": {"bound": "mfma", "kernel": f"{kname} ({kdesc})",
@@ -335,7 +344,7 @@ def main():
                          "package_during_timed_steps": package,
                          "launches": kp["launches"] if kp else 0,
                          "avg_launch_ms": round(kp["ms"] / max(kp["launches"], 1), 4) if kp else 0.0,
-                         "share_of_step": round(kp["ms"] * 1e-3 / (elapsed * prof_steps[0] / args.steps), 4) if kp else 0.0,
+                         "share_of_step": round(kms * 1e-3 / (elapsed * prof_steps[0] / args.steps), 4) if kp else 0.0,
                          "events_from": "the timed steps" if not graph_state["on"] else
                                         "one eager step after the timed region (the timed steps replay a HIP graph: no events inside it)",
                          "conv3x3_direct_equiv_TFLOPs": round(all_direct / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,

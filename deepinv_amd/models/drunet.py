@@ -254,11 +254,12 @@ class DRUNet(Denoiser):
         self._engine = e
         return e
 
-    def _workspace(self, e, B, H, W, device):
-        key = (B, H, W)
+    def _workspace(self, e, B, H, W, device, lane=0):
+        key = (B, H, W, lane)
         ws = e["ws"].get(key)
         if ws is None:
-            e["ws"].clear()  # one geometry at a time keeps the footprint bounded
+            if any(k[1:3] != (H, W) or k[3] == lane for k in e["ws"]):
+                e["ws"].clear()  # one image geometry at a time keeps the footprint bounded (its batch lanes live side by side)
             nc = self.nc
             g = [K.geom(B, H >> i, W >> i) for i in range(4)]
             cin_p = e["head"][0][1]
@@ -321,12 +322,54 @@ class DRUNet(Denoiser):
             cur = dst
         return cur
 
+    # ---- batch lanes: the batch cut into `batch_lanes` contiguous parts, each run through the whole network on its own HIP stream.
+    # The units of a batch are independent through the network, and every convolution launch ends in an incomplete round of
+    # workgroups (a persistent workgroup per compute unit; 800 tiles over 256 units = 3.125 rounds at 4 slices) during which most
+    # of the chip idles: with two lanes the other lane's launch fills the units as they fall idle, and the lanes' epilogues (the
+    # HBM bursts of a launch) no longer coincide.  1 = one launch sequence (default).  Results do not depend on it (every unit is
+    # computed by the same instruction sequence; only the tile a unit shares with a neighbour of the batch changes).
+    batch_lanes = 1
+
+    def _lane_streams(self, device, n):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+        pool = getattr(self, "_lane_pool", None)
+        if pool is None:
+            pool = self._lane_pool = {}
+        if key not in pool:
+            pool[key] = [torch.cuda.Stream(device) for _ in range(n)]
+        return pool[key]
+
     def _hip_forward(self, x, sigma_map):
+        B = x.shape[0]
+        lanes = max(1, min(int(self.batch_lanes), B))
+        if lanes == 1:
+            return self._hip_forward_lane(x, sigma_map)
+        dev = x.device
+        x = x.contiguous().float()
+        y = torch.empty((B, self.out_channels, *x.shape[2:]), device=dev, dtype=torch.float32)
+        cur = torch.cuda.current_stream(dev)
+        streams = self._lane_streams(dev, lanes)
+        q, r = divmod(B, lanes)
+        b0 = 0
+        for i, s in enumerate(streams):
+            b1 = b0 + q + (1 if i < r else 0)
+            sg = sigma_map
+            if isinstance(sg, torch.Tensor) and sg.numel() > 1:      # one value per sample, or a map: this lane's units
+                sg = sg.reshape(B, *sg.shape[1:])[b0:b1] if sg.shape[0] == B else sg
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                self._hip_forward_lane(x[b0:b1], sg, lane=i, out=y[b0:b1])
+            b0 = b1
+        for s in streams:
+            cur.wait_stream(s)
+        return y
+
+    def _hip_forward_lane(self, x, sigma_map, lane=0, out=None):
         """forward_unet (drunet.py:200-210) as 64 conv launches + pack/unpack."""
         dev = x.device
         e = self._prepare(dev)
         B, _, H, W = x.shape
-        ws = self._workspace(e, B, H, W, dev)
+        ws = self._workspace(e, B, H, W, dev, lane)
         g = ws["g"]
         nc = self.nc
         x = x.contiguous().float()
@@ -359,7 +402,7 @@ class DRUNet(Denoiser):
         else:
             (wt, cit, cot) = self._pick(g[0], e["tail"])
             K.conv3x3(g[0], r, wt, cit, cot, ws["out"], cout_valid=self.out_channels, x2=ws["skip0"])
-        y = torch.empty((B, self.out_channels, H, W), device=dev, dtype=torch.float32)
+        y = out if out is not None else torch.empty((B, self.out_channels, H, W), device=dev, dtype=torch.float32)
         K.unpack_output(g[0], ws["out"], self.out_channels, y)
         return y
 

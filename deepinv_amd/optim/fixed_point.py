@@ -6,6 +6,21 @@ import torch.nn as nn
 from .optim_iterators import CallContext
 
 
+_CAPTURE_STREAMS: dict = {}
+
+
+def _capture_stream(device):
+    """ONE capture stream per device, reused by every call: per-stream scratch of the kernels (the F(4x4) tail-split workspace,
+    hip/drunet.py: winograd4_workspace) is then created once - by an eager launch on this stream before the first capture - instead
+    of being allocated inside a capture for every fresh stream of the pool"""
+    import torch
+
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CAPTURE_STREAMS:
+        _CAPTURE_STREAMS[idx] = torch.cuda.Stream(device)
+    return _CAPTURE_STREAMS[idx]
+
+
 class FixedPoint(nn.Module):
     def __init__(self, iterator=None, update_params_fn=None, update_data_fidelity_fn=None, update_prior_fn=None,
                  init_iterate_fn=None, init_metrics_fn=None, update_metrics_fn=None, check_conv_fn=None,
@@ -112,14 +127,16 @@ class FixedPoint(nn.Module):
 
         stop = self._device_stop_ok(X, False) and self.check_conv_fn is not None
         n_eager = 2 if stop else 1
-        for it in range(n_eager):
-            X = self.single_iteration(X, it, *args, **kwargs)
-        static = [t.clone() for t in X["est"]]
-        done = torch.zeros((), dtype=torch.bool, device=static[0].device) if stop else None
         graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
+        # the eager iteration(s) run on the capture stream as well: whatever scratch the kernels keep per stream exists before
+        # the capture begins (nothing is allocated inside it)
+        side = _capture_stream(X["est"][0].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            for it in range(n_eager):
+                X = self.single_iteration(X, it, *args, **kwargs)
+            static = [t.clone() for t in X["est"]]
+            done = torch.zeros((), dtype=torch.bool, device=static[0].device) if stop else None
             with torch.cuda.graph(graph, stream=side):
                 Xp = {"est": tuple(static), "cost": None}
                 Xo = self.single_iteration(Xp, n_eager, *args, **kwargs)

@@ -62,7 +62,18 @@ def _hip_cg_ok(b, init):
     return b.is_cuda and n % 4 == 0 and ew.eligible(b, init) and not torch.is_grad_enabled()
 
 
-CG_CHECK_EVERY = 4   # host looks at the device-side convergence flag every this many iterations
+# The host looks at the device-side convergence flag every this many iterations.  None = by problem size: reading the flag drains
+# the stream (~30 us until the next kernel starts), running past convergence costs up to CG_CHECK_EVERY - 1 operator pairs - for a
+# large system (cfg3: 2 ms per A^T A pair on 8 x 512 x 512) the pair is the expensive side and the flag is read after every
+# iteration, so A^T A is applied exactly as often as the reference applies it; for small systems every 4th iteration.
+CG_CHECK_EVERY = None
+CG_LARGE_SYSTEM = 1 << 20     # elements of b from which an operator pair outweighs a stream drain
+
+
+def cg_check_cadence(b) -> int:
+    if CG_CHECK_EVERY is not None:
+        return int(CG_CHECK_EVERY)
+    return 1 if b.numel() >= CG_LARGE_SYSTEM else 4
 
 
 def _conjugate_gradient_hip(A, b, max_iter, tol, eps, init, verbose, ew=None):
@@ -86,13 +97,14 @@ def _conjugate_gradient_hip(A, b, max_iter, tol, eps, init, verbose, ew=None):
     tol2 = (b_norm_sq * (tol ** 2)).contiguous()
     done = torch.zeros(1, dtype=torch.int32, device=b.device)
     capturing = b.is_cuda and torch.cuda.is_current_stream_capturing()
+    every = cg_check_cadence(b)
     for i in range(int(max_iter)):
         Ap = A(p).contiguous()
         pAp = ew.batched_dot(p, Ap)
         ew.cg_update_xr(res_old, pAp, eps, x, r, p, Ap, done)    # x += alpha p ; r -= alpha Ap
         res_new = ew.batched_dot(r, r)
         ew.cg_check(res_new, tol2, done)
-        if not capturing and (i % CG_CHECK_EVERY == CG_CHECK_EVERY - 1 or i == int(max_iter) - 1) and bool(done.item()):
+        if not capturing and (i % every == every - 1 or i == int(max_iter) - 1) and bool(done.item()):
             if verbose:
                 print("CG Converged at iteration <=", i + 1)
             break

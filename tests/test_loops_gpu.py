@@ -446,3 +446,41 @@ def test_bench_multi_gpu_code_path_preflight_on_one_rank():
     assert cfg["collective"] == "all_gather(reconstruction)"
     assert "eager step after the timed region" in res["roofline"]["events_from"]
     assert res["roofline"]["launches"] > 0 and "cpu_baseline" not in res
+
+
+@pytest.mark.parametrize("B,lanes", [(4, 2), (5, 2), (6, 3)])
+def test_drunet_batch_lanes_equal_one_launch_sequence(dev, B, lanes):
+    """DRUNet.batch_lanes (models/drunet.py): the batch cut into parts that run through the network concurrently on their own HIP
+    streams gives the reconstruction of the single launch sequence (same instruction sequence per unit: fp32 rounding of shared
+    tiles only), eagerly and under HIP-graph replay of the PGD iteration; per-sample and map noise levels follow their units"""
+    import deepinv_amd as dinv
+    from oracle import drunet_cpu as OD
+
+    g = torch.Generator().manual_seed(B)
+    den = dinv.models.DRUNet(2, 2, pretrained=None).to(dev).eval()
+    den.load_state_dict(OD.init_state_dict(2, 2, seed=3))
+    x = torch.rand(B, 2, 64, 96, generator=g).to(dev)
+    for sigma in (0.05, torch.linspace(0.02, 0.1, B).to(dev), (0.02 + 0.1 * torch.rand(B, 1, 64, 96, generator=g)).to(dev)):
+        den.batch_lanes = 1
+        ref = den(x, sigma)
+        den.batch_lanes = lanes
+        out = den(x, sigma)
+        assert float((out - ref).norm() / ref.norm()) < 1e-5
+    # inside the loop, eager and replayed
+    maps = torch.randn(1, 4, 64, 96, dtype=torch.complex64, generator=g) / 2
+    mask = (torch.rand(64, 96, generator=g) > 0.6).float()
+    phys = dinv.physics.MultiCoilMRI(mask=mask.to(dev), coil_maps=maps.to(dev), img_size=(2, 64, 96), device=dev)
+    y = phys.A(x)
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=1.0, g_param=0.05, max_iter=5,
+                           early_stop=False)
+    with torch.no_grad():
+        den.batch_lanes = 1
+        ref = model(y, phys)
+        den.batch_lanes = lanes
+        eager = model(y, phys)
+        model.fixed_point.use_graph = True
+        replay = model(y, phys)
+        replay2 = model(y, phys)
+    torch.cuda.synchronize()
+    assert float((eager - ref).norm() / ref.norm()) < 1e-5
+    assert float((replay - ref).norm() / ref.norm()) < 1e-5 and torch.equal(replay, replay2)

@@ -168,7 +168,7 @@ def test_cfg2_unit_gain_with_the_bf16x3_winograd_form(dev, monkeypatch):
     assert between < 1e-5
 
 
-def full_length_cfg3(dinv, dev, d, B=8, precisions=None, runs=1, exact_cg_counts=False):
+def full_length_cfg3(dinv, dev, d, B=8, precisions=None, runs=1, exact_cg_counts=False, image_seed=50, images=None):
     """BASELINE configs[2] at FULL length on the per-GPU shard (8 images 512x512, 720 angles): FBP-initialised PnP-HQS, 30
     iterations, the prox by CG with the reference's DEFAULT settings (max_iter 50, tol 1e-4: the number of CG iterations is
     decided by `torch.all(residual < tol)` over the BATCH, conjugate_gradient.py:61), DRUNet(1->1), the schedules of bench.py.
@@ -182,8 +182,11 @@ def full_length_cfg3(dinv, dev, d, B=8, precisions=None, runs=1, exact_cg_counts
     from oracle import drunet_cpu as OD
 
     st, stt, iters = int(d["stride"]), int(d["stride_trace"]), int(d["iters"])
-    W, nang = 512, 720
-    x = torch.rand(1, 1, W, W, generator=gen(50)).expand(B, 1, W, W).contiguous().to(dev)
+    W, nang = (int(d["width"]), int(d["angles"])) if "width" in d else (512, 720)
+    if images is not None:          # a batch of DISTINCT units (fixtures with one reconstruction / trace row per unit)
+        x, B = images.to(dev), images.shape[0]
+    else:
+        x = torch.rand(1, 1, W, W, generator=gen(image_seed)).expand(B, 1, W, W).contiguous().to(dev)
     p = dinv.physics.Tomography(angles=nang, img_width=W, circle=False, normalize=True, device=dev)
     assert abs(float(p.operator_norm) - float(d["operator_norm"])) < 1e-4 * float(d["operator_norm"])
     assert (p.max_iter, p.tol) == (int(d["cg_max_iter"]), float(d["cg_tol"]))
@@ -201,7 +204,9 @@ def full_length_cfg3(dinv, dev, d, B=8, precisions=None, runs=1, exact_cg_counts
         den.conv_precision = prec
         for _ in range(runs):
             trace, calls, per_prox = [], [0], []
-            hook = den.register_forward_hook(lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt]))
+            hook = den.register_forward_hook(
+                (lambda m, i, o: trace.append(torch.stack([u.detach().reshape(-1)[::stt] for u in o]))) if images is not None else
+                (lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt])))
 
             def counting(v, **kw):
                 calls[0] += 1
@@ -229,6 +234,12 @@ def full_length_cfg3(dinv, dev, d, B=8, precisions=None, runs=1, exact_cg_counts
                 linear.CG_CHECK_EVERY = check_every
         tr = torch.stack([t.cpu() for t in trace])
         trace_err = [rel_err(a, b) for a, b in zip(tr, d["den_outs"])]
+        if images is not None:
+            per_unit = [rel_err(sub(rec[k:k + 1], st), d["rec"][k]) for k in range(B)]
+            res[prec] = {"vs_reference": max(per_unit), "per_unit": per_unit, "trace_max": max(trace_err), "trace": trace_err,
+                         "ata_per_prox": per_prox, "ata_calls": calls[0], "ata_calls_reference": int(d["n_ata"].sum()), "seconds": dt,
+                         "finite": bool(torch.isfinite(rec).all())}
+            continue
         res[prec] = {"vs_reference": rel_err(sub(rec[:1], st), d["rec"]),
                      "trace_max": max(trace_err), "trace": trace_err, "ata_per_prox": per_prox,
                      "copies_identical": bool(torch.equal(rec[:1].expand_as(rec), rec)),
@@ -272,6 +283,53 @@ def test_cfg3_fbp_pnp_hqs_full_length_30_iterations(dev):
         assert max(agree) < 3e-3, (prec, r["trace"], differ)
 
 
+def _assert_cfg3_run(res, d, n_differ=6):
+    ref_counts = [int(v) for v in d["n_ata"]]
+    for prec, r in res.items():
+        assert r["finite"]
+        assert r["vs_reference"] < TOL, (prec, {k: v for k, v in r.items() if k != "trace"})
+        assert r["trace_max"] < 3e-2, (prec, r["trace"])
+        assert len(r["ata_per_prox"]) == len(ref_counts) == len(r["trace"])
+        differ = [i for i, (a, b) in enumerate(zip(r["ata_per_prox"], ref_counts)) if a != b]
+        assert len(differ) <= n_differ, (prec, r["ata_per_prox"], ref_counts)
+        assert abs(r["ata_calls"] - r["ata_calls_reference"]) <= 0.05 * r["ata_calls_reference"]
+        agree = [e for i, e in enumerate(r["trace"]) if i not in differ]
+        assert max(agree) < 3e-3, (prec, r["trace"], differ)
+
+
+def test_cfg3_full_length_second_draw(dev):
+    """A SECOND full-length draw of configs[2] against the real reference (tests/golden/cfg3_full_b.npz, make_golden_r6.py: another
+    image, another DRUNet initialisation): the 1e-4 end point of the 30-iteration FBP + PnP-HQS loop is not a property of one seed
+    (VERDICT r5 weak #1).  Same assertions as the first draw."""
+    import deepinv_amd as dinv
+
+    if not os.path.exists(os.path.join(G, "cfg3_full_b.npz")):
+        pytest.skip("tests/golden/cfg3_full_b.npz not generated (tests/golden/make_golden_r6.py cfg3_b: ~1.5 h of CPU)")
+    d = load("cfg3_full_b")
+    res = full_length_cfg3(dinv, dev, d, exact_cg_counts=True, image_seed=60)
+    print("cfg3 full length, second draw:", {k: {a: (f"{b:.2e}" if isinstance(b, float) else b) for a, b in v.items() if a != "trace"} for k, v in res.items()})
+    for r in res.values():
+        assert r["copies_identical"]
+    _assert_cfg3_run(res, d)
+
+
+def test_cfg3_two_distinct_images_share_the_batch_wide_cg_stop(dev):
+    """The NON-degenerate batch: two different images (one of them much darker) through the same loop at 256 x 256 / 360 angles
+    (tests/golden/cfg3_pair.npz).  The reference stops its CG when `torch.all(residual < tol)` holds over the BATCH
+    (deepinv/optim/linear/conjugate_gradient.py:61) - the slower unit decides for both - and the device-side flag of
+    dinv_cg_check reproduces exactly that: both reconstructions within 1e-4, per-prox A^T A counts as the reference's."""
+    import deepinv_amd as dinv
+
+    if not os.path.exists(os.path.join(G, "cfg3_pair.npz")):
+        pytest.skip("tests/golden/cfg3_pair.npz not generated (tests/golden/make_golden_r6.py cfg3_pair)")
+    d = load("cfg3_pair")
+    W = int(d["width"])
+    xs = torch.cat((torch.rand(1, 1, W, W, generator=gen(64)), 0.5 * torch.rand(1, 1, W, W, generator=gen(65)) ** 2))
+    res = full_length_cfg3(dinv, dev, d, exact_cg_counts=True, images=xs)
+    print("cfg3 pair:", {k: {a: (f"{b:.2e}" if isinstance(b, float) else b) for a, b in v.items() if a != "trace"} for k, v in res.items()})
+    _assert_cfg3_run(res, d)
+
+
 def full_length_cfg5(dinv, dev, d, B=16, precisions=None, runs=1):
     """BASELINE configs[4] at FULL length on the per-GPU shard (16 images 3x256x256): 100-step DiffPIR, unit 0 = the fixture's
     seeded image with the fixture's torch.randn_like draws replayed (the other units get different images and draws).  Returns
@@ -300,7 +358,9 @@ def full_length_cfg5(dinv, dev, d, B=16, precisions=None, runs=1):
         assert torch.equal(sampler.seq.cpu(), d["seq"])
         for _ in range(runs):       # (the last run is the one timed and compared: the first also packs weights and allocates)
             trace = []
-            hook = den.register_forward_hook(lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt]))
+            hook = den.register_forward_hook(
+                (lambda m, i, o: trace.append(torch.stack([u.detach().reshape(-1)[::stt] for u in o]))) if images is not None else
+                (lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt])))
             # the Gaussian draws of the whole run, made BEFORE the timed region (unit 0 replays the reference's generator stream,
             # the rest of the shard has its own): resident in HBM like every other input
             g0, g1 = gen(74), gen(704)
