@@ -73,7 +73,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the operator rows of configs 3-5")
     ap.add_argument("--lanes", type=int, default=None,
                     help="DRUNet.batch_lanes: the per-GPU batch cut into this many parts, each run through the network on its own HIP "
-                         "stream (models/drunet.py); default: the model's default")
+                         "stream (models/drunet.py); default: the model's default (auto: 2 up to 16 slices of 320 x 320, else 1)")
+    ap.add_argument("--no-tail-split", action="store_true", help="diagnostic: F(4x4) launches without the channel split of their last round")
+    ap.add_argument("--bf16x3", action="store_true", help="diagnostic: the F(4x4) launches in their bf16 x 3 form (hip/drunet.py: FP32_WINOGRAD4_BF16X3)")
     ap.add_argument("--as-multi", action="store_true",
                     help="pre-flight of the multi-GPU code path on ONE rank: create the RCCL process group, replay the iteration as a HIP "
                          "graph, run agree_on_graph / barrier / all-gather / max-over-ranks exactly as an N > 1 run does (world size 1 "
@@ -112,7 +114,11 @@ def main():
     denoiser = dinv.models.DRUNet(2, 2, pretrained=None).to(device).eval()
     if args.lanes is not None:
         denoiser.batch_lanes = args.lanes
-    lanes = max(1, min(int(denoiser.batch_lanes), B_local))
+    if args.no_tail_split:
+        K.WINOGRAD4_TAIL_SPLIT = False
+    if args.bf16x3:
+        K.FP32_WINOGRAD4_BF16X3 = True
+    lanes = denoiser._lanes(torch.empty(B_local, 2, H, W, device="meta"))
     model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(denoiser), stepsize=1.0, g_param=0.05,
                            max_iter=args.iters, early_stop=False)
     # The PGD iteration as a replayed HIP graph (optim/fixed_point.py: use_graph - one host call per iteration instead of ~80 launches):

@@ -87,11 +87,52 @@ struct TileConv {
     int32_t pw, pitch;      // patch columns, LDS row pitch (floats)
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one patch row of one chunk of (up to) four filter columns: output row i of the thread (MASK bit i) multiplies it with filter row
+// r - i, whose four taps are one 16-byte LDS read (the same address in every lane).  The 4 x 4 outputs are held as PAIRS of
+// neighbouring columns, so that a multiply-add is one v_pk_fma_f32 on (tap, tap) x (patch[c], patch[c + 1]); the pairs that start
+// at an odd patch column (taps 1 and 3) are re-packed from the even ones with six register moves.
+template <int MASK, int NV>
+__device__ __forceinline__ void tile_step(f32x2 (&acc)[4][2], const float* __restrict__ prow, const float* __restrict__ krow, int w4) {
+    const float4 a = *reinterpret_cast<const float4*>(prow);
+    const float2 b = *reinterpret_cast<const float2*>(prow + 4);
+    const float2 c = *reinterpret_cast<const float2*>(prow + 6);
+    const f32x2 E0 = {a.x, a.y}, E1 = {a.z, a.w}, E2 = {b.x, b.y};
+    const f32x2 O0 = {a.y, a.z}, O1 = {a.w, b.x}, O2 = {b.y, c.x};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!((MASK >> i) & 1)) continue;
+        const float4 t = *reinterpret_cast<const float4*>(krow - i * w4);
+        if (NV > 0) { acc[i][0] += t.x * E0; acc[i][1] += t.x * E1; }
+        if (NV > 1) { acc[i][0] += t.y * O0; acc[i][1] += t.y * O1; }
+        if (NV > 2) { acc[i][0] += t.z * E1; acc[i][1] += t.z * E2; }
+        if (NV > 3) { acc[i][0] += t.w * O1; acc[i][1] += t.w * O2; }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void tile_chunk(f32x2 (&acc)[4][2], const float* __restrict__ prow, const float* __restrict__ krow, int pitch,
+                                           int w4, int h) {
+    if (h >= 4) {
+        // filter row r - i exists for 0 <= r - i < h: the first and the last three patch rows serve fewer output rows
+        tile_step<1, NV>(acc, prow, krow, w4);
+        tile_step<3, NV>(acc, prow + pitch, krow + w4, w4);
+        tile_step<7, NV>(acc, prow + 2 * pitch, krow + 2 * w4, w4);
+        for (int r = 3; r < h; ++r) tile_step<15, NV>(acc, prow + r * pitch, krow + r * w4, w4);
+        tile_step<14, NV>(acc, prow + h * pitch, krow + h * w4, w4);
+        tile_step<12, NV>(acc, prow + (h + 1) * pitch, krow + (h + 1) * w4, w4);
+        tile_step<8, NV>(acc, prow + (h + 2) * pitch, krow + (h + 2) * w4, w4);
+    } else {       // short filters: every step with all four rows (the table's zero rows above and below make the surplus vanish)
+        for (int r = 0; r < h + 3; ++r) tile_step<15, NV>(acc, prow + r * pitch, krow + r * w4, w4);
+    }
+}
+
 __global__ __launch_bounds__(256) void conv2d_tiled_kernel(TileConv g, const float* __restrict__ in, const float* __restrict__ k,
                                                            float* __restrict__ out) {
     DINV_DYN_LDS(float, smem);
     const int w4 = (g.w + 3) & ~3, ph = 64 + g.h - 1;
-    float* kt = smem;                                   // [(h + 6)][w4]
+    float* kt = smem;                                   // [(h + 6)][w4]: rows -3 .. h + 2 of the (flipped) filter, zero outside
     float* patch = smem + (g.h + 6) * w4;               // [ph][pitch]
     const int bc = blockIdx.z, b = bc / g.C, c = bc % g.C;
     const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * g.h * g.w;
@@ -114,32 +155,16 @@ __global__ __launch_bounds__(256) void conv2d_tiled_kernel(TileConv g, const flo
     }
     __syncthreads();
     const int tx = tid & 15, ty = tid >> 4;
-    float acc[4][4];
+    f32x2 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    const int steps = g.h + 3;
-    for (int cv = 0; cv < w4; cv += 4) {
-        float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1, t3 = t1;
-        const float* prow = patch + (ty * 4) * g.pitch + tx * 4 + cv;
-        const float* krow = kt + 3 * w4 + cv;
-        for (int r = 0; r < steps; ++r) {
-            const float4 a = *reinterpret_cast<const float4*>(prow), bq = *reinterpret_cast<const float4*>(prow + 4);
-            const float4 t0 = *reinterpret_cast<const float4*>(krow);
-            const float sg[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
-            const float tp[4][4] = {{t0.x, t0.y, t0.z, t0.w}, {t1.x, t1.y, t1.z, t1.w}, {t2.x, t2.y, t2.z, t2.w}, {t3.x, t3.y, t3.z, t3.w}};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)          // output row i sees patch row r with filter row u = r - i
-#pragma unroll
-                for (int vv = 0; vv < 4; ++vv)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(tp[i][vv], sg[vv + j], acc[i][j]);
-            t3 = t2; t2 = t1; t1 = t0;
-            prow += g.pitch;
-            krow += w4;
-        }
-    }
+    for (int i = 0; i < 4; ++i) { acc[i][0] = f32x2{0.f, 0.f}; acc[i][1] = f32x2{0.f, 0.f}; }
+    const float* pbase = patch + (ty * 4) * g.pitch + tx * 4;
+    const float* kbase = kt + 3 * w4;
+    const int nfull = g.w >> 2, rem = g.w & 3;
+    for (int q = 0; q < nfull; ++q) tile_chunk<4>(acc, pbase + 4 * q, kbase + 4 * q, g.pitch, w4, g.h);
+    if (rem == 1) tile_chunk<1>(acc, pbase + 4 * nfull, kbase + 4 * nfull, g.pitch, w4, g.h);
+    else if (rem == 2) tile_chunk<2>(acc, pbase + 4 * nfull, kbase + 4 * nfull, g.pitch, w4, g.h);
+    else if (rem == 3) tile_chunk<3>(acc, pbase + 4 * nfull, kbase + 4 * nfull, g.pitch, w4, g.h);
     float* o = out + (int64_t)bc * g.Ho * g.Wo;
     const int oc = c0 + tx * 4;
     const bool vec = (g.Wo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && (((int64_t)g.Ho * g.Wo) % 4 == 0);
@@ -148,12 +173,13 @@ __global__ __launch_bounds__(256) void conv2d_tiled_kernel(TileConv g, const flo
         const int orow = r0 + ty * 4 + i;
         if (orow >= g.Ho) continue;
         float* dst = o + (int64_t)orow * g.Wo + oc;
+        const float v4[4] = {acc[i][0].x, acc[i][0].y, acc[i][1].x, acc[i][1].y};
         if (vec && oc + 3 < g.Wo) {
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            *reinterpret_cast<float4*>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (oc + j < g.Wo) dst[j] = acc[i][j];
+                if (oc + j < g.Wo) dst[j] = v4[j];
         }
     }
 }
@@ -616,11 +642,11 @@ struct PitchedColsIo {      // column pass over the first Q columns of t [P, N, 
 // The middle pass of the fused operator: t <- F_H^-1( SYMBOL( F_H t ) ) on strips of L columns - the forward column transform
 // leaves its outputs, symbol applied, in a second LDS tile in natural order; the inverse transform reads them from there.  The
 // spectrum crosses HBM once in each direction instead of three times (forward columns, symbol, inverse columns).
-template <class P, int L>
-__global__ __launch_bounds__(256) void blurfft_cols_kernel(float2* __restrict__ t, int64_t pitch, int64_t Q, int64_t qtiles,
+template <class P, int L, int NT>
+__global__ __launch_bounds__(NT, (NT == 512 && P::N <= 256) ? 4 : 2) void blurfft_cols_kernel(float2* __restrict__ t, int64_t pitch, int64_t Q, int64_t qtiles,
                                                            int64_t ntiles, const void* table, Symbol sym) {
-    using TF = TileFft<P, false, false, L>;
-    using TI = TileFft<P, true, false, L>;
+    using TF = TileFft<P, false, false, L, NT>;
+    using TI = TileFft<P, true, false, L, NT>;
     constexpr int N = P::N;
     __shared__ __attribute__((aligned(16))) float2 buf[TF::lds_floats2];
     __shared__ __attribute__((aligned(16))) float2 ksp[(size_t)L * N];
@@ -652,7 +678,10 @@ int launch_blurfft_cols(float2* t, int64_t pitch, int64_t P_, int64_t Q, const v
     constexpr int L = BlurColsL<N>::value;
     const int64_t qtiles = ceil_div(Q, L), ntiles = P_ * qtiles;
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 4 * kMaxGrid);
-    hipLaunchKernelGGL((blurfft_cols_kernel<P, L>), dim3(grid), dim3(256), 0, s, t, pitch, Q, qtiles, ntiles, table, sym);
+    // 512 threads from 256 points up: half the register arrays per thread (202 -> ~110 registers at N = 256), twice the waves per
+    // compute unit behind the same two LDS tiles
+    constexpr int NT = N >= 256 ? 512 : 256;
+    hipLaunchKernelGGL((blurfft_cols_kernel<P, L, NT>), dim3(grid), dim3(NT), 0, s, t, pitch, Q, qtiles, ntiles, table, sym);
     DINV_CHECK_LAUNCH();
     return 0;
 }

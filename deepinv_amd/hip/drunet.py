@@ -26,6 +26,9 @@ WINOGRAD4_MIN_TILES = 64
 # matrix cores (dinv_conv3x3_winograd4_bf16x3: same per-layer accuracy, 3/8 of the matrix-pipe time).  Off by default: sustained,
 # the package power limit makes the two forms equally fast at every batch (scripts/r05/bf16x3_e2e.py)
 FP32_WINOGRAD4_BF16X3 = False
+# False: the F(4x4,3x3) launches get no workspace, i.e. the incomplete last round of tiles is not cut along the input channels
+# (diagnostic switch: bench.py --no-tail-split)
+WINOGRAD4_TAIL_SPLIT = True
 
 
 def _l():
@@ -466,11 +469,13 @@ def conv3x3_winograd(g, x, wino, cin, cout, y, res1=None, relu=False):
 _W4_WS: dict = {}
 
 
-def winograd4_workspace(device) -> torch.Tensor:
+def winograd4_workspace(device):
     """the workspace of dinv_conv3x3_winograd4's tail split for the CURRENT stream of `device` (zero-filled once; the library
     keeps its ticket words zero between launches).  Launches on one stream are ordered, so one buffer serves every layer issued
     there; two streams of a device must not share one (their tail parts would take each other's tickets and partial outputs),
     hence the key (device, stream)."""
+    if not WINOGRAD4_TAIL_SPLIT:
+        return None
     device = torch.device(device)
     if device.type == "cuda":
         idx = device.index if device.index is not None else torch.cuda.current_device()

@@ -328,7 +328,17 @@ class DRUNet(Denoiser):
     # of the chip idles: with two lanes the other lane's launch fills the units as they fall idle, and the lanes' epilogues (the
     # HBM bursts of a launch) no longer coincide.  1 = one launch sequence (default).  Results do not depend on it (every unit is
     # computed by the same instruction sequence; only the tile a unit shares with a neighbour of the batch changes).
-    batch_lanes = 1
+    # "auto": two lanes while the whole batch is at most 16 slices of 320 x 320 (measured on MI355X, cfg2, graph replay, ms per
+    # 50-iteration step with 1 / 2 lanes: 4 slices 327 / 311, 8 slices 602 / 538, 16 slices 1081 / 1060, 32 slices 2013 / 2039 - at
+    # 32 slices a launch has 25 full rounds and the package is at its power limit: nothing idles that a second lane could use).
+    batch_lanes = "auto"
+    AUTO_LANES_MAX_PIXELS = 16 * 320 * 320
+
+    def _lanes(self, x):
+        B = x.shape[0]
+        if self.batch_lanes == "auto":
+            return 2 if (B >= 2 and B * x.shape[-2] * x.shape[-1] <= self.AUTO_LANES_MAX_PIXELS) else 1
+        return max(1, min(int(self.batch_lanes), B))
 
     def _lane_streams(self, device, n):
         key = (device.index if device.index is not None else torch.cuda.current_device(), n)
@@ -341,7 +351,7 @@ class DRUNet(Denoiser):
 
     def _hip_forward(self, x, sigma_map):
         B = x.shape[0]
-        lanes = max(1, min(int(self.batch_lanes), B))
+        lanes = self._lanes(x)
         if lanes == 1:
             return self._hip_forward_lane(x, sigma_map)
         dev = x.device
