@@ -286,10 +286,11 @@ class DRUNet(Denoiser):
         F(2x2,3x3) kernel, else the direct MFMA kernel"""
         if (pk[5] is not None and K.FP32_WINOGRAD_TILE == 4 and g.height % 4 == 0 and g.width % 4 == 0
                 and -(-g.batch * (g.height // 4) * (g.width // 4) // 32) * (pk[0][2] // 64) >= K.WINOGRAD4_MIN_TILES):
+            wsp = K.winograd4_workspace(x.device) if self._tail_split else None
             if pk[6] is not None:       # (K.FP32_WINOGRAD4_BF16X3 when the packs were built)
-                K.conv3x3_winograd4_bf16x3(g, x, pk[6], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=K.winograd4_workspace(x.device))
+                K.conv3x3_winograd4_bf16x3(g, x, pk[6], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=wsp)
             else:
-                K.conv3x3_winograd4(g, x, pk[5], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=K.winograd4_workspace(x.device))
+                K.conv3x3_winograd4(g, x, pk[5], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=wsp)
             return
         if pk[2] is not None:
             K.conv3x3_winograd(g, x, pk[2], pk[0][1], pk[0][2], y, res1=res1, relu=relu)
@@ -328,16 +329,19 @@ class DRUNet(Denoiser):
     # of the chip idles: with two lanes the other lane's launch fills the units as they fall idle, and the lanes' epilogues (the
     # HBM bursts of a launch) no longer coincide.  1 = one launch sequence (default).  Results do not depend on it (every unit is
     # computed by the same instruction sequence; only the tile a unit shares with a neighbour of the batch changes).
-    # "auto": two lanes while the whole batch is at most 16 slices of 320 x 320 (measured on MI355X, cfg2, graph replay, ms per
-    # 50-iteration step with 1 / 2 lanes: 4 slices 327 / 311, 8 slices 602 / 538, 16 slices 1081 / 1060, 32 slices 2013 / 2039 - at
-    # 32 slices a launch has 25 full rounds and the package is at its power limit: nothing idles that a second lane could use).
+    # "auto" = two lanes for every batch of at least two units.  Measured on MI355X (cfg2, graph replay, ms per 50-iteration step;
+    # one lane with the channel split of the last round / two lanes with it / two lanes without it): 4 slices 327 / 311 / 304,
+    # 8 slices 602 / 538 / 513, 16 slices 1081 / 1060 / 987, 32 slices 2013 / 2039 / 1952 (profiles/r06_lanes.jsonl).  With a second
+    # lane filling the idle units, cutting the last round's tiles along the input channels (csrc/drunet_wino4.hip: partial outputs
+    # through a workspace, a ticket, the last part adds them) only costs - the lanes run the F(4x4) launches WITHOUT it, and a
+    # unit's result then does not depend on the batch it is computed in at all (no summation order depends on the tile round).
     batch_lanes = "auto"
-    AUTO_LANES_MAX_PIXELS = 16 * 320 * 320
+    _tail_split = True
 
     def _lanes(self, x):
         B = x.shape[0]
         if self.batch_lanes == "auto":
-            return 2 if (B >= 2 and B * x.shape[-2] * x.shape[-1] <= self.AUTO_LANES_MAX_PIXELS) else 1
+            return 2 if B >= 2 else 1
         return max(1, min(int(self.batch_lanes), B))
 
     def _lane_streams(self, device, n):
@@ -368,7 +372,11 @@ class DRUNet(Denoiser):
                 sg = sg.reshape(B, *sg.shape[1:])[b0:b1] if sg.shape[0] == B else sg
             s.wait_stream(cur)
             with torch.cuda.stream(s):
-                self._hip_forward_lane(x[b0:b1], sg, lane=i, out=y[b0:b1])
+                self._tail_split = False        # (see batch_lanes: the other lane fills the last round)
+                try:
+                    self._hip_forward_lane(x[b0:b1], sg, lane=i, out=y[b0:b1])
+                finally:
+                    self._tail_split = True
             b0 = b1
         for s in streams:
             cur.wait_stream(s)
