@@ -21,7 +21,7 @@ _declared = False
 # ResBlock convolutions take (4: csrc/drunet_wino4.hip, 2: csrc/drunet_wino.hip) and the fewest workgroup tiles (64 couts x
 # 32 tile positions) a launch must have for the F(4x4,3x3) kernel (one persistent workgroup per CU: 256 on MI355X)
 FP32_WINOGRAD_TILE = 4
-WINOGRAD4_MIN_TILES = 64
+WINOGRAD4_MIN_TILES = 32
 # True: the F(4x4,3x3) launches of the fp32 setting evaluate their multiplies as a three-part bf16 split, six products on the bf16
 # matrix cores (dinv_conv3x3_winograd4_bf16x3: same per-layer accuracy, 3/8 of the matrix-pipe time).  Off by default: sustained,
 # the package power limit makes the two forms equally fast at every batch (scripts/r05/bf16x3_e2e.py)

@@ -97,6 +97,16 @@ def run_four_windows(net, x, field=32):
     return out
 
 
+_CUS: dict = {}
+
+
+def _compute_units(device) -> int:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CUS:
+        _CUS[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count) if device.type == "cuda" else 256
+    return _CUS[idx]
+
+
 class DRUNet(Denoiser):
     def __init__(self, in_channels=3, out_channels=3, nc=(64, 128, 256, 512), nb=4, act_mode="R",
                  downsample_mode="strideconv", upsample_mode="convtranspose", pretrained=None,
@@ -286,7 +296,11 @@ class DRUNet(Denoiser):
         F(2x2,3x3) kernel, else the direct MFMA kernel"""
         if (pk[5] is not None and K.FP32_WINOGRAD_TILE == 4 and g.height % 4 == 0 and g.width % 4 == 0
                 and -(-g.batch * (g.height // 4) * (g.width // 4) // 32) * (pk[0][2] // 64) >= K.WINOGRAD4_MIN_TILES):
-            wsp = K.winograd4_workspace(x.device) if self._tail_split else None
+            # inside a batch lane the last, incomplete round of tiles is left to the other lane (see batch_lanes) - unless the
+            # WHOLE launch is less than one round (fewer tiles than compute units: the deep levels of a small lane), where cutting
+            # the tiles along the input channels is what fills the chip
+            tiles = -(-g.batch * (g.height // 4) * (g.width // 4) // 32) * (pk[0][2] // 64)
+            wsp = K.winograd4_workspace(x.device) if (self._tail_split or tiles < _compute_units(x.device)) else None
             if pk[6] is not None:       # (K.FP32_WINOGRAD4_BF16X3 when the packs were built)
                 K.conv3x3_winograd4_bf16x3(g, x, pk[6], pk[0][1], pk[0][2], y, res1=res1, relu=relu, workspace=wsp)
             else:

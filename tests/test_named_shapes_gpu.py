@@ -358,9 +358,7 @@ def full_length_cfg5(dinv, dev, d, B=16, precisions=None, runs=1):
         assert torch.equal(sampler.seq.cpu(), d["seq"])
         for _ in range(runs):       # (the last run is the one timed and compared: the first also packs weights and allocates)
             trace = []
-            hook = den.register_forward_hook(
-                (lambda m, i, o: trace.append(torch.stack([u.detach().reshape(-1)[::stt] for u in o]))) if images is not None else
-                (lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt])))
+            hook = den.register_forward_hook(lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt]))
             # the Gaussian draws of the whole run, made BEFORE the timed region (unit 0 replays the reference's generator stream,
             # the rest of the shard has its own): resident in HBM like every other input
             g0, g1 = gen(74), gen(704)
