@@ -354,6 +354,8 @@ class DRUNet(Denoiser):
 
     def _lanes(self, x):
         B = x.shape[0]
+        if not x.is_cuda and x.device.type != "meta":     # (host emulation of the kernels, tests/emu_backend.py: no streams)
+            return 1
         if self.batch_lanes == "auto":
             return 2 if B >= 2 else 1
         return max(1, min(int(self.batch_lanes), B))
