@@ -24,6 +24,9 @@ import os
 import sys
 import time
 
+# (deepinv_amd sets the same default at import; bench.py touches the device before it imports the package)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # hardware queues for the streams of the batch lanes beside RCCL's: deepinv_amd/__init__.py
+
 import torch
 import torch.distributed as dist
 
@@ -119,6 +122,10 @@ def main():
     if args.bf16x3:
         K.FP32_WINOGRAD4_BF16X3 = True
     lanes = denoiser._lanes(torch.empty(B_local, 2, H, W, device="meta"))
+    if lanes > 1:
+        from deepinv_amd.hip import lane_streams
+        if lane_streams(device, lanes) is None:     # no pair of streams that overlaps on this device: the model runs one lane
+            lanes = 1
     model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(denoiser), stepsize=1.0, g_param=0.05,
                            max_iter=args.iters, early_stop=False)
     # The PGD iteration as a replayed HIP graph (optim/fixed_point.py: use_graph - one host call per iteration instead of ~80 launches):

@@ -205,3 +205,62 @@ def fft_plan_host_table(n: int) -> torch.Tensor:
         check(l.dinv_fft_plan_init(int(n), ctypes.byref(plan), ctypes.c_void_p(host.data_ptr())))
         _plan_host[int(n)] = host
     return _plan_host[int(n)]
+
+
+# --------------------------------------------------------------------------- batch lanes
+_LANE_STREAMS: dict = {}
+
+
+def _streams_overlap(a, b, device) -> bool:
+    """do kernels on streams a and b run CONCURRENTLY?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+    default); two streams that share a queue execute one after the other - measured: two batch lanes on one queue take 400 ms where
+    one lane takes 327 and two real lanes 302 (profiles/r06_lanes_hw_queues.txt).  Probe: a spin kernel of ~0.1 ms on each stream;
+    on separate queues the pair ends after ~one kernel time, on a shared queue after two."""
+    sleep = getattr(torch.cuda, "_sleep", None)
+    if sleep is None:
+        return True
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    cycles = 250_000
+    torch.cuda.synchronize(device)
+    with torch.cuda.stream(a):
+        ev[0].record()
+        sleep(cycles)
+        ev[1].record()
+    with torch.cuda.stream(b):
+        sleep(cycles)
+        ev[2].record()
+    torch.cuda.synchronize(device)
+    one, both = ev[0].elapsed_time(ev[1]), ev[0].elapsed_time(ev[2])
+    return both < 1.6 * one
+
+
+def lane_streams(device, n: int):
+    """The HIP streams on which independent parts of a batch run concurrently (models/drunet.py: DRUNet.batch_lanes): ONE set per
+    (device, n) for the whole process, chosen from PyTorch's stream pool so that every pair really overlaps on the device (see
+    _streams_overlap; the package also raises GPU_MAX_HW_QUEUES to 8 at import, which makes the first candidates pass).  None when no
+    such set is found (or while a HIP graph is being captured before the set exists): the caller then runs one lane."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(n))
+    if key in _LANE_STREAMS:
+        return _LANE_STREAMS[key]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    chosen, tries = [], 0
+    while len(chosen) < n and tries < 4 * n + 8:
+        cand = torch.cuda.Stream(device)
+        tries += 1
+        if all(_streams_overlap(c, cand, device) for c in chosen):
+            chosen.append(cand)
+    _LANE_STREAMS[key] = chosen if len(chosen) == n else None
+    return _LANE_STREAMS[key]
+
+
+def split_batch(B: int, n: int):
+    """n contiguous slabs (start, stop) of a batch of B units, sizes differing by at most one"""
+    q, r = divmod(B, n)
+    out, b0 = [], 0
+    for i in range(n):
+        b1 = b0 + q + (1 if i < r else 0)
+        out.append((b0, b1))
+        b0 = b1
+    return out

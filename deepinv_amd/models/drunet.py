@@ -361,28 +361,23 @@ class DRUNet(Denoiser):
         return max(1, min(int(self.batch_lanes), B))
 
     def _lane_streams(self, device, n):
-        key = (device.index if device.index is not None else torch.cuda.current_device(), n)
-        pool = getattr(self, "_lane_pool", None)
-        if pool is None:
-            pool = self._lane_pool = {}
-        if key not in pool:
-            pool[key] = [torch.cuda.Stream(device) for _ in range(n)]
-        return pool[key]
+        """the process-wide lane streams (hip.lane_streams): a module keeps no stream objects - it stays deep-copyable"""
+        from ..hip import lane_streams
+        return lane_streams(device, n)
 
     def _hip_forward(self, x, sigma_map):
+        from ..hip import split_batch
+
         B = x.shape[0]
         lanes = self._lanes(x)
-        if lanes == 1:
+        streams = self._lane_streams(x.device, lanes) if lanes > 1 else None
+        if streams is None:         # one lane, or no set of streams that overlap on this device (hip.lane_streams)
             return self._hip_forward_lane(x, sigma_map)
         dev = x.device
         x = x.contiguous().float()
         y = torch.empty((B, self.out_channels, *x.shape[2:]), device=dev, dtype=torch.float32)
         cur = torch.cuda.current_stream(dev)
-        streams = self._lane_streams(dev, lanes)
-        q, r = divmod(B, lanes)
-        b0 = 0
-        for i, s in enumerate(streams):
-            b1 = b0 + q + (1 if i < r else 0)
+        for i, (s, (b0, b1)) in enumerate(zip(streams, split_batch(B, lanes))):
             sg = sigma_map
             if isinstance(sg, torch.Tensor) and sg.numel() > 1:      # one value per sample, or a map: this lane's units
                 sg = sg.reshape(B, *sg.shape[1:])[b0:b1] if sg.shape[0] == B else sg
@@ -393,7 +388,6 @@ class DRUNet(Denoiser):
                     self._hip_forward_lane(x[b0:b1], sg, lane=i, out=y[b0:b1])
                 finally:
                     self._tail_split = True
-            b0 = b1
         for s in streams:
             cur.wait_stream(s)
         return y

@@ -484,3 +484,24 @@ def test_drunet_batch_lanes_equal_one_launch_sequence(dev, B, lanes):
     torch.cuda.synchronize()
     assert float((eager - ref).norm() / ref.norm()) < 1e-5
     assert float((replay - ref).norm() / ref.norm()) < 1e-5 and torch.equal(replay, replay2)
+    import copy
+    twin = copy.deepcopy(den)                      # a model that has run lanes stays deep-copyable (no stream objects inside)
+    assert torch.equal(twin(x, 0.05), den(x, 0.05))
+
+
+def test_lane_streams_overlap_or_are_refused(dev):
+    """hip.lane_streams: the streams handed to the batch lanes really run concurrently (two spin kernels end in about one kernel
+    time), also when the process holds many other streams; a set that cannot overlap is refused (None -> one lane)"""
+    import deepinv_amd.hip as H
+
+    others = [torch.cuda.Stream(dev) for _ in range(9)]          # a process with plenty of streams of its own
+    for s in others:
+        with torch.cuda.stream(s):
+            torch.zeros(8, device=dev)
+    H._LANE_STREAMS.clear()
+    st = H.lane_streams(dev, 2)
+    assert st is None or (len(st) == 2 and H._streams_overlap(st[0], st[1], dev))
+    assert H.lane_streams(dev, 2) is st                           # cached: one set per process
+    assert st is not None, "GPU_MAX_HW_QUEUES=8 (deepinv_amd/__init__.py) should leave room for two concurrent lanes"
+    same = torch.cuda.Stream(dev)
+    assert not H._streams_overlap(same, same, dev)                # the probe does detect serialisation
