@@ -121,11 +121,7 @@ def main():
         K.WINOGRAD4_TAIL_SPLIT = False
     if args.bf16x3:
         K.FP32_WINOGRAD4_BF16X3 = True
-    lanes = denoiser._lanes(torch.empty(B_local, 2, H, W, device="meta"))
-    if lanes > 1:
-        from deepinv_amd.hip import lane_streams
-        if lane_streams(device, lanes) is None:     # no pair of streams that overlaps on this device: the model runs one lane
-            lanes = 1
+    lanes_asked = denoiser._lanes(torch.empty(B_local, 2, H, W, device="meta"))
     model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(denoiser), stepsize=1.0, g_param=0.05,
                            max_iter=args.iters, early_stop=False)
     # The PGD iteration as a replayed HIP graph (optim/fixed_point.py: use_graph - one host call per iteration instead of ~80 launches):
@@ -288,6 +284,8 @@ def main():
         # `direct_equiv` / `frac_direct_equiv` (that one can exceed 1 and is not a fraction of any roofline).
         # batch lanes > 1: the launches of the lanes run CONCURRENTLY (each on the compute units the other leaves idle), so the HIP-event
         # durations of the launches overlap in time; the time the kernel family occupies the chip is their sum / lanes
+        from deepinv_amd import hip as HIP
+        lanes = lanes_asked if (lanes_asked > 1 and HIP._LANE_STREAMS.get(HIP.lane_key(device, lanes_asked)) is not None) else 1
         kms = kp["ms"] / lanes if kp else 0.0
         achieved = kp["direct_flops"] / (kms * 1e-3) if kp else 0.0
         executed = kp["mfma_flops"] / (kms * 1e-3) if kp else 0.0
@@ -341,7 +339,7 @@ def main():
                                    "DRUNet(2->2, random init), global batch %d" % args.batch,
                        "global_batch": args.batch, "per_gpu_batch": B_local, "iters": args.iters,
                        "parallelism": f"dp{world}", "collective": "all_gather(reconstruction)" if multi else "none",
-                       "conv_precision": "fp32", "batch_lanes": lanes, "loop_graph": graph_state["on"], "loop_graph_error": graph_state["error"],
+                       "conv_precision": "fp32", "batch_lanes": lanes, "batch_lanes_calibration": getattr(denoiser, "_lane_calibration", None), "loop_graph": graph_state["on"], "loop_graph_error": graph_state["error"],
                        **({"as_multi_preflight": True, "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}}
                           if args.as_multi else {})},
             "roofline": {"bound": "mfma", "kernel": f"{kname} ({kdesc})",

@@ -208,51 +208,18 @@ def fft_plan_host_table(n: int) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- batch lanes
+# (device index, n) -> the n HIP streams on which independent parts of a batch run concurrently, or None when concurrent lanes were
+# measured NOT to pay on this device in this process (models/drunet.py: DRUNet._calibrated_lane_streams decides, once).  One set per
+# process: HIP multiplexes the streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default; this package asks
+# for 8 at import), and two lanes whose streams share a queue run one after the other - 400 ms per step at 4 slices where one
+# lane takes 327 and two overlapping lanes 302 (profiles/r06_lanes_hw_queues.txt).  Which streams share a queue depends on what
+# else the process created before (RCCL, graph capture, user code), so the choice is made by timing the real launch sequence.
 _LANE_STREAMS: dict = {}
 
 
-def _streams_overlap(a, b, device) -> bool:
-    """do kernels on streams a and b run CONCURRENTLY?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
-    default); two streams that share a queue execute one after the other - measured: two batch lanes on one queue take 400 ms where
-    one lane takes 327 and two real lanes 302 (profiles/r06_lanes_hw_queues.txt).  Probe: a spin kernel of ~0.1 ms on each stream;
-    on separate queues the pair ends after ~one kernel time, on a shared queue after two."""
-    sleep = getattr(torch.cuda, "_sleep", None)
-    if sleep is None:
-        return True
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    cycles = 250_000
-    torch.cuda.synchronize(device)
-    with torch.cuda.stream(a):
-        ev[0].record()
-        sleep(cycles)
-        ev[1].record()
-    with torch.cuda.stream(b):
-        sleep(cycles)
-        ev[2].record()
-    torch.cuda.synchronize(device)
-    one, both = ev[0].elapsed_time(ev[1]), ev[0].elapsed_time(ev[2])
-    return both < 1.6 * one
-
-
-def lane_streams(device, n: int):
-    """The HIP streams on which independent parts of a batch run concurrently (models/drunet.py: DRUNet.batch_lanes): ONE set per
-    (device, n) for the whole process, chosen from PyTorch's stream pool so that every pair really overlaps on the device (see
-    _streams_overlap; the package also raises GPU_MAX_HW_QUEUES to 8 at import, which makes the first candidates pass).  None when no
-    such set is found (or while a HIP graph is being captured before the set exists): the caller then runs one lane."""
+def lane_key(device, n: int):
     device = torch.device(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(n))
-    if key in _LANE_STREAMS:
-        return _LANE_STREAMS[key]
-    if torch.cuda.is_current_stream_capturing():
-        return None
-    chosen, tries = [], 0
-    while len(chosen) < n and tries < 4 * n + 8:
-        cand = torch.cuda.Stream(device)
-        tries += 1
-        if all(_streams_overlap(c, cand, device) for c in chosen):
-            chosen.append(cand)
-    _LANE_STREAMS[key] = chosen if len(chosen) == n else None
-    return _LANE_STREAMS[key]
+    return (device.index if device.index is not None else torch.cuda.current_device(), int(n))
 
 
 def split_batch(B: int, n: int):

@@ -350,34 +350,28 @@ class DRUNet(Denoiser):
     # through a workspace, a ticket, the last part adds them) only costs - the lanes run the F(4x4) launches WITHOUT it, and a
     # unit's result then does not depend on the batch it is computed in at all (no summation order depends on the tile round).
     batch_lanes = "auto"
+    LANES_MIN_PIXELS = 4 * 128 * 128
     _tail_split = True
 
     def _lanes(self, x):
         B = x.shape[0]
         if not x.is_cuda and x.device.type != "meta":     # (host emulation of the kernels, tests/emu_backend.py: no streams)
             return 1
+        if B * x.shape[-2] * x.shape[-1] < self.LANES_MIN_PIXELS:      # launches of a few tiles: nothing to fill, nothing to time
+            return 1
         if self.batch_lanes == "auto":
             return 2 if B >= 2 else 1
         return max(1, min(int(self.batch_lanes), B))
 
-    def _lane_streams(self, device, n):
-        """the process-wide lane streams (hip.lane_streams): a module keeps no stream objects - it stays deep-copyable"""
-        from ..hip import lane_streams
-        return lane_streams(device, n)
-
-    def _hip_forward(self, x, sigma_map):
+    def _run_lanes(self, x, sigma_map, streams):
+        """the batch lanes of one call on the given streams (one contiguous part of the batch each); the current stream waits for
+        all of them"""
         from ..hip import split_batch
 
-        B = x.shape[0]
-        lanes = self._lanes(x)
-        streams = self._lane_streams(x.device, lanes) if lanes > 1 else None
-        if streams is None:         # one lane, or no set of streams that overlap on this device (hip.lane_streams)
-            return self._hip_forward_lane(x, sigma_map)
-        dev = x.device
-        x = x.contiguous().float()
+        B, dev = x.shape[0], x.device
         y = torch.empty((B, self.out_channels, *x.shape[2:]), device=dev, dtype=torch.float32)
         cur = torch.cuda.current_stream(dev)
-        for i, (s, (b0, b1)) in enumerate(zip(streams, split_batch(B, lanes))):
+        for i, (s, (b0, b1)) in enumerate(zip(streams, split_batch(B, len(streams)))):
             sg = sigma_map
             if isinstance(sg, torch.Tensor) and sg.numel() > 1:      # one value per sample, or a map: this lane's units
                 sg = sg.reshape(B, *sg.shape[1:])[b0:b1] if sg.shape[0] == B else sg
@@ -391,6 +385,54 @@ class DRUNet(Denoiser):
         for s in streams:
             cur.wait_stream(s)
         return y
+
+    def _calibrated_lane_streams(self, x, sigma_map, lanes):
+        """The streams of the lanes on this device - decided ONCE per process and (device, lanes) by timing this very call: one launch
+        sequence against `lanes` concurrent ones, on up to four candidate stream sets from PyTorch's pool.  Two lanes whose streams
+        landed on one hardware queue run one after the other and lose (hip/__init__.py: _LANE_STREAMS); such a set is passed over,
+        and when no set is at least as fast as the single sequence the lanes are switched off for the process (None).  Not decided
+        while a HIP graph is being captured (no timing there): one lane until an eager call has calibrated."""
+        from .. import hip as H
+
+        key = H.lane_key(x.device, lanes)
+        if key in H._LANE_STREAMS:
+            return H._LANE_STREAMS[key]
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        dev = x.device
+
+        def gpu_ms(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+
+        self._hip_forward_lane(x, sigma_map)                    # packs the weights, creates the buffers
+        t_one = min(gpu_ms(lambda: self._hip_forward_lane(x, sigma_map)) for _ in range(2))
+        best = None
+        for attempt in range(4):
+            cand = [torch.cuda.Stream(dev) for _ in range(lanes)]
+            self._run_lanes(x, sigma_map, cand)                 # (the lanes' own buffers)
+            t = min(gpu_ms(lambda: self._run_lanes(x, sigma_map, cand)) for _ in range(2))
+            if t <= 1.03 * t_one and (best is None or t < best[0]):
+                best = (t, cand)
+            if best is not None and (attempt >= 1 or t < 0.9 * t_one):
+                break
+        H._LANE_STREAMS[key] = best[1] if best is not None else None
+        self._lane_calibration = {"one_sequence_ms": round(t_one, 3), "lanes_ms": None if best is None else round(best[0], 3),
+                                  "lanes": lanes, "attempts": attempt + 1, "batch": int(x.shape[0])}
+        return H._LANE_STREAMS[key]
+
+    def _hip_forward(self, x, sigma_map):
+        lanes = self._lanes(x)
+        if lanes > 1:
+            x = x.contiguous().float()
+            streams = self._calibrated_lane_streams(x, sigma_map, lanes)
+            if streams is not None:
+                return self._run_lanes(x, sigma_map, streams)
+        return self._hip_forward_lane(x, sigma_map)
 
     def _hip_forward_lane(self, x, sigma_map, lane=0, out=None):
         """forward_unet (drunet.py:200-210) as 64 conv launches + pack/unpack."""

@@ -459,17 +459,20 @@ def test_drunet_batch_lanes_equal_one_launch_sequence(dev, B, lanes):
     g = torch.Generator().manual_seed(B)
     den = dinv.models.DRUNet(2, 2, pretrained=None).to(dev).eval()
     den.load_state_dict(OD.init_state_dict(2, 2, seed=3))
-    x = torch.rand(B, 2, 64, 96, generator=g).to(dev)
-    for sigma in (0.05, torch.linspace(0.02, 0.1, B).to(dev), (0.02 + 0.1 * torch.rand(B, 1, 64, 96, generator=g)).to(dev)):
-        den.batch_lanes = 1
-        ref = den(x, sigma)
-        den.batch_lanes = lanes
-        out = den(x, sigma)
+    x = torch.rand(B, 2, 128, 160, generator=g).to(dev)
+    import deepinv_amd.hip as H
+    for sigma in (0.05, torch.linspace(0.02, 0.1, B).to(dev), (0.02 + 0.1 * torch.rand(B, 1, 128, 160, generator=g)).to(dev)):
+        with torch.no_grad():       # (the inference engine; with gradients the training node runs)
+            den.batch_lanes = 1
+            ref = den(x, sigma)
+            den.batch_lanes = lanes
+            out = den(x, sigma)
+        assert H.lane_key(dev, lanes) in H._LANE_STREAMS           # the lanes were calibrated (and, if they pay, ran)
         assert float((out - ref).norm() / ref.norm()) < 1e-5
     # inside the loop, eager and replayed
-    maps = torch.randn(1, 4, 64, 96, dtype=torch.complex64, generator=g) / 2
-    mask = (torch.rand(64, 96, generator=g) > 0.6).float()
-    phys = dinv.physics.MultiCoilMRI(mask=mask.to(dev), coil_maps=maps.to(dev), img_size=(2, 64, 96), device=dev)
+    maps = torch.randn(1, 4, 128, 160, dtype=torch.complex64, generator=g) / 2
+    mask = (torch.rand(128, 160, generator=g) > 0.6).float()
+    phys = dinv.physics.MultiCoilMRI(mask=mask.to(dev), coil_maps=maps.to(dev), img_size=(2, 128, 160), device=dev)
     y = phys.A(x)
     model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=1.0, g_param=0.05, max_iter=5,
                            early_stop=False)
@@ -486,22 +489,46 @@ def test_drunet_batch_lanes_equal_one_launch_sequence(dev, B, lanes):
     assert float((replay - ref).norm() / ref.norm()) < 1e-5 and torch.equal(replay, replay2)
     import copy
     twin = copy.deepcopy(den)                      # a model that has run lanes stays deep-copyable (no stream objects inside)
-    assert torch.equal(twin(x, 0.05), den(x, 0.05))
+    with torch.no_grad():
+        assert torch.equal(twin(x, 0.05), den(x, 0.05))
 
 
-def test_lane_streams_overlap_or_are_refused(dev):
-    """hip.lane_streams: the streams handed to the batch lanes really run concurrently (two spin kernels end in about one kernel
-    time), also when the process holds many other streams; a set that cannot overlap is refused (None -> one lane)"""
+def test_lane_streams_are_calibrated_by_timing(dev):
+    """DRUNet._calibrated_lane_streams: the streams of the batch lanes are chosen once per process by timing the real launch
+    sequence (two lanes on one HIP hardware queue run one after the other and lose); the decision is cached per device, a set that
+    loses is refused (None -> one lane), and a process with many other streams still finds a pair that overlaps"""
+    import deepinv_amd as dinv
     import deepinv_amd.hip as H
+    from oracle import drunet_cpu as OD
 
     others = [torch.cuda.Stream(dev) for _ in range(9)]          # a process with plenty of streams of its own
     for s in others:
         with torch.cuda.stream(s):
             torch.zeros(8, device=dev)
-    H._LANE_STREAMS.clear()
-    st = H.lane_streams(dev, 2)
-    assert st is None or (len(st) == 2 and H._streams_overlap(st[0], st[1], dev))
-    assert H.lane_streams(dev, 2) is st                           # cached: one set per process
-    assert st is not None, "GPU_MAX_HW_QUEUES=8 (deepinv_amd/__init__.py) should leave room for two concurrent lanes"
-    same = torch.cuda.Stream(dev)
-    assert not H._streams_overlap(same, same, dev)                # the probe does detect serialisation
+    den = dinv.models.DRUNet(2, 2, pretrained=None).to(dev).eval()
+    den.load_state_dict(OD.init_state_dict(2, 2, seed=3))
+    x = torch.rand(8, 2, 320, 320, generator=torch.Generator().manual_seed(1)).to(dev)
+    saved = dict(H._LANE_STREAMS)
+    try:
+        H._LANE_STREAMS.clear()
+        with torch.no_grad():
+            den.batch_lanes = 1
+            ref = den(x, 0.05)
+            den.batch_lanes = 2
+            out = den(x, 0.05)
+        key = H.lane_key(dev, 2)
+        assert key in H._LANE_STREAMS                              # decided, cached
+        cal = den._lane_calibration
+        print("lane calibration:", cal)
+        assert float((out - ref).norm() / ref.norm()) < 1e-5
+        st = H._LANE_STREAMS[key]
+        # at 8 slices of 320 x 320 two overlapping lanes are 10-15 % faster than one sequence: with GPU_MAX_HW_QUEUES = 8 (set by the
+        # package at import) a pair that overlaps is found
+        assert st is not None and len(st) == 2 and cal["lanes_ms"] < cal["one_sequence_ms"]
+        assert den._calibrated_lane_streams(x, 0.05, 2) is st      # no second calibration
+        H._LANE_STREAMS[key] = None                                # a refused set: one lane, same result
+        with torch.no_grad():
+            assert torch.equal(den(x, 0.05), ref)
+    finally:
+        H._LANE_STREAMS.clear()
+        H._LANE_STREAMS.update(saved)
