@@ -20,6 +20,9 @@ for _, s, e in rows:
 if cur_e is not None:
     union += cur_e - cur_s
 union /= 1e6
+big = [e - s for n, s, e in rows if not split.search(n) and e - s >= 0.3e6]
+print(f"# conv3x3_wino4_kernel, launches of at least 0.3 ms (the 16-slice lanes of the bench's 32-slice batch; the short ones are the 4-slice "
+      f"layer-error and 8-slice parity runs of the same process): {len(big)} calls, mean {sum(big) / max(len(big), 1) / 1e6:.4f} ms")
 print(f"# conv3x3_wino4_kernel: {len(rows)} launches = {calls} calls (tail-split launches counted into their call); sum of durations {total:.1f} ms "
       f"= mean {total / max(calls, 1):.4f} ms per call (to compare with roofline.avg_launch_ms); the launches of the two batch lanes overlap: "
       f"the kernel occupies the device for {union:.1f} ms = {union / max(calls, 1):.4f} ms per call (concurrency {total / max(union, 1e-9):.2f})")
