@@ -1,6 +1,9 @@
 import os
 import sys
 
+# (as deepinv_amd/__init__.py: the HIP runtime reads it when it initialises - `torch.cuda.is_available()` below comes first here)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import pytest
 import torch
 
