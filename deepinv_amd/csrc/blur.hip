@@ -17,6 +17,8 @@ using namespace dinv;
 
 namespace {
 
+constexpr int64_t kMaxGridZ = 65535;      // planes per launch (grid.y / grid.z limit)
+
 enum PadMode { PAD_VALID = 0, PAD_CIRCULAR = 1, PAD_REFLECT = 2, PAD_REPLICATE = 3, PAD_CONSTANT = 4 };
 
 struct ConvGeom {
@@ -339,6 +341,7 @@ struct ConvGeom3 {
     int32_t mode;
     int32_t pf, pt, pl, pk, pb, pr;   // pads front / top / left / back / bottom / right
     int32_t Do, Ho, Wo;
+    int32_t z0;                       // first (batch, channel, depth) plane of this launch: grids are cut at 65535 planes (grid.z)
 };
 
 // y[b,c,ko,io,jo] = sum_{t,u,v} kf[t,u,v] * xpad[ko+t, io+u, jo+v],  kf = k flipped along all three axes
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void conv3d_pad_kernel(ConvGeom3 g, const floa
                                                          float* __restrict__ y) {
     DINV_DYN_LDS(float, ks);
     const int nk = g.d * g.h * g.w;
-    const int z = blockIdx.z, bc = z / g.Do, ko = z - bc * g.Do, b = bc / g.C, c = bc % g.C;
+    const int z = blockIdx.z + g.z0, bc = z / g.Do, ko = z - bc * g.Do, b = bc / g.C, c = bc % g.C;
     const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * nk;
     for (int i = threadIdx.x; i < nk; i += 256) ks[i] = kf[nk - 1 - i];
     __syncthreads();
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256) void conv3d_pad_transpose_kernel(ConvGeom3 g, 
                                                                    const float* __restrict__ k, float* __restrict__ x) {
     DINV_DYN_LDS(float, ks);
     const int nk = g.d * g.h * g.w;
-    const int z = blockIdx.z, bc = z / g.D, dd = z - bc * g.D, b = bc / g.C, c = bc % g.C;
+    const int z = blockIdx.z + g.z0, bc = z / g.D, dd = z - bc * g.D, b = bc / g.C, c = bc % g.C;
     const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * nk;
     for (int i = threadIdx.x; i < nk; i += 256) ks[i] = kf[nk - 1 - i];
     __syncthreads();
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void conv3d_filter_grad_kernel(ConvGeom3 g, co
     __shared__ float red[4];
     const int nk = g.d * g.h * g.w;
     const int tap = blockIdx.x, t = tap / (g.h * g.w), uv = tap - t * g.h * g.w, u = uv / g.w, v = uv - u * g.w;
-    const int bc = blockIdx.y;
+    const int bc = blockIdx.y + g.z0;
     const float* vol = x + (int64_t)bc * g.D * g.H * g.W;
     const float* go = gy + (int64_t)bc * g.Do * g.Ho * g.Wo;
     float acc = 0.f;
@@ -464,7 +467,8 @@ int make_geom3(const dinv_conv3d_desc* d, ConvGeom3* g) {
         if (d->mode == PAD_REFLECT) DINV_REQUIRE(pd < d->depth && ph < d->height && pw < d->width, "reflect padding must be smaller than the volume");
         g->Do = d->depth; g->Ho = d->height; g->Wo = d->width;
     }
-    DINV_REQUIRE((int64_t)g->B * g->C * std::max(g->D, g->Do) <= 65535, "too many (batch * channel * depth) planes per call");
+    DINV_REQUIRE((int64_t)g->B * g->C * std::max(g->D, g->Do) < (1ll << 31), "too many (batch * channel * depth) planes per call");
+    g->z0 = 0;
     DINV_REQUIRE((size_t)g->d * g->h * g->w * sizeof(float) <= 64 * 1024, "filter too large for LDS");
     return 0;
 }
@@ -824,8 +828,11 @@ extern "C" int dinv_conv3d(const dinv_conv3d_desc* d, const float* x, const floa
     if (int e = make_geom3(d, &g)) return e;
     if (g.B == 0) return 0;
     DINV_REQUIRE(x && filter && y, "null pointer");
-    hipLaunchKernelGGL(conv3d_pad_kernel, dim3((g.Wo + 63) / 64, (g.Ho + 3) / 4, g.B * g.C * g.Do), dim3(256),
-                       g.d * g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, x, filter, y);
+    for (int64_t z0 = 0, nz = (int64_t)g.B * g.C * g.Do; z0 < nz; z0 += kMaxGridZ) {      // grid.z holds 65535 planes per launch
+        g.z0 = (int32_t)z0;
+        hipLaunchKernelGGL(conv3d_pad_kernel, dim3((g.Wo + 63) / 64, (g.Ho + 3) / 4, (unsigned)std::min<int64_t>(nz - z0, kMaxGridZ)), dim3(256),
+                           g.d * g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, x, filter, y);
+    }
     DINV_CHECK_LAUNCH();
     return 0;
 }
@@ -835,8 +842,11 @@ extern "C" int dinv_conv3d_transpose(const dinv_conv3d_desc* d, const float* y, 
     if (int e = make_geom3(d, &g)) return e;
     if (g.B == 0) return 0;
     DINV_REQUIRE(x && filter && y, "null pointer");
-    hipLaunchKernelGGL(conv3d_pad_transpose_kernel, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.B * g.C * g.D), dim3(256),
-                       g.d * g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y, filter, x);
+    for (int64_t z0 = 0, nz = (int64_t)g.B * g.C * g.D; z0 < nz; z0 += kMaxGridZ) {
+        g.z0 = (int32_t)z0;
+        hipLaunchKernelGGL(conv3d_pad_transpose_kernel, dim3((g.W + 63) / 64, (g.H + 3) / 4, (unsigned)std::min<int64_t>(nz - z0, kMaxGridZ)),
+                           dim3(256), g.d * g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y, filter, x);
+    }
     DINV_CHECK_LAUNCH();
     return 0;
 }
@@ -847,8 +857,11 @@ extern "C" int dinv_conv3d_filter_grad(const dinv_conv3d_desc* d, const float* x
     if (int e = make_geom3(d, &g)) return e;
     if (g.B == 0) return 0;
     DINV_REQUIRE(x && gy && dk_planes, "null pointer");
-    hipLaunchKernelGGL(conv3d_filter_grad_kernel, dim3(g.d * g.h * g.w, g.B * g.C), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       g, x, gy, dk_planes);
+    for (int64_t z0 = 0, nz = (int64_t)g.B * g.C; z0 < nz; z0 += kMaxGridZ) {
+        g.z0 = (int32_t)z0;
+        hipLaunchKernelGGL(conv3d_filter_grad_kernel, dim3(g.d * g.h * g.w, (unsigned)std::min<int64_t>(nz - z0, kMaxGridZ)), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), g, x, gy, dk_planes);
+    }
     DINV_CHECK_LAUNCH();
     return 0;
 }
