@@ -477,10 +477,12 @@ __device__ __forceinline__ float lane_next(float v) {     // value of lane + 1
 #endif
 }
 
-template <int COUT>
+// RB = output rows per wave: 8 where the launch has waves to spare (10 input rows per 8 output rows), 4 or 2 for small launches
+// (a 4-slice batch at RB = 8 is 960 waves for 1024 SIMDs - each walking 80 dependent row loads: 100 us where the two tensors
+// stream in 20)
+template <int COUT, int RB>
 __global__ __launch_bounds__(256) void tail3x3_shift_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ x2,
                                                             const float* __restrict__ w, float* __restrict__ y, int ncb, int sw) {
-    constexpr int RB = 8;
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * sw + lane;                                 // padded column of this lane
     const int rg = blockIdx.y * 4 + (threadIdx.x >> 6);                   // group of RB image rows (wave-uniform)
@@ -653,13 +655,20 @@ extern "C" int dinv_conv3x3_tail(const dinv_act_geom* g, const float* x, const f
     const Geom gg = make_geom(*g);
     if (g->batch <= 65535) {
         const int nstrip = (int)ceil_div(g->width, 62), sw = (int)ceil_div(g->width, nstrip);     // balanced strips of <= 62 columns
-        const dim3 rgrid((unsigned)nstrip, (unsigned)ceil_div(ceil_div(g->height, 8), 4), (unsigned)g->batch);
+        // rows per wave: the largest of 8, 4, 2 that still gives every SIMD of the chip about two waves
+        int rb = 8;
+        while (rb > 2 && (int64_t)nstrip * ceil_div(g->height, rb) * g->batch < 2048) rb >>= 1;
+        const dim3 rgrid((unsigned)nstrip, (unsigned)ceil_div(ceil_div(g->height, rb), 4), (unsigned)g->batch);
+#define DINV_TAIL(CO, RBV) hipLaunchKernelGGL((tail3x3_shift_kernel<CO, RBV>), rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw)
+#define DINV_TAIL_RB(CO) do { if (rb == 8) DINV_TAIL(CO, 8); else if (rb == 4) DINV_TAIL(CO, 4); else DINV_TAIL(CO, 2); } while (0)
         switch (cout) {
-            case 1: hipLaunchKernelGGL(tail3x3_shift_kernel<1>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw); break;
-            case 2: hipLaunchKernelGGL(tail3x3_shift_kernel<2>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw); break;
-            case 3: hipLaunchKernelGGL(tail3x3_shift_kernel<3>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw); break;
-            default: hipLaunchKernelGGL(tail3x3_shift_kernel<4>, rgrid, dim3(256), 0, st, gg, x, x2, w_tail, y, cin / 8, sw); break;
+            case 1: DINV_TAIL_RB(1); break;
+            case 2: DINV_TAIL_RB(2); break;
+            case 3: DINV_TAIL_RB(3); break;
+            default: DINV_TAIL_RB(4); break;
         }
+#undef DINV_TAIL_RB
+#undef DINV_TAIL
         DINV_CHECK_LAUNCH();
         return 0;
     }
