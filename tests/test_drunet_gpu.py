@@ -328,7 +328,7 @@ def test_winograd4_tail_split_two_streams(dev):
 @pytest.mark.parametrize("B,H,W,cin,cout,skip", [(2, 9, 21, 16, 2, True), (1, 19, 70, 8, 1, False), (1, 8, 130, 16, 3, True),
                                                  (3, 17, 62, 24, 4, True), (4, 320, 320, 64, 2, True), (1, 5, 63, 8, 2, False)])
 def test_tail_conv_lane_shift(dev, B, H, W, cin, cout, skip):
-    """dinv_conv3x3_tail (csrc/drunet.hip tail3x3_shift_kernel: one load per pixel and tensor, column taps through
+    """dinv_conv3x3_tail (csrc/drunet_tail.hip tail3x3_shift_kernel: one load per pixel and tensor, column taps through
     v_mov_b32_dpp wave_shr / wave_shl, 8 output rows per lane, strips of <= 62 columns per wave) against an fp64 conv2d of
     x (+ x2): one to six strips, ragged row groups, the bench shape; frame and spare channels of the output untouched"""
     from deepinv_amd.hip import drunet as K
@@ -354,6 +354,47 @@ def test_tail_conv_lane_shift(dev, B, H, W, cin, cout, skip):
     assert float(yv[0, :, 1:H + 1, 1:W + 1, 4:].min()) == 7.0 and float(yv[0, :, 0].min()) == 7.0
     assert float(yv[0, :, :, 0].min()) == 7.0 and float(yv[0, :, :, W + 1:].min()) == 7.0
     assert float(yv[0, :, H + 1:].min()) == 7.0
+
+
+@pytest.mark.parametrize("B,side,cout", [(8, 256, 1), (8, 256, 2), (8, 256, 3), (8, 256, 4), (32, 320, 2), (2, 320, 3)])
+def test_tail_conv_reproducible_beside_a_bf16_split_launch(dev, B, side, cout):
+    """The tail convolution on one stream while bf16-split convolutions (csrc/drunet_wsplit.hip) run on another - what the batch
+    lanes of models/drunet.py do - returns the bits it returns alone.  Built with SLP-packed fp32 ops it did not (60 of 60
+    launches: single terms dropped in lanes 48..63 of a wave, scripts/r06/race_hunt8.py / race_hunt11.py); csrc/Makefile builds
+    drunet_tail.hip without them.  Row groups of 8, 4 and 2 rows per wave (launch sizes 32, 8 and 2 slices)."""
+    from deepinv_amd.hip import drunet as K
+
+    gen = torch.Generator().manual_seed(cout)
+    geo, c = K.geom(B, side, side), 64
+
+    def act(fill=True):
+        a = K.alloc(geo, c, dev)
+        if fill:
+            t = torch.randn(B, c, side, side, generator=gen).to(dev)
+            a[:, geo.sl:geo.sl + geo.np].view(-1, B, geo.hp, geo.wp, 8)[:, :, 1:side + 1, 1:side + 1] = \
+                t.view(B, -1, 8, side, side).permute(1, 0, 3, 4, 2)
+        return a
+
+    xa, x2a, xb, rb, yb = act(), act(), act(), act(), act(False)
+    wt = K.pack_tail_weight((torch.randn(cout, c, 3, 3, generator=gen) / 24).to(dev))
+    wws = K.pack_wsplit_weight((torch.randn(c, c, 3, 3, generator=gen) / 24).to(dev))
+    yt = K.alloc(geo, cout, dev)
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        K.conv3x3_tail(geo, xa, wt, c, cout, yt, x2=x2a)
+    torch.cuda.synchronize()
+    alone = yt.clone()
+    for _ in range(20):
+        yt.zero_()
+        for s, n in ((sb, 2), (sa, 0), (sb, 2)):
+            with torch.cuda.stream(s):
+                for _ in range(n):
+                    K.conv3x3_wsplit(geo, xb, wws, c, c, yb, res1=rb)
+                if not n:
+                    K.conv3x3_tail(geo, xa, wt, c, cout, yt, x2=x2a)
+        torch.cuda.synchronize()
+        assert torch.equal(yt, alone)
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 24, 16, 64), (3, 40, 40, 64, 128), (1, 64, 64, 256, 512), (32, 80, 80, 128, 256)])

@@ -493,6 +493,37 @@ def test_drunet_batch_lanes_equal_one_launch_sequence(dev, B, lanes):
         assert torch.equal(twin(x, 0.05), den(x, 0.05))
 
 
+@pytest.mark.parametrize("precision", ["bf16split", "fp32"])
+def test_drunet_batch_lanes_are_reproducible(dev, precision):
+    """Two lanes overlap launches of DIFFERENT kernels (one lane's last layer beside the other's bf16-split convolutions ...):
+    thirty runs of the model under lanes return the same bits (and the two half-batches run one after the other, to 1e-5).  (Found
+    by the full-length cfg5 run: with the tail convolution built with packed fp32 ops, bf16-split runs differed by up to 1e-3
+    from one another - csrc/drunet_tail.hip.)"""
+    import deepinv_amd as dinv
+    import deepinv_amd.hip as H
+    from oracle import drunet_cpu as OD
+
+    den = dinv.models.DRUNet(3, 3, pretrained=None).to(dev).eval()
+    den.load_state_dict(OD.init_state_dict(3, 3, seed=5))
+    den.conv_precision = precision
+    x = torch.rand(16, 3, 256, 256, generator=torch.Generator().manual_seed(2)).to(dev)
+    key, saved = H.lane_key(dev, 2), dict(H._LANE_STREAMS)
+    try:
+        H._LANE_STREAMS[key] = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]      # lanes whatever the timing calibration says
+        with torch.no_grad():
+            den.batch_lanes = 1
+            ref = torch.cat((den(x[:8], 0.1), den(x[8:], 0.1)))
+            den.batch_lanes = 2
+            first = den(x, 0.1)
+            assert float((first - ref).norm() / ref.norm()) < 1e-5  # (the Winograd tail split regroups sums: not the same bits)
+            for it in range(30):
+                out = den(x, 0.1)
+                assert torch.equal(out, first), f"run {it}: max difference {float((out - first).abs().max()):.3e}"
+    finally:
+        H._LANE_STREAMS.clear()
+        H._LANE_STREAMS.update(saved)
+
+
 def test_lane_streams_are_calibrated_by_timing(dev):
     """DRUNet._calibrated_lane_streams: the streams of the batch lanes are chosen once per process by timing the real launch
     sequence (two lanes on one HIP hardware queue run one after the other and lose); the decision is cached per device, a set that
