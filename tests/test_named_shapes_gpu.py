@@ -283,7 +283,10 @@ def test_cfg3_fbp_pnp_hqs_full_length_30_iterations(dev):
         assert max(agree) < 3e-3, (prec, r["trace"], differ)
 
 
-def _assert_cfg3_run(res, d, n_differ=6):
+def _assert_cfg3_run(res, d, n_differ=8):
+    """A prox's CG count is where a float residual crosses the tolerance: it moves by one or two with the last bits of the iterate (the
+    fp32 and bf16-split settings of ONE run already disagree at a prox or two), so: at most `n_differ` of the 30 counts differ from the
+    reference's, none by more than 3, the total within 5 %; where the counts agree the denoiser inputs agree to 3e-3."""
     ref_counts = [int(v) for v in d["n_ata"]]
     for prec, r in res.items():
         assert r["finite"]
@@ -292,6 +295,7 @@ def _assert_cfg3_run(res, d, n_differ=6):
         assert len(r["ata_per_prox"]) == len(ref_counts) == len(r["trace"])
         differ = [i for i, (a, b) in enumerate(zip(r["ata_per_prox"], ref_counts)) if a != b]
         assert len(differ) <= n_differ, (prec, r["ata_per_prox"], ref_counts)
+        assert max(abs(a - b) for a, b in zip(r["ata_per_prox"], ref_counts)) <= 3, (prec, r["ata_per_prox"], ref_counts)
         assert abs(r["ata_calls"] - r["ata_calls_reference"]) <= 0.05 * r["ata_calls_reference"]
         agree = [e for i, e in enumerate(r["trace"]) if i not in differ]
         assert max(agree) < 3e-3, (prec, r["trace"], differ)
