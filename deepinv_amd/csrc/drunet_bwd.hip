@@ -36,6 +36,7 @@ struct WgradArgs {
     int32_t nparts;       // pixel slices per tile = workgroups per tile (each of the 4 waves takes a quarter of the slice)
     int64_t per_wave;     // pixels per wave (a multiple of 16)
     DepthMap dm;          // 3-D stride-2 layers: image of S (half grid) -> image of L (full grid)
+    int64_t l_step, part_step;   // blockIdx.y = depth tap of a 3x3x3 layer: L shifted by l_step floats per tap, its own partials
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     const int cm = m0 + lc, cn = n0 + lc;
     const bool mv = cm < a.cs_alloc, nv = cn < a.cl_alloc;
     const float* sp = a.s + ((int64_t)(mv ? cm / 8 : 0) * a.gs.cs + a.gs.sl) * 8 + (mv ? cm % 8 : 0);
-    const float* lp = a.l + ((int64_t)(nv ? cn / 8 : 0) * a.gl.cs + a.gl.sl) * 8 + (nv ? cn % 8 : 0);
+    const float* lp = a.l + (int64_t)blockIdx.y * a.l_step + ((int64_t)(nv ? cn / 8 : 0) * a.gl.cs + a.gl.sl) * 8 + (nv ? cn % 8 : 0);
     int64_t off[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
     // workgroup sum (waves in order) of TG taps at a time, then one partial tile per workgroup.
     // D[i][j] of lane l, register r:  32 x 32: j = l & 31, i = (r & 3) + 8 (r >> 2) + 4 (l >> 5);  16 x 16: j = l & 15, i = 4 (l >> 4) + r
-    float* out = a.part + (int64_t)part * a.M * a.N * T;
+    float* out = a.part + (int64_t)blockIdx.y * a.part_step + (int64_t)part * a.M * a.N * T;
     constexpr int RG = TG * NACC;                        // registers per lane per round
     for (int t0 = 0; t0 < T; t0 += TG) {
         if (t0) __syncthreads();
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradArgs a) {
         l_l[k] = (P + rp) * TILE + 4 * q;
     }
     const float* sbase = a.s + a.gs.sl * 8;
-    const float* lbase = a.l + a.gl.sl * 8;
+    const float* lbase = a.l + (int64_t)blockIdx.y * a.l_step + a.gl.sl * 8;
     float4 sr[SI], lr[LI];
     // chunk c -> registers.  S pixels past the end of the slice are redirected to pixel 0 of the buffer (the corner of the
     // first frame: zero in S like every frame pixel); L needs no guard (finite data in the slack, multiplied by S = 0)
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradArgs a) {
     }
     // workgroup sum (waves in order) of TG taps at a time, then one partial tile per workgroup (as in wgrad_kernel)
     float* red = lds;
-    float* out = a.part + (int64_t)part * a.M * a.N * T;
+    float* out = a.part + (int64_t)blockIdx.y * a.part_step + (int64_t)part * a.M * a.N * T;
     for (int t0 = 0; t0 < T; t0 += TG) {
         if (t0) __syncthreads();
 #pragma unroll
@@ -293,22 +294,25 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradArgs a) {
 }
 
 // dw[e] (+)= sum over slices in a fixed order: 16 lanes share an element (lane j adds slices j, j + 16, ... in order,
-// then the 16 partial sums are added in lane order), 16 elements per workgroup
+// then the 16 partial sums are added in lane order), 16 elements per workgroup.  blockIdx.y = depth tap z of nz: its own
+// partials, element (mn, t) lands at dw[mn][z][t]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int nsplit, int accumulate,
-                                                           float* __restrict__ dw) {
+                                                           float* __restrict__ dw, int64_t part_step, int taps) {
     __shared__ float red[16][17];
     const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int64_t e = (int64_t)blockIdx.x * 16 + el;
+    part += (int64_t)blockIdx.y * part_step;
     float v = 0.f;
     if (e < n)
         for (int s = grp; s < nsplit; s += 16) v += part[(int64_t)s * n + e];
     red[grp][el] = v;
     __syncthreads();
     if (grp == 0 && e < n) {
-        float t = accumulate ? dw[e] : 0.f;
+        const int64_t d = gridDim.y == 1 ? e : ((e / taps) * gridDim.y + blockIdx.y) * taps + e % taps;
+        float t = accumulate ? dw[d] : 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += red[j][el];
-        dw[e] = t;
+        dw[d] = t;
     }
 }
 
@@ -343,7 +347,7 @@ extern "C" size_t dinv_conv_wgrad_workspace_bytes(const dinv_act_geom* gs, int32
 
 static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m, const float* l, int32_t n,
                         int32_t taps, float* dw, int32_t accumulate, void* ws, size_t ws_bytes, DepthMap dm,
-                        dinv_stream_t stream) {
+                        dinv_stream_t stream, int ndepth = 1, int64_t l_step = 0) {
     if (int e = check_geom(gs)) return e;
     if (int e = check_geom(gl)) return e;
     DINV_REQUIRE(s && l && dw && ws, "null pointer");
@@ -358,7 +362,7 @@ static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const 
             DINV_REQUIRE(dm.dep_s >= 3 && dm.dep_l == 2 * (dm.dep_s - 2) + 2 && gs->batch % dm.dep_s == 0 && gl->batch % dm.dep_l == 0 &&
                          gs->batch / dm.dep_s == gl->batch / dm.dep_l && (dm.dz == 0 || dm.dz == 1), "2x2x2 weight gradient: bad depth pairing");
     }
-    DINV_REQUIRE(ws_bytes >= dinv_conv_wgrad_workspace_bytes(gs, m, n, taps), "workspace too small");
+    DINV_REQUIRE(ws_bytes >= ndepth * dinv_conv_wgrad_workspace_bytes(gs, m, n, taps), "workspace too small");
     DINV_REQUIRE(gs->np < (int64_t)1 << 31 && gl->np < (int64_t)1 << 31, "more than 2^31 padded pixels");
     WgradArgs a{};
     a.gs = make_geom(*gs); a.gl = make_geom(*gl);
@@ -370,8 +374,9 @@ static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const 
     a.nparts = part_count(gs, m, n);
     a.per_wave = (ceil_div(gs->np, (int64_t)4 * a.nparts) + 15) / 16 * 16;   // whole iterations of 4 k-steps (of 2 or 4 pixels)
     a.dm = dm;
+    a.l_step = l_step; a.part_step = (int64_t)a.nparts * m * n * taps;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)(a.mt * a.nt * a.nparts)), block(256);
+    const dim3 grid((unsigned)(a.mt * a.nt * a.nparts), (unsigned)ndepth), block(256);
     if (taps == 9) {
         DINV_REQUIRE((int64_t)(a.cs_alloc / 8 + 1) * gs->cs * 8 < ((int64_t)1 << 31) && (int64_t)(a.cl_alloc / 8 + 1) * gl->cs * 8 < ((int64_t)1 << 31),
                      "activation buffers too large for 32-bit staging offsets");
@@ -381,8 +386,8 @@ static int wgrad_launch(const dinv_act_geom* gs, const dinv_act_geom* gl, const 
     else hipLaunchKernelGGL((wgrad_kernel<4, true, 32>), grid, block, 0, st, a);
     DINV_CHECK_LAUNCH();
     const int64_t ne = (int64_t)m * n * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ne, 16)), dim3(256), 0, st, a.part, ne, a.nparts,
-                       accumulate, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(ne, 16), (unsigned)ndepth), dim3(256), 0, st, a.part, ne, a.nparts,
+                       accumulate, dw, a.part_step, taps);
     DINV_CHECK_LAUNCH();
     return 0;
 }
@@ -391,6 +396,13 @@ extern "C" int dinv_conv_wgrad(const dinv_act_geom* gs, const dinv_act_geom* gl,
                                const float* l, int32_t n, int32_t taps, float* dw, int32_t accumulate, void* ws,
                                size_t ws_bytes, dinv_stream_t stream) {
     return wgrad_launch(gs, gl, s, m, l, n, taps, dw, accumulate, ws, ws_bytes, DepthMap{0, 0, 0}, stream);
+}
+
+extern "C" int dinv_conv_wgrad_3x3x3(const dinv_act_geom* g, const float* s, int32_t m, const float* l, int32_t n,
+                                     int64_t depth_stride, float* dw, int32_t accumulate, void* ws, size_t ws_bytes,
+                                     dinv_stream_t stream) {
+    DINV_REQUIRE(depth_stride > 0, "bad depth stride %lld", (long long)depth_stride);
+    return wgrad_launch(g, g, s, m, l, n, 9, dw, accumulate, ws, ws_bytes, DepthMap{0, 0, 0}, stream, 3, depth_stride);
 }
 
 extern "C" int dinv_conv_wgrad_3d(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m,

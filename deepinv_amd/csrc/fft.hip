@@ -12,7 +12,7 @@ using namespace dinv;
 extern "C" const char* dinv_last_error(void) { return err_buf(); }
 // 1: round 1.  2: + dinv_mri_normal, tiled / fan-beam Radon, FFT ramp filter, bf16-split convolutions (3x3, 2x2 down / up,
 // 3-D slice pairing), convolution weight gradients, Philox noise / mask generators, masked CG updates.
-extern "C" int dinv_version(void) { return 8; }
+extern "C" int dinv_version(void) { return 9; }
 extern "C" int dinv_device_count(int* count) {
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);

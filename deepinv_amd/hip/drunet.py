@@ -63,6 +63,7 @@ def _l():
         l.dinv_conv_down2x2_bf16s_3d.argtypes = [G, G, vp, vp, i32, i32, vp, i32, i32, i32, vp]
         l.dinv_conv_up2x2_bf16s_3d.argtypes = [G, G, vp, vp, vp, i32, i32, vp, i32, i32, vp]
         l.dinv_conv_wgrad_3d.argtypes = [G, G, vp, i32, vp, i32, vp, i32, vp, ctypes.c_size_t, i32, i32, vp]
+        l.dinv_conv_wgrad_3x3x3.argtypes = [G, vp, i32, vp, i32, ctypes.c_int64, vp, i32, vp, ctypes.c_size_t, vp]
         l.dinv_conv_up2x2.argtypes = [G, G, vp, vp, vp, i32, i32, vp, vp]
         _declared = True
     return l
@@ -563,6 +564,16 @@ def conv_wgrad(gs, gl, s, m, l, n, taps, dw=None, accumulate=False):
     ws = torch.empty(_l().dinv_conv_wgrad_workspace_bytes(ctypes.byref(gs), m, n, taps), device=s.device, dtype=torch.uint8)
     check(_l().dinv_conv_wgrad(ctypes.byref(gs), ctypes.byref(gl), ptr(s), m, ptr(l), n, taps, ptr(dw), int(accumulate), ptr(ws),
                                ws.numel(), stream_ptr(s.device)))
+    return dw
+
+
+def conv_wgrad_3x3x3(g, s, m, l_first, n, depth_stride):
+    """[m, n, 3, 3, 3] weight gradient of a 3x3x3 layer in one call: the three depth taps are the second grid dimension of ONE launch
+    and of one reduction (csrc/drunet_bwd.hip: dinv_conv_wgrad_3x3x3); l_first = the layer input shifted by -1 slice"""
+    dw = torch.empty((m, n, 3, 3, 3), device=s.device, dtype=torch.float32)
+    ws = torch.empty(3 * _l().dinv_conv_wgrad_workspace_bytes(ctypes.byref(g), m, n, 9), device=s.device, dtype=torch.uint8)
+    check(_l().dinv_conv_wgrad_3x3x3(ctypes.byref(g), ptr(s), m, ptr(l_first), n, int(depth_stride), ptr(dw), 0, ptr(ws), ws.numel(),
+                                     stream_ptr(s.device)))
     return dw
 
 

@@ -40,10 +40,21 @@ def _r16(c):
 
 
 _POOL: dict = {}        # (device, channels, level shape) -> released activation buffers
-POOL_MAX_BYTES = 16 << 30      # cap of the free list (config 4's training step recycles about 6 GiB)
+POOL_MAX_BYTES = None          # cap of the free list; None = 40 % of the device's memory (config 4's training step holds ~45 GB of
+                               # activations for its backward pass: under the 16-GiB cap of rounds 3-5 sixty 655-MB buffers per step
+                               # fell off the list and were zero-filled again, 5 ms of the 154-ms step)
+_POOL_CAPS: dict = {}
 CHECK_RECYCLED = False         # debugging aid (the GPU test switches it on): verify the invariant below on every reuse
 _pool_bytes = 0
 _pool_sig = None               # (device, B, D, H, W) of the last call: another problem shape drops the whole list
+
+
+def _pool_cap(device):
+    if POOL_MAX_BYTES is not None:
+        return POOL_MAX_BYTES
+    if device not in _POOL_CAPS:
+        _POOL_CAPS[device] = int(0.4 * torch.cuda.get_device_properties(device).total_memory) if device.type == "cuda" else 16 << 30
+    return _POOL_CAPS[device]
 
 
 class Vol:
@@ -83,7 +94,7 @@ class Vol:
         global _pool_bytes
         try:
             t, key = self.t, self.key
-            if self.sig == _pool_sig and _pool_bytes + t.numel() * 4 <= POOL_MAX_BYTES:
+            if self.sig == _pool_sig and _pool_bytes + t.numel() * 4 <= _pool_cap(t.device):
                 _POOL.setdefault(key, []).append(t)
                 _pool_bytes += t.numel() * 4
         except Exception:       # interpreter shutdown
@@ -185,7 +196,7 @@ def _flip_t(w5):
 
 def wgrad3(lv, gout: Vol, x: Vol, m, n):
     """[m, n, 3, 3, 3] weight gradient of conv3 (S = dL/dy, L = x shifted by the depth tap)"""
-    return torch.stack([K.conv_wgrad(lv.g, lv.g, gout.view(), m, x.view(dz - 1), n, 9) for dz in range(3)], dim=2)
+    return K.conv_wgrad_3x3x3(lv.g, gout.view(), m, x.view(-1), n, int(lv.g.plane) * 8)
 
 
 def wgrad2(lvs, lvl, small: Vol, m, large: Vol, n):

@@ -35,7 +35,7 @@ typedef void* dinv_stream_t; /* hipStream_t */
 /* library / error                                                            */
 /* ------------------------------------------------------------------------- */
 const char* dinv_last_error(void);
-int dinv_version(void);   /* 8 = this header (adds dinv_blurfft_apply, dinv_blurfft_workspace_bytes, dinv_spectrum_symbol); 7: (adds dinv_conv3x3_winograd4_last_split, dinv_conv3x3_winograd4_bf16x3, dinv_conv2d/3d_filter_grad, dinv_conv3d*, dinv_cdiv_real, dinv_mask_solve and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
+int dinv_version(void);   /* 9 = this header (adds dinv_conv_wgrad_3x3x3); 8: (adds dinv_blurfft_apply, dinv_blurfft_workspace_bytes, dinv_spectrum_symbol); 7: (adds dinv_conv3x3_winograd4_last_split, dinv_conv3x3_winograd4_bf16x3, dinv_conv2d/3d_filter_grad, dinv_conv3d*, dinv_cdiv_real, dinv_mask_solve and the dinv_mri_desc.reserved test hook; 6: adds dinv_affine and dinv_conv_down2x2_bf16x3; the parallel-beam Radon entry points stopped reading xn; 5: natural point order in the packed weights of dinv_conv3x3_winograd4; 4: before dinv_conv3x3_winograd4; 3: round 3 before dinv_conv3x3_wsplit; 2: round 2; 1: the round-1 entry points only) */
 /* number of visible HIP devices (0 when no GPU): used by the host to fail loudly */
 int dinv_device_count(int* count);
 
@@ -277,6 +277,13 @@ int dinv_conv_down2x2_bf16s_3d(const dinv_act_geom* gin, const dinv_act_geom* go
 int dinv_conv_up2x2_bf16s_3d(const dinv_act_geom* gin, const dinv_act_geom* gout, const float* x, const float* x2,
                              const void* w_split, int32_t cin, int32_t cout, float* y, int32_t depth_in, int32_t dz,
                              dinv_stream_t stream);
+/* weight gradient of a 3x3x3 layer in ONE call (the three depth taps as the second grid dimension of one launch, one
+ * reduction): l = the layer input shifted by -1 slice (depth tap 0), depth_stride = floats from one depth tap to the
+ * next (= plane * 8); dw [m][n][3][3][3]; ws of 3 x dinv_conv_wgrad_workspace_bytes(g, m, n, 9).  Replaces three
+ * dinv_conv_wgrad calls + a stack (torch.autograd's conv3d weight gradient, deepinv/models/drunet.py:323-434 with dim=3). */
+int dinv_conv_wgrad_3x3x3(const dinv_act_geom* g, const float* s, int32_t m, const float* l, int32_t n,
+                          int64_t depth_stride, float* dw, int32_t accumulate, void* ws, size_t ws_bytes,
+                          dinv_stream_t stream);
 /* weight gradient of the depth tap dz of a 2x2x2 stride-2 (transposed) convolution: S on the half grid (depth_s slices
  * per volume), L on the full grid; dw [m][n][2][2] */
 int dinv_conv_wgrad_3d(const dinv_act_geom* gs, const dinv_act_geom* gl, const float* s, int32_t m, const float* l,

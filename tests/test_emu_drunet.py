@@ -481,6 +481,47 @@ def test_wgrad_2x2x2_depth_tap(up):
         assert float((dw.double() - w.grad[:, :, dz]).norm() / w.grad[:, :, dz].norm()) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,D,H,W,cout", [(2, 16, 3, 6, 16, 16), (1, 24, 2, 9, 10, 40), (2, 3, 4, 5, 7, 16), (1, 64, 2, 8, 8, 32)])
+def test_wgrad_3x3x3_one_call_matches_autograd(B, C, D, H, W, cout):
+    """dinv_conv_wgrad_3x3x3 (the three depth taps as the second grid dimension of one launch and of one reduction) against the
+    autograd weight gradient of conv3d in fp64, and equal to three dinv_conv_wgrad calls on slice-shifted views bit for bit"""
+    gen = torch.Generator().manual_seed(C + cout)
+    x = torch.randn(B, C, D, H, W, generator=gen)
+    gy = torch.randn(B, cout, D, H, W, generator=gen)
+    w = torch.zeros(cout, C, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv3d(x.double(), w, padding=1) * gy.double()).sum().backward()
+    g = geom(B * (D + 2), H, W)
+    guard = g.plane
+    g.cs = (g.cs + 2 * guard + 3) // 4 * 4
+
+    def to_vol(t):
+        c = t.shape[1]
+        cp = (c + 7) // 8 * 8
+        a = torch.zeros(cp // 8, g.cs, 8)
+        t2 = torch.nn.functional.pad(t.permute(0, 2, 1, 3, 4), (0, 0, 0, 0, 0, cp - c, 1, 1)).reshape(B * (D + 2), cp, H, W)
+        fr = a[:, guard + g.sl: guard + g.sl + g.np].view(-1, B * (D + 2), g.hp, g.wp, 8)
+        fr[:, :, 1:H + 1, 1:W + 1] = t2.reshape(B * (D + 2), -1, 8, H, W).permute(1, 0, 3, 4, 2)
+        return a
+
+    lib = E.lib()
+    lib.dinv_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    sa, la = to_vol(gy), to_vol(x)
+    view = lambda a, dz=0: ctypes.c_void_p(a[:, guard + dz * g.plane:].data_ptr())
+    dw = torch.full((cout, C, 3, 3, 3), float("nan"))
+    nb = lib.dinv_conv_wgrad_workspace_bytes(ctypes.byref(g), cout, C, 9)
+    ws = torch.zeros(3 * nb, dtype=torch.uint8)
+    E.check(lib.dinv_conv_wgrad_3x3x3(ctypes.byref(g), view(sa), cout, view(la, -1), C, ctypes.c_int64(g.plane * 8), E.p(dw), 0, E.p(ws),
+                                      ctypes.c_size_t(ws.numel()), None))
+    assert not torch.isnan(dw).any()
+    assert float((dw.double() - w.grad).norm() / w.grad.norm()) < 1e-5
+    for dz in range(3):
+        one = torch.full((cout, C, 3, 3), float("nan"))
+        ws1 = torch.zeros(nb, dtype=torch.uint8)
+        E.check(lib.dinv_conv_wgrad(ctypes.byref(g), ctypes.byref(g), view(sa), cout, view(la, dz - 1), C, 9, E.p(one), 0, E.p(ws1),
+                                    ctypes.c_size_t(ws1.numel()), None))
+        assert torch.equal(one, dw[:, :, dz])
+
+
 @pytest.mark.parametrize("mode", ["plain", "relu_split_chain"])
 def test_conv3x3x3_single_launch(mode):
     """dinv_conv3x3x3_split: the three depth taps inside the K loop of the 2-D-tile kernel, padding slices written as zeros;
