@@ -251,7 +251,11 @@ __global__ __launch_bounds__(256) void conv3_thin_kernel(Conv3Args a) {
         const int64_t o = ((int64_t)cb * a.g.cs + a.g.sl + p) * 8 + 4 * (lq & 1);
         float4 v = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
         if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        if (NRES >= 1) v = add4(v, ld4(a.res1 + o));
+        if (NRES == 1) v = add4(v, ld4(a.res1 + o));
+        if (NRES == 2) {     // res1 is a GATE (the forward pass's ReLU output): ReLU backward in the data-gradient convolution's epilogue
+            const float4 gt = ld4(a.res1 + o);
+            v = make_float4(gt.x > 0.f ? v.x : 0.f, gt.y > 0.f ? v.y : 0.f, gt.z > 0.f ? v.z : 0.f, gt.w > 0.f ? v.w : 0.f);
+        }
         if (!writes_value(a, p)) v = make_float4(0.f, 0.f, 0.f, 0.f);
         st4(a.y + o, v);
     }
@@ -479,7 +483,7 @@ static int conv3_launch(const dinv_act_geom* g, const float* x, const float* x2,
     if (int e = check_geom(g)) return e;
     DINV_REQUIRE(x && w_packed && y, "null tensor pointer");
     DINV_REQUIRE(cin % KC == 0 && cin >= KC, "cin=%d must be a positive multiple of %d (pad with zero channels)", cin, KC);
-    const bool thin = cout_tile == 16;
+    const bool thin = cout_tile == 16, gate = (relu & 2) != 0;
     if (thin) {
         DINV_REQUIRE(cout == 16 && cout_valid >= 1 && cout_valid <= 16 && !x2 && !res2, "thin kernel: cout padded to 16, no x2 / res2");
     } else {
@@ -498,7 +502,10 @@ static int conv3_launch(const dinv_act_geom* g, const float* x, const float* x2,
     const int nres = (res1 ? 1 : 0) + (res2 ? 1 : 0);
     DINV_REQUIRE(res1 || !res2, "res2 given without res1");
     const dim3 grid(gx);
-    if (thin) {
+    if (gate) {
+        DINV_REQUIRE(thin && res1 && !(relu & 1), "gate (relu bit 1): thin kernel only, with the gating activation as res1, without ReLU");
+        hipLaunchKernelGGL((conv3_thin_kernel<false, 2>), grid, dim3(256), 0, s, a);
+    } else if (thin) {
         if (relu) { if (nres) hipLaunchKernelGGL((conv3_thin_kernel<true, 1>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv3_thin_kernel<true, 0>), grid, dim3(256), 0, s, a); }
         else      { if (nres) hipLaunchKernelGGL((conv3_thin_kernel<false, 1>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv3_thin_kernel<false, 0>), grid, dim3(256), 0, s, a); }
     } else if (cout_tile == 64) {

@@ -402,11 +402,12 @@ def pack_conv3x3x3_weight(w5: torch.Tensor) -> tuple[torch.Tensor, int, int]:
     return wp, cin_p, cout_p
 
 
-def conv3x3x3(g, x, wpk, cin, cout, y, depth, cout_valid=None, res1=None, relu=False):
+def conv3x3x3(g, x, wpk, cin, cout, y, depth, cout_valid=None, res1=None, relu=False, gate=False):
     """fp32 3x3x3 convolution of volumes stored as stacks of depth + 2 slices, ONE launch (depth taps inside the K loop
-    of csrc/drunet.hip: conv3x3_kernel / conv3_thin_kernel); wpk from pack_conv3x3x3_weight; views as for conv3x3x3_split"""
+    of csrc/drunet.hip: conv3x3_kernel / conv3_thin_kernel); wpk from pack_conv3x3x3_weight; views as for conv3x3x3_split.
+    gate (thin kernel): y = res1 > 0 ? conv : 0"""
     check(_l().dinv_conv3x3x3(ctypes.byref(g), ptr(x), ptr(wpk), cin, cout, cout if cout_valid is None else cout_valid,
-                              int(wpk.shape[4]), ptr(y), ptr(res1), int(relu), int(depth), stream_ptr(y.device)))
+                              int(wpk.shape[4]), ptr(y), ptr(res1), int(relu) | (2 if gate else 0), int(depth), stream_ptr(y.device)))
 
 
 def conv3x3_tail(g, x, wtail, cin, cout, y, x2=None):

@@ -134,7 +134,10 @@ def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=F
     mask-exact training forward; layers of <= 16 output channels on the 16x16x4 MFMA tile)"""
     cout, cin = (w5.shape[1], w5.shape[0]) if flip else w5.shape[:2]
     y = Vol(lv, cout, x.t.device)
-    if cin >= 16 and cout >= 16 and not fp32:
+    # 16 -> 16 channels is ONE 16 x 16 x 4 MFMA tile of the fp32 thin kernel; the bf16-split kernel pads the outputs to its 64-row
+    # tile (measured at config 4's level 0: 0.43 ms against 0.32 ms), so those layers take the fp32 kernel in every setting
+    thin = cin <= 16 and cout <= 16
+    if cin >= 16 and cout >= 16 and not fp32 and not thin:
         pk = _cached(("c3x3", flip), w5, 0, lambda: K.pack_split3d_weight(_pad_w(_flip_t(w5) if flip else w5, _r64(cout), _r16(cin))))
         r1 = gate if gate is not None else res
         K.conv3x3x3_split(lv.g, x.view(), pk, _r16(cin), _r64(cout), y.view(), lv.D, res1=r1.view() if r1 is not None else None,
@@ -142,6 +145,10 @@ def conv3(lv, w5, x: Vol, relu=False, res: Vol | None = None, fp32=False, flip=F
         return y
     assert not (x_presplit or y_presplit)
     pk, cip, cop = _cached(("c3f", flip), w5, 0, lambda: K.pack_conv3x3x3_weight(_flip_t(w5) if flip else w5))
+    if gate is not None and int(pk.shape[4]) == 16:          # thin kernel: ReLU backward in the epilogue
+        assert res is None and not relu
+        K.conv3x3x3(lv.g, x.view(), pk, cip, cop, y.view(), lv.D, cout_valid=cout, res1=gate.view(), gate=True)
+        return y
     K.conv3x3x3(lv.g, x.view(), pk, cip, cop, y.view(), lv.D, cout_valid=cout, res1=res.view() if res is not None else None,
                 relu=relu)
     if gate is not None:
@@ -235,7 +242,7 @@ class DRUNet3dFunction(torch.autograd.Function):
                 w1, w2 = W[f"{_blk(model, prefix, k)}.res.0.weight"], W[f"{_blk(model, prefix, k)}.res.2.weight"]
                 # inference: the ReLU temporary travels pre-split (consumed only by the second convolution); training keeps
                 # it in fp32 (the backward pass reads its sign)
-                ps = (not train) and min(w1.shape[0], w1.shape[1], w2.shape[0], w2.shape[1]) >= 16
+                ps = (not train) and min(w1.shape[0], w1.shape[1], w2.shape[0], w2.shape[1]) >= 16 and max(w1.shape[0], w1.shape[1]) > 16
                 a1 = conv3(l, w1, cur, relu=True, fp32=f32, y_presplit=ps)
                 out = conv3(l, w2, a1, res=cur, fp32=f32, x_presplit=ps)
                 if train:

@@ -150,7 +150,9 @@ int dinv_conv3x3(const dinv_act_geom* g, const float* x, const float* x2, const 
  * depth + 2 slices (see the 3-D section below), ONE launch: y = [relu](conv3x3x3(x)) (+res1), the padding slices of y
  * written as zeros.  w_packed: [cout/MT][dz 3][cin/8][9 taps][MT][8]; cout_tile = MT in {16, 32, 64}; MT = 16 (cout
  * padded to 16) selects the thin-layer kernel on the 16x16x4 fp32 MFMA tile (also accepted by dinv_conv3x3: x2 = res2 =
- * NULL).  x must be readable one slice before and after the buffer's range. */
+ * NULL).  x must be readable one slice before and after the buffer's range.  relu: bit 0 = ReLU; bit 1 (thin kernel
+ * only, with res1, without bit 0) = res1 is a GATE: y = res1 > 0 ? conv : 0 (ReLU backward in the epilogue of the data-
+ * gradient convolution; torch.autograd's threshold_backward after conv3d's input gradient). */
 int dinv_conv3x3x3(const dinv_act_geom* g, const float* x, const float* w_packed, int32_t cin, int32_t cout,
                    int32_t cout_valid, int32_t cout_tile, float* y, const float* res1, int32_t relu, int32_t depth,
                    dinv_stream_t stream);

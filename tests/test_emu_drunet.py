@@ -607,10 +607,11 @@ def test_conv3x3x3_as_three_shifted_2d_launches():
 
 
 @pytest.mark.parametrize("cin,cout,relu,res", [(16, 16, True, False), (3, 16, False, False), (16, 2, False, True), (16, 32, True, False),
-                                              (24, 64, False, True)])
+                                              (24, 64, False, True), (16, 16, False, "gate"), (8, 3, False, "gate")])
 def test_conv3x3x3_fp32_single_launch(cin, cout, relu, res):
     """dinv_conv3x3x3 (csrc/drunet.hip: fp32 MFMA, depth taps inside the K loop; cout <= 16: conv3_thin_kernel on the
-    16x16x4 tile) against conv3d in fp64: ReLU / residual epilogues, zeroed padding slices, stale output overwritten"""
+    16x16x4 tile) against conv3d in fp64: ReLU / residual / gate (ReLU backward: y = r > 0 ? conv : 0) epilogues, zeroed padding
+    slices, stale output overwritten"""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from deepinv_amd.hip.drunet import pack_conv3x3x3_weight
@@ -641,7 +642,7 @@ def test_conv3x3x3_fp32_single_launch(cin, cout, relu, res):
     wpk, cip, cop = pack_conv3x3x3_weight(w)
     view = lambda a: ctypes.c_void_p(a[:, guard:].data_ptr())
     E.check(E.lib().dinv_conv3x3x3(ctypes.byref(g), view(xa), ctypes.c_void_p(wpk.data_ptr()), cip, cop, cout, int(wpk.shape[4]),
-                                   view(ya), view(ra) if res else None, int(relu), D, None))
+                                   view(ya), view(ra) if res else None, int(relu) | (2 if res == "gate" else 0), D, None))
     out = ya[:, guard + g.sl: guard + g.sl + g.np].view(-1, B, D + 2, g.hp, g.wp, 8)
     assert float(out[:, :, 0].abs().max()) == 0 and float(out[:, :, D + 1].abs().max()) == 0          # padding slices
     assert float(out[:, :, :, 0].abs().max()) == 0 and float(out[:, :, :, :, 0].abs().max()) == 0     # frames
@@ -650,7 +651,10 @@ def test_conv3x3x3_fp32_single_launch(cin, cout, relu, res):
     ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
     if relu:
         ref = ref.clamp_min(0)
-    if res:
+    if res == "gate":
+        ref = ref * (r > 0)
+        assert bool((got[r <= 0] == 0).all())
+    elif res:
         ref = ref + r.double()
     assert float((got.double() - ref).norm() / ref.norm()) < 2e-6
 
