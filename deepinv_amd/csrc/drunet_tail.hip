@@ -2,15 +2,13 @@
 // With 1-4 output channels the 32-row MFMA tile of drunet.hip computes 8-16x more than needed (measured 1.12 ms at 32 x 320 x 320);
 // here a lane produces pixels x COUT channels with wave-uniform weights (scalar loads).
 //
-// This file is compiled WITHOUT SLP vectorisation (csrc/Makefile: -fno-slp-vectorize), i.e. without v_pk_{mul,fma,add}_f32:
-// built with the packed ops, tail3x3_shift_kernel is not reproducible when a bf16-split convolution (drunet_wsplit.hip, bf16
-// MFMA) runs on another stream of the same device - the batch lanes of models/drunet.py do exactly that.  Measured
-// (scripts/r06/race_hunt8.py, race_hunt11.py, 60 of 60 launches): in lanes 48..63 of a wave single terms of the sum are dropped
-// (the first product of a packed chain reads as zero), output channel 0 only, whatever the weights come through (scalar
-// loads, vector loads or LDS); alone, beside the fp32 Winograd kernel or beside a second tail launch the same binary is
-// bit-reproducible.  The scalar-FMA build is reproducible in all of those cases and runs at the same 0.39 ms (the kernel
-// streams its two input tensors).  The mechanism was not isolated (a register-only v_pk_fma_f32 chain beside a bf16 MFMA
-// loop, scripts/r06/probe/pk_mfma_probe.hip, is clean); tests/test_loops_gpu.py holds the regression test.
+// Built without SLP vectorisation like the whole library (csrc/Makefile).  This kernel is where the reason was found: with hipcc's
+// SLP-packed fp32 ops, tail3x3_shift_kernel was not reproducible while a bf16-split convolution (drunet_wsplit.hip, bf16 MFMA) ran on
+// another stream of the same device - the batch lanes of models/drunet.py do exactly that.  In lanes 48..63 of a wave single terms of
+// the sum were dropped: the LOW result of v_pk_mul_f32 / v_pk_fma_f32 forms that read the HIGH half of src1 (op_sel[1] = 1) is wrong
+// there while another kernel's wave runs bf16 MFMAs on the SIMD (scripts/r06/probe/pk_forms_probe.hip).  The
+// scalar-FMA build is bit-reproducible in every setting and runs at the same 0.39 ms (the kernel streams its two input tensors);
+// tests/test_drunet_gpu.py and tests/test_loops_gpu.py hold the regression tests.
 #include "drunet_common.hpp"
 
 using namespace dinv;

@@ -15,9 +15,11 @@ from deepinv_amd.hip import drunet as K  # noqa: E402
 dev = torch.device("cuda:0")
 sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 gen = torch.Generator().manual_seed(0)
-B, side, c = 8, 256, 64
+B, side, c = 8, int(os.environ.get('SIDE', '256')), 64
+NOX2 = os.environ.get('NOX2') == '1'
 cout = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 g = K.geom(B, side, side)
+SW = -(-side // -(-side // 62))          # the kernel's strip width: lanes 1 .. SW write
 
 
 def act(ch, fill=True):
@@ -38,7 +40,7 @@ xb, rb, yb = act(c), act(c), act(c, False)
 
 
 def tail():
-    K.conv3x3_tail(g, xa, wtp, c, cout, yt, x2=x2a)
+    K.conv3x3_tail(g, xa, wtp, c, cout, yt, x2=None if NOX2 else x2a)
 
 
 with torch.cuda.stream(sA):
@@ -69,6 +71,6 @@ for name, partner in partners.items():
             bad += 1
             d = (yt - ref)[0, g.sl:g.sl + g.np].view(B, g.hp, g.wp, 8).abs()
             idx = (d > 0).nonzero()
-            cols.update(((idx[:, 2] - 1) % 52).tolist())
+            cols.update(((idx[:, 2] - 1) % SW + 1).tolist())
             chans.update(idx[:, 3].tolist())
-    print(json.dumps({"cout": cout, "partner": name, "differing_runs_of_60": bad, "cols_mod_52": dict(sorted(cols.items())), "channels": dict(chans)}), flush=True)
+    print(json.dumps({"cout": cout, "partner": name, "differing_runs_of_60": bad, "side": side, "x2": not NOX2, "lanes": dict(sorted(cols.items())), "channels": dict(chans)}), flush=True)

@@ -94,3 +94,22 @@ def test_operators_fail_loudly_without_gpu():
         dinv.physics.Blur(filter=torch.ones(1, 1, 3, 3) / 9).A(torch.randn(1, 1, 8, 8))
     with pytest.raises(RuntimeError):
         dinv.models.DRUNet(1, 1, pretrained=None)(torch.randn(1, 1, 32, 32), 0.1)
+
+
+def test_no_packed_fp32_instruction_reads_src1_high_for_its_low_result():
+    """A gfx950 hazard measured in round 6 (scripts/r06/probe/pk_forms_probe.hip): v_pk_{mul,fma,add}_f32 with op_sel[1] = 1
+    returns wrong LOW results in lanes 48..63 while a wave of another kernel executes bf16 MFMAs on the same SIMD - what the batch lanes of
+    DRUNet arrange all the time.  The library is built without SLP vectorisation and its hand-written packed arithmetic uses src0 for the
+    broadcast; this scans every gfx950 code object of the built library for the unsafe form."""
+    import importlib.util
+    import shutil
+
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or shutil.which("c++filt") is None:
+        pytest.skip("no llvm-objdump here")
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("scan_pk_opsel", os.path.join(here, "scripts", "r06", "scan_pk_opsel.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.scan(os.path.join(here, "deepinv_amd", "libdeepinv_amd.so"))
+    assert res["code_objects"] >= 10                       # one per translation unit
+    assert not res["pk_op_sel_src1_hi"], dict(res["pk_op_sel_src1_hi"])

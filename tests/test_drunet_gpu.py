@@ -360,8 +360,8 @@ def test_tail_conv_lane_shift(dev, B, H, W, cin, cout, skip):
 def test_tail_conv_reproducible_beside_a_bf16_split_launch(dev, B, side, cout):
     """The tail convolution on one stream while bf16-split convolutions (csrc/drunet_wsplit.hip) run on another - what the batch
     lanes of models/drunet.py do - returns the bits it returns alone.  Built with SLP-packed fp32 ops it did not (60 of 60
-    launches: single terms dropped in lanes 48..63 of a wave, scripts/r06/race_hunt8.py / race_hunt11.py); csrc/Makefile builds
-    drunet_tail.hip without them.  Row groups of 8, 4 and 2 rows per wave (launch sizes 32, 8 and 2 slices)."""
+    launches: single terms dropped in lanes 48..63 of a wave, scripts/r06/race_hunt8.py / race_hunt11.py - the op_sel[1] = 1 forms of
+    DESIGN.md 3.6); csrc/Makefile builds the library without them.  Row groups of 8, 4 and 2 rows per wave (launch sizes 32, 8 and 2 slices)."""
     from deepinv_amd.hip import drunet as K
 
     gen = torch.Generator().manual_seed(cout)
