@@ -32,6 +32,14 @@
 
 using namespace dinv;
 
+// Two objects are built from this file (csrc/Makefile): DINV_RADON_PART = 1 is dinv_radon_forward_tiled alone, compiled WITH SLP
+// vectorisation (its window arithmetic packs into v_pk_* forms that pay: 1.16 against 1.31 ms at config 3, and none of them is the
+// op_sel[1] = 1 form of DESIGN.md 3.6 - tests/test_abi.py scans for it); DINV_RADON_PART = 2 is everything else, without SLP like the
+// rest of the library (the adjoint is 17 % faster that way: 0.71 against 0.86 ms).  0 = the whole file (host emulation).
+#ifndef DINV_RADON_PART
+#define DINV_RADON_PART 0
+#endif
+
 #ifdef DINV_EMU
 extern "C" { int dinv_emu_window_misses = 0; int dinv_emu_segment_misses = 0; }
 #endif
@@ -302,6 +310,7 @@ __global__ __launch_bounds__(512, MAXPF <= 10 ? 4 : 2) void radon_fwd_tiled_kern
     }
 }
 
+#if DINV_RADON_PART != 1
 // ---------------------------------------------------------------------------------------------------- adjoint
 // sino [n_img, G, A] -> sp [groups][A][JPAD + G + JPAD][NB] (zero padded rows)
 template <int NB>
@@ -556,6 +565,8 @@ __global__ __launch_bounds__(256) void ramp_fft_kernel(int n_img, int N, int A, 
     }
 }
 
+#endif  // DINV_RADON_PART != 1
+
 // ---------------------------------------------------------------------------------------------------- host side
 int make_geom(const dinv_radon_desc* d, TiledGeom* g, int* NBsel) {
     DINV_REQUIRE(d != nullptr, "null descriptor");
@@ -611,6 +622,7 @@ int set_dyn_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
+#if DINV_RADON_PART != 1
 extern "C" size_t dinv_radon_plan_bytes(const dinv_radon_desc* d) {
     TiledGeom g;
     int NB;
@@ -742,6 +754,9 @@ extern "C" size_t dinv_radon_tiled_workspace_bytes(const dinv_radon_desc* d, int
     return (2 * (size_t)g.groups * g.PH * g.PW * NB + kSlackFloats) * sizeof(float);
 }
 
+#endif  // DINV_RADON_PART != 1
+
+#if DINV_RADON_PART != 2
 #define DINV_FWD_LAUNCH(PF)                                                                                              \
     do {                                                                                                                 \
         if (int e = set_dyn_lds(radon_fwd_tiled_kernel<NB, false, PF>, lds)) return e;                                  \
@@ -794,6 +809,9 @@ extern "C" int dinv_radon_forward_tiled(const dinv_radon_desc* d, const dinv_rad
     return 0;
 }
 
+#endif  // DINV_RADON_PART != 2
+
+#if DINV_RADON_PART != 1
 extern "C" int dinv_radon_adjoint_tiled(const dinv_radon_desc* d, const float* sino, const float* xn, const float* cs,
                                         const float* norm_dev, float* x, void* ws, size_t ws_bytes,
                                         dinv_stream_t stream) {
@@ -881,3 +899,4 @@ extern "C" int dinv_radon_ramp_fft(int32_t n_img, int32_t n_det, int32_t n_angle
     DINV_CHECK_LAUNCH();
     return 0;
 }
+#endif  // DINV_RADON_PART != 1
