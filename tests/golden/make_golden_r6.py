@@ -12,7 +12,11 @@
                      W = 128, acceleration 4 and 8), the offset histogram of `EquispacedMaskGenerator` with the column sets of every
                      offset, `PolyOrderMaskGenerator`'s pdf (the binary-searched Bernoulli probabilities) and its inclusion counts.
 
-    python tests/golden/make_golden_r6.py [masks] [cfg3_pair] [cfg3_b]      # masks: ~1 min, cfg3_pair: ~15 min, cfg3_b: ~1.5 h
+* `cfg5_full_b.npz`  a SECOND full-length draw of BASELINE configs[4] (100-step DiffPIR on Downsampling x4 + DRUNet(3->3)): another
+                     image (seed 80), another DRUNet initialisation (82), other noise (83) and other Gaussian draws along the path (84);
+                     same contents as cfg5_full.npz (make_golden_r5.py: cfg5) plus the seeds, so the 4e-6 end point is not one draw.
+
+    python tests/golden/make_golden_r6.py [masks] [cfg3_pair] [cfg3_b] [cfg5_b]   # masks ~1 min, cfg3_pair ~15 min, cfg3_b ~1.5 h, cfg5_b ~40 min
 """
 import os
 import sys
@@ -112,6 +116,63 @@ def cfg3_pair():
     hqs_run("cfg3_pair", W, 360, xs, 66, per_unit=True)
 
 
+def cfg5_b(seeds=(80, 82, 83, 84)):
+    """make_golden_r5.py: cfg5 with other seeds (image, DRUNet initialisation, measurement noise, draws along the path)"""
+    from oracle import optim_cpu as OO
+    from oracle import physics_cpu as O
+    s_img, s_net, s_noise, s_draw = seeds
+    img, f, steps = (3, 256, 256), 4, 100
+    x = torch.rand(1, *img, generator=g(s_img))
+    p = dinv.physics.Downsampling(img_size=img, filter="bicubic", factor=f, padding="circular",
+                                  noise_model=dinv.physics.GaussianNoise(0.05))
+    y = p.A(x)
+    sd = OD.init_state_dict(3, 3, seed=s_net)
+    den = dinv.models.DRUNet(in_channels=3, out_channels=3, pretrained=None)
+    den.load_state_dict(sd)
+    den.eval()
+    outs = []
+
+    class Trace(torch.nn.Module):
+        def forward(self, u, sigma, *a, **k):
+            o = den(u, sigma, *a, **k)
+            outs.append(sub(o, STRIDE_TRACE))
+            return o
+
+    yn = y + 0.05 * torch.randn(1, 3, 64, 64, generator=g(s_noise))
+    gen = g(s_draw)
+    _orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: torch.randn(t.shape, generator=gen)
+    sampler = dinv.sampling.DiffPIR(Trace(), dinv.optim.L2(), sigma=0.05, max_iter=steps, zeta=0.1, lambda_=7.0, device="cpu")
+    t0 = time.time()
+    try:
+        out = sampler(yn, p)
+    finally:
+        torch.randn_like = _orig
+    print("cfg5_b loop", time.time() - t0, flush=True)
+    dt = torch.float64
+    sd64 = {k: v.to(dt) for k, v in sd.items()}
+    k64 = p.filter.to(dt)
+    gen = g(s_draw)
+    draws = (torch.randn(1, *img, generator=gen).to(dt) for _ in range(2 * steps))
+    outs64 = []
+
+    def den64(u, s):
+        o = OD.drunet(sd64, u, s)
+        outs64.append(sub(o, STRIDE_TRACE).float())
+        return o
+
+    t0 = time.time()
+    with torch.no_grad():
+        exact = OO.diffpir(yn.to(dt), lambda v: O.downsampling_AT(v, k64, f, img),
+                           lambda zz, yy, gam: O.downsampling_prox_l2(zz, yy, gam, k64, f, img),
+                           den64, draws, sigma=0.05, max_iter=steps, noise_sigma=0.05)
+    err = float((out.double() - exact).norm() / exact.norm())
+    print("cfg5_b fp64 evaluation", time.time() - t0, "reference vs fp64:", err, flush=True)
+    save("cfg5_full_b", y=y, out=sub(out), out_exact=sub(exact).float(), out_err_vs_exact=np.float64(err),
+         den_outs=torch.stack(outs), den_outs_exact=torch.stack(outs64), seq=sampler.seq, stride=STRIDE,
+         stride_trace=STRIDE_TRACE, drunet_seed=s_net, steps=steps, seeds=np.int32(seeds))
+
+
 def masks():
     from deepinv.physics.generator import (EquispacedMaskGenerator, GaussianMaskGenerator, RandomMaskGenerator)
     from deepinv.physics.generator.mri import PolyOrderMaskGenerator
@@ -145,6 +206,6 @@ def masks():
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count() or 8)))
-    for name in sys.argv[1:] or ["masks", "cfg3_pair", "cfg3_b"]:
-        {"masks": masks, "cfg3_pair": cfg3_pair, "cfg3_b": cfg3_b}[name]()
+    for name in sys.argv[1:] or ["masks", "cfg3_pair", "cfg3_b", "cfg5_b"]:
+        {"masks": masks, "cfg3_pair": cfg3_pair, "cfg3_b": cfg3_b, "cfg5_b": cfg5_b}[name]()
     print("done")
