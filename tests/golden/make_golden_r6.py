@@ -12,6 +12,9 @@
                      W = 128, acceleration 4 and 8), the offset histogram of `EquispacedMaskGenerator` with the column sets of every
                      offset, `PolyOrderMaskGenerator`'s pdf (the binary-searched Bernoulli probabilities) and its inclusion counts.
 
+* `cfg2_b.npz`       a second draw of the HEADLINE configs[1] (50-iteration PnP-PGD, 8-coil 320x320 MultiCoilMRI, DRUNet(2->2)) with everything
+                     re-drawn: other coil maps (seed 5), a 60-spoke radial mask, other images / noise (seeds 2000 + i), another DRUNet
+                     initialisation (seed 81), g_param 0.08; four slices through deepinv.optim.PGD.
 * `cfg5_full_b.npz`  a SECOND full-length draw of BASELINE configs[4] (100-step DiffPIR on Downsampling x4 + DRUNet(3->3)): another
                      image (seed 80), another DRUNet initialisation (82), other noise (83) and other Gaussian draws along the path (84);
                      same contents as cfg5_full.npz (make_golden_r5.py: cfg5) plus the seeds, so the 4e-6 end point is not one draw.
@@ -173,6 +176,36 @@ def cfg5_b(seeds=(80, 82, 83, 84)):
          stride_trace=STRIDE_TRACE, drunet_seed=s_net, steps=steps, seeds=np.int32(seeds))
 
 
+def cfg2_b():
+    """second draw of the headline loop (make_golden_r5.py: cfg2_slices with other seeds and parameters)"""
+    from oracle import physics_cpu as OP
+    H = W = 320
+    coils, iters, seed, spokes, g_param, nsl = 8, 50, 81, 60, 0.08, 4
+    maps = torch.randn(1, coils, H, W, dtype=torch.complex64, generator=g(5))
+    maps = maps / maps.abs().pow(2).sum(dim=1, keepdim=True).sqrt()
+    mask = OP.radial_mask(H, W, spokes)
+    p = dinv.physics.MultiCoilMRI(mask=mask, coil_maps=maps, img_size=(2, H, W), device="cpu")
+    ys = []
+    for i in range(nsl):
+        gi = g(2000 + i)
+        x = torch.rand(1, 2, H, W, generator=gi)
+        noise = torch.randn(1, 2, coils, H, W, generator=gi)
+        ys.append(p.A(x) + 0.01 * noise * p.mask[:, :, None])
+    y = torch.cat(ys)
+    den = dinv.models.DRUNet(in_channels=2, out_channels=2, pretrained=None)
+    den.load_state_dict(OD.init_state_dict(2, 2, seed=seed))
+    den.eval()
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=1.0, g_param=g_param, max_iter=iters,
+                           early_stop=False)
+    t0 = time.time()
+    with torch.no_grad():
+        rec = model(y, p)
+    print("cfg2_b reference PGD", time.time() - t0, "s", flush=True)
+    assert torch.isfinite(rec).all()
+    save("cfg2_b", rec=torch.stack([sub(r) for r in rec]), y0=sub(y[:1]), stride=STRIDE, drunet_seed=seed, iters=iters, spokes=spokes,
+         g_param=np.float32(g_param), maps_seed=5, slice_seed0=2000, slices=nsl)
+
+
 def masks():
     from deepinv.physics.generator import (EquispacedMaskGenerator, GaussianMaskGenerator, RandomMaskGenerator)
     from deepinv.physics.generator.mri import PolyOrderMaskGenerator
@@ -206,6 +239,6 @@ def masks():
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count() or 8)))
-    for name in sys.argv[1:] or ["masks", "cfg3_pair", "cfg3_b", "cfg5_b"]:
-        {"masks": masks, "cfg3_pair": cfg3_pair, "cfg3_b": cfg3_b, "cfg5_b": cfg5_b}[name]()
+    for name in sys.argv[1:] or ["masks", "cfg3_pair", "cfg3_b", "cfg5_b", "cfg2_b"]:
+        {"masks": masks, "cfg3_pair": cfg3_pair, "cfg3_b": cfg3_b, "cfg5_b": cfg5_b, "cfg2_b": cfg2_b}[name]()
     print("done")

@@ -469,3 +469,39 @@ def test_cfg2_multicoil_pnp_pgd_320(dev, gain_tag):
             ds = load("cfg2_slices")
             errs = {int(i): rel_err(sub(rec[int(i):int(i) + 1], int(ds["stride"])), ds["rec"][k]) for k, i in enumerate(ds["slices"])}
             assert len(errs) == 7 and max(errs.values()) < TOL, (prec, errs)
+
+
+def test_cfg2_second_draw_other_maps_mask_and_initialisation(dev):
+    """A second draw of the HEADLINE loop with everything re-drawn (tests/golden/cfg2_b.npz, make_golden_r6.py: cfg2_b - other coil
+    maps, a 60-spoke mask, other images and noise, another DRUNet initialisation, g_param 0.08): four slices through the real
+    reference's deepinv.optim.PGD, 50 iterations, both arithmetic settings."""
+    import deepinv_amd as dinv
+    from oracle import drunet_cpu as OD
+
+    if not os.path.exists(os.path.join(G, "cfg2_b.npz")):
+        pytest.skip("tests/golden/cfg2_b.npz not generated (tests/golden/make_golden_r6.py cfg2_b: ~3 min of CPU)")
+    d = load("cfg2_b")
+    st, iters, nsl, H, W, coils = int(d["stride"]), int(d["iters"]), int(d["slices"]), 320, 320, 8
+    maps = torch.randn(1, coils, H, W, dtype=torch.complex64, generator=gen(int(d["maps_seed"])))
+    maps = maps / maps.abs().pow(2).sum(dim=1, keepdim=True).sqrt()
+    physics = dinv.physics.MultiCoilMRI(mask=dinv.utils.radial_mask(H, W, int(d["spokes"])), coil_maps=maps, img_size=(2, H, W), device=dev)
+    ys = []
+    for i in range(nsl):
+        gi = gen(int(d["slice_seed0"]) + i)
+        x = torch.rand(1, 2, H, W, generator=gi).to(dev)
+        noise = torch.randn(1, 2, coils, H, W, generator=gi).to(dev)
+        ys.append(physics.A(x) + 0.01 * noise * physics.mask[:, :, None])
+    y = torch.cat(ys)
+    assert rel_err(sub(y[:1], st), d["y0"]) < TOL
+    den = dinv.models.DRUNet(2, 2, pretrained=None).to(dev).eval()
+    den.load_state_dict(OD.init_state_dict(2, 2, seed=int(d["drunet_seed"])))
+    model = dinv.optim.PGD(data_fidelity=dinv.optim.L2(), prior=dinv.optim.PnP(den), stepsize=1.0, g_param=float(d["g_param"]),
+                           max_iter=iters, early_stop=False)
+    from deepinv_amd.models.drunet import CONV_PRECISIONS
+    for prec in CONV_PRECISIONS:
+        den.conv_precision = prec
+        with torch.no_grad():
+            rec = model(y, physics)
+        errs = [rel_err(sub(rec[k:k + 1], st), d["rec"][k]) for k in range(nsl)]
+        print("cfg2 second draw", prec, ["%.2e" % e for e in errs])
+        assert torch.isfinite(rec).all() and max(errs) < TOL, (prec, errs)
