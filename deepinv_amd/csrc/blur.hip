@@ -348,6 +348,194 @@ inline int launch_tiled(const ConvGeom& g, bool transpose, const float* in, cons
     return 0;
 }
 
+// ---- LDS-tiled forms for stride s >= 2 (Downsampling.A / A_adjoint: bicubic x4 on 256 x 256 is a 16 x 16 filter at stride 4).  The
+// general kernels above read every tap from global memory through pad_map (57 us) or walk pre-image lists with integer divisions and
+// spill (91 us) for 12.6 MB of input: ten times what the bytes cost.  Forward: a workgroup owns 16 x 16 outputs; its
+// (15 s + h) x (15 s + w) input patch goes through pad_map once per element into LDS, stored DE-INTERLEAVED by column phase
+// (column j s + b at [b][j]) so that the 16 lanes of an output row read consecutive words for a tap; two LDS reads per
+// multiply-add, no global access and no division in the loop.  Transposed (valid / constant, circular with sizes divisible by
+// the stride): x[r, c] = sum over the taps u = (r + pt) mod s + t s, v = (c + pl) mod s + q s of kf[u, v] y[(r + pt) / s - t,
+// (c + pl) / s - q]: a workgroup owns 64 x 64 outputs and stages the (64 / s + (h - 1) / s + 2)^2 measurements they touch.
+struct StrideConv {
+    int32_t C, fb, fc;
+    int32_t Hi, Wi, Ho, Wo;     // forward: input / output;  transposed: Hi x Wi = the measurement y, Ho x Wo = the image x
+    int32_t h, w, s, pt, pl, mode;
+    int32_t PH, PWs, pitch;     // forward: patch rows, columns per phase, row pitch;  transposed: PH x PWs staged measurements, pitch
+};
+
+// FAST4 (stride 4, filter width a multiple of 4 - bicubic x4): the patch keeps its natural column order; the four taps v .. v + 3 of
+// lane tx are the 16 bytes at column 4 tx + v, so the 16 lanes of an output row read 256 contiguous bytes with ONE ds_read_b128 and the
+// four taps come with one more (the same address in every lane): 2 LDS reads per 4 multiply-adds, 64 trips per output instead of 256
+// dependent ones (29.6 -> us measured in the launcher's comment).
+template <bool FAST4>
+__global__ __launch_bounds__(256) void conv2d_strided_kernel(StrideConv g, const float* __restrict__ in, const float* __restrict__ k,
+                                                             float* __restrict__ out) {
+    DINV_DYN_LDS(float, smem);
+    float* ks = smem;                      // flipped filter [h][w]
+    float* patch = smem + g.h * g.w;       // [PH][pitch]; general form: a row = s phases of PWs columns (column j s + b at [b][j])
+    const int bc = blockIdx.z, b = bc / g.C, c = bc % g.C;
+    const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * g.h * g.w;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < g.h * g.w; i += 256) ks[i] = kf[g.h * g.w - 1 - i];
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+    const float* img = in + (int64_t)bc * g.Hi * g.Wi;
+    const int pwide = g.s * g.PWs;
+    // four elements per trip: their global loads are in flight together
+    for (int idx0 = tid; idx0 < g.PH * pwide; idx0 += 1024) {
+        float val[4];
+        int dst[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = idx0 + 256 * e;
+            const int pr = idx / pwide, pc = idx - pr * pwide;
+            const int rr = pad_map(r0 * g.s + pr - g.pt, g.Hi, g.mode);
+            const int cc = pad_map(c0 * g.s + pc - g.pl, g.Wi, g.mode);
+            const int j = pc / g.s, ph = pc - j * g.s;
+            const bool ok = idx < g.PH * pwide && rr >= 0 && rr < g.Hi && cc >= 0 && cc < g.Wi;
+            dst[e] = idx < g.PH * pwide ? pr * g.pitch + (FAST4 ? pc : ph * g.PWs + j) : -1;
+            val[e] = ok ? img[(int64_t)rr * g.Wi + cc] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (dst[e] >= 0) patch[dst[e]] = val[e];
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc = 0.f;
+    if (FAST4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int u = 0; u < g.h; ++u) {
+            const float* prow = patch + (ty * 4 + u) * g.pitch + tx * 4;
+            const float* krow = ks + u * g.w;
+#pragma unroll 4
+            for (int v = 0; v < g.w; v += 4) {
+                const float4 p4 = *reinterpret_cast<const float4*>(prow + v);
+                const float4 t4 = *reinterpret_cast<const float4*>(krow + v);
+                a0 = fmaf(t4.x, p4.x, a0); a1 = fmaf(t4.y, p4.y, a1); a2 = fmaf(t4.z, p4.z, a2); a3 = fmaf(t4.w, p4.w, a3);
+            }
+        }
+        acc = (a0 + a1) + (a2 + a3);
+    } else {
+        for (int u = 0; u < g.h; ++u) {
+            const float* prow = patch + (ty * g.s + u) * g.pitch + tx;
+            const float* krow = ks + u * g.w;
+            for (int ph = 0; ph < g.s; ++ph) {
+                const float* pp = prow + ph * g.PWs;
+                for (int v = ph, q = 0; v < g.w; v += g.s, ++q) acc = fmaf(krow[v], pp[q], acc);
+            }
+        }
+    }
+    const int io = r0 + ty, jo = c0 + tx;
+    if (io < g.Ho && jo < g.Wo) out[((int64_t)bc * g.Ho + io) * g.Wo + jo] = acc;
+}
+
+// FAST16 (stride 4, 16 x 16 filter - bicubic x4): the 16 outputs of a thread (rows r0 + ty + 4 i) share their tap phases, so the 4 x 4
+// taps they use are read ONCE into registers, and measurement row R serves the outputs i = R - R0 + t (t = 0 .. 3): the thread walks the
+// 19 rows it touches, four values each - 76 + 16 LDS reads for 256 multiply-adds instead of 512.
+template <bool FAST16>
+__global__ __launch_bounds__(256) void conv2d_strided_transpose_kernel(StrideConv g, const float* __restrict__ y,
+                                                                       const float* __restrict__ k, float* __restrict__ x) {
+    DINV_DYN_LDS(float, smem);
+    float* ks = smem;                      // flipped filter [h][w]
+    float* yp = smem + g.h * g.w;          // [PH][pitch] measurements
+    const int bc = blockIdx.z, b = bc / g.C, c = bc % g.C;
+    const float* kf = k + ((int64_t)(g.fb > 1 ? b : 0) * g.fc + (g.fc > 1 ? c : 0)) * g.h * g.w;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < g.h * g.w; i += 256) ks[i] = kf[g.h * g.w - 1 - i];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int base_r = (r0 + g.pt) / g.s - (g.h - 1) / g.s, base_c = (c0 + g.pl) / g.s - (g.w - 1) / g.s;
+    const float* meas = y + (int64_t)bc * g.Hi * g.Wi;
+    for (int idx = tid; idx < g.PH * g.PWs; idx += 256) {
+        const int i = idx / g.PWs, j = idx - i * g.PWs;
+        int rr = base_r + i, cc = base_c + j;
+        if (g.mode == PAD_CIRCULAR) {
+            rr %= g.Hi; if (rr < 0) rr += g.Hi;
+            cc %= g.Wi; if (cc < 0) cc += g.Wi;
+        }
+        yp[i * g.pitch + j] = (rr >= 0 && rr < g.Hi && cc >= 0 && cc < g.Wi) ? meas[(int64_t)rr * g.Wi + cc] : 0.f;
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    const int cx = c0 + tx;
+    const int C0 = (cx + g.pl) / g.s, bph = (cx + g.pl) - C0 * g.s;
+    const float* ycol = yp + (C0 - base_c);
+    if (FAST16) {
+        const int Rb = (r0 + ty + g.pt) >> 2, a = (r0 + ty + g.pt) & 3;
+        float T[4][4], acc[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[t][q] = ks[(a + 4 * t) * 16 + bph + 4 * q];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int rel = -3; rel < 16; ++rel) {
+            const float* yrow = ycol + (Rb + rel - base_r) * g.pitch;
+            const float y0 = yrow[0], y1 = yrow[-1], y2 = yrow[-2], y3 = yrow[-3];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = rel + t;
+                if (i >= 0 && i < 16) acc[i] += (T[t][0] * y0 + T[t][1] * y1) + (T[t][2] * y2 + T[t][3] * y3);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + ty + 4 * i;
+            if (r < g.Ho && cx < g.Wo) x[((int64_t)bc * g.Ho + r) * g.Wo + cx] = acc[i];
+        }
+        return;
+    }
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i;
+        const int R0 = (r + g.pt) / g.s, a = (r + g.pt) - R0 * g.s;
+        float acc = 0.f;
+        for (int u = a, t = 0; u < g.h; u += g.s, ++t) {
+            const float* yrow = ycol + (R0 - t - base_r) * g.pitch;
+            const float* krow = ks + u * g.w;
+#pragma unroll 4
+            for (int v = bph, q = 0; v < g.w; v += g.s, ++q) acc = fmaf(krow[v], yrow[-q], acc);
+        }
+        if (r < g.Ho && cx < g.Wo) x[((int64_t)bc * g.Ho + r) * g.Wo + cx] = acc;
+    }
+}
+
+// the strided LDS-tiled kernels; *took = 1 when they ran the call
+inline int launch_strided(const ConvGeom& g, bool transpose, const float* in, const float* k, float* out, hipStream_t s, int* took) {
+    *took = 0;
+    if (g.stride < 2 || g.stride > 16) return 0;
+    StrideConv t;
+    t.C = g.C; t.fb = g.fb; t.fc = g.fc; t.h = g.h; t.w = g.w; t.s = g.stride; t.pt = g.pt; t.pl = g.pl; t.mode = g.mode;
+    if (!transpose) {
+        t.Hi = g.H; t.Wi = g.W; t.Ho = g.Ho; t.Wo = g.Wo;
+        t.PH = 15 * g.stride + g.h;
+        t.PWs = 15 + (g.w + g.stride - 1) / g.stride;
+        t.pitch = g.stride * t.PWs;
+        const bool fast4 = g.stride == 4 && g.w % 4 == 0;
+        if (fast4) t.pitch = (t.pitch + 3) & ~3;            // 16-byte rows
+        else while (t.pitch % 8 != 4) ++t.pitch;            // rows s apart land 16 banks apart at stride 4
+        const size_t lds = ((size_t)g.h * g.w + (size_t)t.PH * t.pitch) * sizeof(float);
+        if (lds > 64 * 1024) return 0;
+        const dim3 grid((g.Wo + 15) / 16, (g.Ho + 15) / 16, g.B * g.C);
+        if (fast4) hipLaunchKernelGGL(conv2d_strided_kernel<true>, grid, dim3(256), lds, s, t, in, k, out);
+        else hipLaunchKernelGGL(conv2d_strided_kernel<false>, grid, dim3(256), lds, s, t, in, k, out);
+    } else {
+        if (!(g.mode == PAD_VALID || g.mode == PAD_CONSTANT || (g.mode == PAD_CIRCULAR && g.H % g.stride == 0 && g.W % g.stride == 0)))
+            return 0;
+        t.Hi = g.Ho; t.Wi = g.Wo; t.Ho = g.H; t.Wo = g.W;
+        t.PH = 63 / g.stride + (g.h - 1) / g.stride + 2;
+        t.PWs = 63 / g.stride + (g.w - 1) / g.stride + 2;
+        t.pitch = t.PWs | 1;
+        const size_t lds = ((size_t)g.h * g.w + (size_t)t.PH * t.pitch) * sizeof(float);
+        if (lds > 64 * 1024) return 0;
+        const dim3 grid((g.W + 63) / 64, (g.H + 63) / 64, g.B * g.C);
+        if (g.stride == 4 && g.h == 16 && g.w == 16) hipLaunchKernelGGL(conv2d_strided_transpose_kernel<true>, grid, dim3(256), lds, s, t, in, k, out);
+        else hipLaunchKernelGGL(conv2d_strided_transpose_kernel<false>, grid, dim3(256), lds, s, t, in, k, out);
+    }
+    DINV_CHECK_LAUNCH();
+    *took = 1;
+    return 0;
+}
+
 // ------------------------------------------------------------------ 3-D (volumes [B,C,D,H,W]; conv3d / conv_transpose3d,
 // convolution.py:333-452: the same padding rule per axis, stride 1)
 struct ConvGeom3 {
@@ -798,6 +986,8 @@ extern "C" int dinv_conv2d(const dinv_conv_desc* d, const float* x, const float*
     int took = 0;
     if (int e = launch_tiled(g, false, x, filter, y, reinterpret_cast<hipStream_t>(stream), &took)) return e;
     if (took) return 0;
+    if (int e = launch_strided(g, false, x, filter, y, reinterpret_cast<hipStream_t>(stream), &took)) return e;
+    if (took) return 0;
     hipLaunchKernelGGL(conv2d_pad_kernel, dim3((g.Wo + 63) / 64, (g.Ho + 3) / 4, g.B * g.C), dim3(256),
                        g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, x, filter, y);
     DINV_CHECK_LAUNCH();
@@ -812,6 +1002,8 @@ extern "C" int dinv_conv2d_transpose(const dinv_conv_desc* d, const float* y, co
     DINV_REQUIRE(x && filter && y, "null pointer");
     int took = 0;
     if (int e = launch_tiled(g, true, y, filter, x, reinterpret_cast<hipStream_t>(stream), &took)) return e;
+    if (took) return 0;
+    if (int e = launch_strided(g, true, y, filter, x, reinterpret_cast<hipStream_t>(stream), &took)) return e;
     if (took) return 0;
     hipLaunchKernelGGL(conv2d_pad_transpose_kernel, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.B * g.C), dim3(256),
                        g.h * g.w * sizeof(float), reinterpret_cast<hipStream_t>(stream), g, y, filter, x);

@@ -39,7 +39,11 @@ def _ref_conv(x, k, mode, stride):
 
 @pytest.mark.parametrize("mode", ["valid", "circular", "reflect", "replicate", "constant"])
 @pytest.mark.parametrize("shape", [(2, 3, 12, 15, 1, 1, 3, 3, 1), (1, 2, 16, 16, 1, 2, 5, 5, 2), (2, 1, 20, 12, 2, 1, 4, 4, 4),
-                                   (1, 3, 9, 11, 1, 3, 3, 5, 1)])
+                                   (1, 3, 9, 11, 1, 3, 3, 5, 1),
+                                   # the strided LDS-tiled kernels: several tiles, ragged edges, filters wider than the stride (bicubic x4 =
+                                   # 16 x 16 at stride 4), sizes that the stride does not divide (circular transposed: the general kernel)
+                                   (1, 2, 72, 80, 1, 1, 16, 16, 4), (2, 1, 70, 66, 2, 1, 8, 6, 2), (1, 1, 45, 70, 1, 1, 7, 9, 3),
+                                   (1, 1, 132, 40, 1, 1, 5, 5, 4)])
 def test_conv2d_and_transpose_emulated(mode, shape):
     B, C, H, W, fb, fc, fh, fw, s = shape
     gen = torch.Generator().manual_seed(H * W + fh)
@@ -59,7 +63,10 @@ def test_conv2d_and_transpose_emulated(mode, shape):
     xt = torch.full((B, C, H, W), float("nan"))
     E.check(l.dinv_conv2d_transpose(ctypes.byref(d), E.p(v), E.p(k), E.p(xt), None))
     lhs, rhs = float((y.double() * v.double()).sum()), float((x.double() * xt.double()).sum())
-    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0)
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0, 0.01 * float(y.double().norm() * v.double().norm()))   # (|<Ax, v>| can be small by cancellation)
+    xd = x.double().requires_grad_(True)
+    (_ref_conv(xd, k, mode, s) * v.double()).sum().backward()
+    assert float((xt.double() - xd.grad).norm() / xd.grad.norm()) < 2e-6        # and the adjoint itself against autograd in fp64
     # gradient w.r.t. the filter, per (b, c) plane, against autograd through the fp64 reference convolution with a per-plane filter
     kp = k.expand(B, C, fh, fw).clone().double().requires_grad_(True)
     (_ref_conv(x, kp, mode, s) * v.double()).sum().backward()
