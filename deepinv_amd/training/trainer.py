@@ -109,7 +109,7 @@ class Trainer:
             # the reference stores its histories as {class name: [value per epoch]} (trainer.py:454-480, 1192-1198); this trainer
             # keeps the total loss and the first metric: read either form
             self.train_loss_history = self._history(ck.get("loss"), [l.__class__.__name__ for l in self.losses], self.train_loss_history, total=True)
-            self.eval_metric_history = self._history(ck.get("eval_metrics"), [m.__class__.__name__ for m in self.metrics],
+            self.eval_metric_history = self._history(ck.get("eval_metrics"), [self._metric_name(m) for m in self.metrics],
                                                      self.eval_metric_history)
             self.epoch_start = ck.get("epoch", -1) + 1
         if train and self.optimizer is None:
@@ -256,7 +256,7 @@ class Trainer:
         os.makedirs(self.save_path, exist_ok=True)
         # the reference's fields and their shapes (trainer.py:1192-1198): epoch, state_dict, optimizer, scheduler, and the histories
         # as {name: [value per epoch]} - here the total training loss and the first evaluation metric
-        metric = self.metrics[0].__class__.__name__ if self.metrics else "metric"
+        metric = self._metric_name(self.metrics[0]) if self.metrics else "metric"      # (a plain function has no class name of its own)
         torch.save({"epoch": epoch, "state_dict": self.model.state_dict(), "loss": {"TotalLoss": list(self.train_loss_history)},
                     "optimizer": self.optimizer.state_dict() if self.optimizer else None,
                     "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None,
