@@ -368,8 +368,10 @@ def full_length_cfg5(dinv, dev, d, B=16, precisions=None, runs=1):
             hook = den.register_forward_hook(lambda m, i, o: trace.append(o[:1].detach().reshape(-1)[::stt]))
             # the Gaussian draws of the whole run, made BEFORE the timed region (unit 0 replays the reference's generator stream,
             # the rest of the shard has its own): resident in HBM like every other input
-            g0, g1 = gen(s_draw), gen(704)
-            pool = [torch.cat((torch.randn(1, *img, generator=g0), torch.randn(B - 1, *img, generator=g1))).to(dev)
+            # (unit 0 on the CPU generator whose stream the fixture recorded; the other units' draws are compared with nothing and come
+            # from the device's generator - 100 host draws of 15 images were 8 s of every run of this helper)
+            g0, g1 = gen(s_draw), torch.Generator(device=dev).manual_seed(704)
+            pool = [torch.cat((torch.randn(1, *img, generator=g0).to(dev), torch.randn(B - 1, *img, generator=g1, device=dev)))
                     for _ in range(int(d["steps"]) + 1)]
             pool.reverse()
 
