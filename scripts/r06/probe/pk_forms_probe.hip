@@ -103,6 +103,18 @@ __global__ __launch_bounds__(256, 2) void partner_kernel(float* __restrict__ out
         if (KIND == 2) { d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, d1, 0, 0, 0); }
         if (KIND == 3) { s += lds[(threadIdx.x * 4 + i) & 4095]; s += lds[(threadIdx.x * 8 + 3 * i) & 4095]; }
         if (KIND == 4) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s) : "v"(t)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(t) : "v"(s)); }
+        if (KIND == 5) { d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t, s, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(s, t, d1, 0, 0, 0); }
+        if (KIND == 6) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            const s16x4 a4 = {1, 2, 3, 4}, b4 = {4, 3, 2, 1};
+            d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, b4, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(b4, a4, d1, 0, 0, 0);
+        }
+        if (KIND == 7) {
+            typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+            h16x8 ha, hb;
+            for (int q = 0; q < 8; ++q) { ha[q] = (_Float16)(float)a[q]; hb[q] = (_Float16)(float)b[q]; }
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb, ha, d1, 0, 0, 0);
+        }
     }
     for (int i = 0; i < 16; ++i) s += c0[i] + c1[i];
     out[blockIdx.x * 256 + threadIdx.x] = s + t + d0[0] + d1[1];
@@ -148,10 +160,11 @@ int main(int argc, char** argv) {
     hipStream_t sa, sb; CK(hipStreamCreate(&sa)); CK(hipStreamCreate(&sb));
     const char* names[NF] = {"fma op_sel_hi:[1,0,1]", "fma op_sel_hi:[0,1,1]", "fma plain", "fma op_sel:[1,0,0] hi:[0,1,1]", "fma op_sel:[0,0,1] hi:[1,1,0]",
                              "fma op_sel:[0,1,0] hi:[1,0,1]", "mul op_sel:[0,1] hi:[1,0] -> fma", "mul plain -> add", "add -> fma", "mul op_sel_hi:[0,1] -> add"};
-    const char* pnames[7] = {"none", "conv3x3_wsplit (the product's kernel)", "loop of v_mfma_f32_32x32x16_bf16", "loop of v_mfma_f32_32x32x2_f32",
-                             "loop of v_mfma_f32_16x16x32_bf16", "loop of LDS reads", "loop of v_fma_f32"};
+    const char* pnames[10] = {"none", "conv3x3_wsplit (the product's kernel)", "loop of v_mfma_f32_32x32x16_bf16", "loop of v_mfma_f32_32x32x2_f32",
+                              "loop of v_mfma_f32_16x16x32_bf16", "loop of LDS reads", "loop of v_fma_f32", "loop of v_mfma_f32_16x16x4_f32",
+                              "loop of v_mfma_f32_16x16x16_bf16", "loop of v_mfma_f32_16x16x32_f16"};
     float* pout; CK(hipMalloc(&pout, 2048 * 256 * 4));
-    for (int partner = 0; partner < 7; ++partner) {
+    for (int partner = 0; partner < 10; ++partner) {
         CK(hipMemset(bad, 0, NF * 8 * 4)); CK(hipDeviceSynchronize());
         auto go = [&]() {
             switch (partner) {
@@ -161,6 +174,9 @@ int main(int argc, char** argv) {
                 case 4: hipLaunchKernelGGL(partner_kernel<2>, dim3(2048), dim3(256), 0, sb, pout, 6000); break;
                 case 5: hipLaunchKernelGGL(partner_kernel<3>, dim3(2048), dim3(256), 0, sb, pout, 6000); break;
                 case 6: hipLaunchKernelGGL(partner_kernel<4>, dim3(2048), dim3(256), 0, sb, pout, 20000); break;
+                case 7: hipLaunchKernelGGL(partner_kernel<5>, dim3(2048), dim3(256), 0, sb, pout, 3000); break;
+                case 8: hipLaunchKernelGGL(partner_kernel<6>, dim3(2048), dim3(256), 0, sb, pout, 6000); break;
+                case 9: hipLaunchKernelGGL(partner_kernel<7>, dim3(2048), dim3(256), 0, sb, pout, 6000); break;
                 default: break;
             }
         };
